@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec (+ DDPG updates/sec) of the batched shems_LU1 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one VECTOR step of the hot path over all envs of a rank:
+  mode "train" (default once the DDPG path is built): actor forward + Gaussian noise + scale_action +
+       step! + replay insert for every env, plus `--updates` DDPG updates (BATCH=120) -- the body of
+       the reference's episode! loop (DDPG.jl:195-234) for 65 536 households at once;
+  mode "env": step! only, on pre-generated random targets (populate_memory's inner loop, MPS:12-24).
+Every 72 steps the episode ends and reset! runs (inside the timed region).
+Workload = BASELINE.json configs[2]: 65 536 parallel shems_LU1 envs per GPU, Charger98 synthetic table,
+72-step episodes (weak scaling: each rank owns its own 65 536-env shard; `--envs` overrides).
+Inputs are resident in HBM before the timed region starts.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "master-thesis-deep-reinforcement-learning-ddpg-in-home-energy-management_amd"
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA
+BYTES_PER_ENV_STEP = 92        # obs 36 + action 8 + idx 4 in; obs' 36 + reward 4 + idx 4 out
+EP_LEN = 72
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=720)
+    ap.add_argument("--warmup", type=int, default=72)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--mode", default="auto", choices=["auto", "train", "env"])
+    ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class EnvWorkload:
+    """step! only: random SoC targets, one k_step launch per vector step."""
+
+    name = "env"
+    dtype = "f32/f64"
+
+    def __init__(self, S, torch, n, seed):
+        self.S, self.torch, self.n = S, torch, n
+        self.tab = S.tables.synthetic_table("train", 98)
+        self.env = S.ShemsBatch(n, EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
+                                device=torch.cuda.current_device()).use_torch_stream()
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        self.actions = [torch.rand((n, 2), generator=g, device="cuda", dtype=torch.float32) for _ in range(8)]
+        self.rew32 = torch.empty(n, dtype=torch.float32, device="cuda")
+        self.seed = seed
+        self.t = 0
+        self.episode = 0
+        self.env.reset_(seed, episode=0)
+
+    def step(self):
+        if self.t and self.t % EP_LEN == 0:
+            self.episode += 1
+            v = self.env.view()
+            self.S._capi.check(self.S._capi.lib().shems_reset_seeded_dev(C.byref(v), self.seed, self.episode, self.env._stream()))
+        self.env.step_dev(self.actions[self.t % 8], 0, rewards_f32=self.rew32)
+        self.t += 1
+
+    def finish(self):
+        self.env.check_error()
+
+    def kernel_pass(self, reps):
+        """HIP-event timing of the dominant kernel alone (events on the launch stream)."""
+        torch = self.torch
+        self.env.reset_(self.seed, episode=1000)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            if i and i % (EP_LEN - 1) == 0:
+                self.env.reset_(self.seed, episode=1000 + i)
+            a.record()
+            self.env.step_dev(self.actions[i % 8], 0, rewards_f32=self.rew32)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ms) / len(ms)
+        return dict(kernel="shems::k_step", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+                    bound="hbm", algorithmic=BYTES_PER_ENV_STEP * self.n, unit="GB/s", peak=HBM_PEAK_GBS)
+
+    def extra(self):
+        return {}
+
+
+def cpu_baseline(n_envs, budget_s=12.0):
+    """The CPU oracle (C restatement of shems_LU1.jl, `kind: port`) on this box's host cores: one
+    thread, the same workload (random targets, 72-step episodes), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_c
+    S = importlib.import_module(PKG)
+    tab = S.tables.synthetic_table("train", 98)
+    n = min(n_envs, 16384)
+    b = oracle_c.Batch(n, EP_LEN, tab, oracle_c.profile(98))
+    rng = np.random.default_rng(0)
+    acts = [rng.random((n, 2)).astype(np.float32) for _ in range(4)]
+    idx0 = rng.integers(1, tab.shape[0] - EP_LEN + 1, n)
+    soc0 = (rng.random(n) * 6.75).astype(np.float32)
+    L = oracle_c.lib()
+    rew = np.empty(n)
+    steps = 0
+    t_step = 0.0
+    t_all0 = time.perf_counter()
+    while time.perf_counter() - t_all0 < budget_s:
+        b.reset(False, idx0, soc0)                  # python-loop reset: not timed
+        t0 = time.perf_counter()
+        for t in range(EP_LEN):
+            L.orc_batch_step(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, None, None)
+        t_step += time.perf_counter() - t0
+        steps += n * EP_LEN
+    one = steps / t_step
+    # all host cores (OpenMP over envs), short
+    ncore = os.cpu_count() or 1
+    b.reset(False, idx0, soc0)
+    obs = np.empty((n, 9), np.float32)
+    t0 = time.perf_counter()
+    for t in range(EP_LEN):
+        L.orc_batch_step_omp(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, obs.ctypes.data)
+    allc = n * EP_LEN / (time.perf_counter() - t0)
+    return {"value": one, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes, random targets, {steps} env-steps in {t_step:.1f} s (policy/update not included)",
+            "all_cores_value": allc, "all_cores": ncore}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    S = importlib.import_module(PKG)
+
+    mode = args.mode
+    train_mod = None
+    if mode in ("auto", "train"):
+        try:
+            train_mod = importlib.import_module(PKG + ".ddpg")
+            if not hasattr(train_mod, "TrainWorkload"):
+                train_mod = None
+        except ImportError:
+            train_mod = None
+        if train_mod is None and mode == "train":
+            raise SystemExit("train mode requested but the DDPG path is not built")
+        mode = "train" if train_mod is not None else "env"
+    if mode == "train":
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist)
+    else:
+        wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    wl.finish()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        k = wl.kernel_pass(min(args.steps, 500))
+        achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
+        roof = {"bound": k["bound"], "achieved": achieved, "peak": k["peak"], "unit": k["unit"],
+                "frac": achieved / k["peak"], "traffic": None, "kernel": k["kernel"],
+                "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
+                "algorithmic_per_launch": k["algorithmic"]}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.envs)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        total_env_steps = args.envs * world * args.steps
+        out = {
+            "metric": "env-steps/sec",
+            "value": total_env_steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": wl.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{args.envs} parallel shems_LU1 envs per GPU, Charger98 synthetic train table "
+                                   f"(4320 rows), {EP_LEN}-step episodes, mode={mode}",
+                       "envs_per_gpu": args.envs, "episode_len": EP_LEN, "mode": mode},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        out.update(wl.extra())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

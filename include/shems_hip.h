@@ -1,0 +1,178 @@
+/*
+ * shems_hip.h -- C ABI of libshems_hip.so: the batched, MI355X-native (gfx950)
+ * replacement for the hot path of the reference
+ *   RL-SHEMS/RL_environments/envs/shems_LU1.jl        (LU1, the environment)
+ *   RL-SHEMS/algorithms/DDPG.jl                        (DDPG.jl, act/replay/episode!)
+ *   RL-SHEMS/src/memory_plotting_saving.jl             (MPS, replay buffer + normalisation)
+ *
+ * The reference has no FFI today: LU1 extends the Reinforce.jl generics
+ * `reset!/step!/action/finished` on `Shems <: AbstractEnvironment` (LU1:62-65,169).
+ * Each entry point below names the reference method it replaces; the Julia
+ * `ccall` stubs a maintainer would add are in INTEGRATION.md, and the Python
+ * `ctypes` mirror used by this repo's tests is the package's `_capi.py`.
+ *
+ * Conventions
+ *   - plain C types only; every function returns SHEMS_OK (0) or a negative error
+ *     code, and shems_last_error() returns a thread-local message.
+ *   - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device memory.
+ *   - row / step indices are 1-based at this boundary, exactly as in the Julia code.
+ *   - observation layout is [N][9] float32 = Julia's 9xN column-major Matrix{Float32}
+ *     (state order LU1:101-111: Soc_b, Soc_ev, c_ev, d_e, g_e, p_buy, h_cos, h_sin, season).
+ *   - a table is [nrow][8] float32: h_countdown, soc_ev, electkwh, PV_generation,
+ *     p_buy, hour_cos, hour_sin, season  (the columns LU1:251-260 / 268-279 read).
+ *   - `stream` arguments are a hipStream_t passed as void* (NULL = the legacy default stream).
+ */
+#ifndef SHEMS_HIP_H
+#define SHEMS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHEMS_ABI_VERSION 1
+
+enum {
+    SHEMS_OK          =  0,
+    SHEMS_ERR_ARG     = -1,  /* bad argument (NULL, size, range)                                   */
+    SHEMS_ERR_HIP     = -2,  /* a HIP runtime call failed                                           */
+    SHEMS_ERR_INDEX   = -3,  /* table access out of range: Julia BoundsError (LU1:227,239,265-279) */
+    SHEMS_ERR_NOMEM   = -4,
+    SHEMS_ERR_NODEVICE= -5,  /* no gfx950 device visible: the library never falls back to the CPU   */
+    SHEMS_ERR_STATE   = -6   /* call order (tables/configs not set, not reset)                      */
+};
+
+enum { SHEMS_NSTATE = 9, SHEMS_NACTION = 2, SHEMS_NCOL = 8, SHEMS_NRESULT = 23 };
+
+/* track modes of step!(env, s, a; track) (LU1:343-354, 466-484) */
+enum {
+    SHEMS_TRACK_OFF   = 0,   /* track == 0 : a = SoC targets in [0,1]                               */
+    SHEMS_TRACK_DRL   = 1,   /* track  > 0 : same, plus the 23-column results row (LU1:476-478)     */
+    SHEMS_TRACK_RULE  = -1   /* track  < 0 : a = kWh set-points (B, EV); penalty forced to 0        */
+};
+
+/* One "config" = what the reference spreads over module globals and env.path:
+ * charger capacities (LU1:47-59), Battery/EV/Market constants (LU1:92-99), reward weights
+ * (LU1:40-43; per-env in the discomfort-weight sweep) and the input table (env.path, LU1:176). */
+typedef struct shems_config {
+    float   cap_ev;          /* ev.soc_max  [kWh]   capacities[id][1]                               */
+    float   soc_max;         /* b.soc_max   [kWh]   capacities[id][2] (an f32 product, e.g. 7.5f0*0.9f0) */
+    double  rate_max;        /* b.rate_max  [kW]    capacities[id][3] (Float64)                     */
+    double  disc_weight;     /* m.discomfort_weight_ev = Float64(DISCOMFORT_WEIGHT_EV::Float32)     */
+    double  disc_pot;        /* m.disc_pot             = Float64(DISC_POT::Float32)                 */
+    float   penalty_weight;  /* penalty_weight::Float32 (LU1:43)                                    */
+    int32_t table_row0;      /* 0-based first row of this config's table in the uploaded row array  */
+    int32_t nrow;            /* nrow(df) of that table                                              */
+    int32_t reserved;
+} shems_config;              /* 48 bytes */
+
+typedef struct shems_env shems_env;      /* opaque: N parallel Shems instances on one GPU */
+
+/* ------------------------------------------------------------------ library -- */
+int         shems_abi_version(void);
+const char *shems_last_error(void);
+int         shems_device_count(int *out_count);
+
+/* ------------------------------------------------- handle API (host arrays) -- */
+/* Shems(maxsteps, path) x n_envs (LU1:203; called from input.jl:162-164).  Selects `device`
+ * (the reference: CUDA.device!(GPU_ID), DDPG_reinforce_charger_v1.jl:12-14). */
+int shems_create(int64_t n_envs, int32_t maxsteps, int device, shems_env **out);
+int shems_destroy(shems_env *env);
+int shems_n_envs(const shems_env *env, int64_t *out);
+
+/* Replaces CSV.read(env.path, DataFrame) (LU1:217, 265): all tables, concatenated row-wise,
+ * are uploaded once.  rows = [total_rows][8] float32 host memory. */
+int shems_set_tables(shems_env *env, const float *rows, int64_t total_rows);
+/* Replaces the module globals LU1:40-59, 92-99.  cfg_of_env = [n_envs] host indices into cfgs
+ * (NULL: every env uses cfgs[0]). */
+int shems_set_configs(shems_env *env, const shems_config *cfgs, int32_t n_cfg,
+                      const uint16_t *cfg_of_env);
+
+/* reset!(env; rng) (LU1:206-262).  rng_minus1 != 0  <=>  rng == -1: Soc_b = 0.5*(soc_min+soc_max),
+ * idx = 1.  Otherwise the two MersenneTwister draws are inputs: idx0[i] in 1..(nrow-maxsteps)
+ * (1-based) and soc_b0[i]; the episode-extension loop LU1:227-246 runs on the device. */
+int shems_reset(shems_env *env, int rng_minus1, const int32_t *idx0, const float *soc_b0);
+/* Same, with both draws taken from the library's counter-based generator (Philox4x32-10):
+ * idx0 = 1 + x0 mod (nrow-maxsteps), soc_b0 = float(x1 >> 8) * 2^-24 * soc_max,
+ * (x0,x1,..) = philox(key = seed, counter = (env index, episode, 0, 0)). */
+int shems_reset_seeded(shems_env *env, uint64_t seed, uint32_t episode);
+
+/* step!(env, s, a; track) (LU1:343-485).  actions = [n][2] host float32.  Outputs (each may be
+ * NULL): rewards [n] Float64, obs [n][9] (= Vector{Float32}(env.state)), results [n][23] Float64
+ * (column order LU1:476-478; written for every track_mode if non-NULL).
+ * Returns SHEMS_ERR_INDEX (and steps no env past the table) if any env has idx+1 > nrow. */
+int shems_step(shems_env *env, const float *actions, int track_mode,
+               double *rewards, float *obs, double *results);
+
+/* action(env, a::ShemsAction) (LU1:283-316): targets [n][2] -> kWh set-points [n][2] (B, EV). */
+int shems_action(shems_env *env, const float *targets, float *out_b_ev);
+/* action(env, track) (LU1:318-340), the rule-based controller -> [n][2] (B, EV). */
+int shems_rule_action(shems_env *env, float *out_b_ev);
+/* finished(env, s') (LU1:487-502): always false; done = [n] bytes. */
+int shems_finished(shems_env *env, uint8_t *done);
+
+/* env.state / env.idx / env.step accessors (LU1:169-177).  Any pointer may be NULL. */
+int shems_get_state(shems_env *env, float *obs, int32_t *idx, int32_t *step);
+int shems_set_state(shems_env *env, const float *obs, const int32_t *idx, const int32_t *step);
+
+/* ----------------------------------------- device-pointer (zero-copy) API -- */
+/* Device views of a handle, for chaining with the policy / DDPG kernels without host copies. */
+typedef struct shems_view {
+    int64_t  n_envs;
+    int32_t  maxsteps;
+    int32_t  n_cfg;
+    float   *obs;            /* dev [n][9]                         */
+    int32_t *idx;            /* dev [n]   1-based row index        */
+    int32_t *step;           /* dev [n]                            */
+    const uint16_t     *cfg_of_env;   /* dev [n]                   */
+    const shems_config *cfgs;         /* dev [n_cfg]               */
+    const float        *tables;       /* dev [total_rows][8]       */
+    int64_t  total_rows;
+    int32_t *err;            /* dev [1]: sticky error word (SHEMS_ERR_*) set by kernels */
+} shems_view;
+int shems_get_view(shems_env *env, shems_view *out);
+int shems_set_stream(shems_env *env, void *stream);     /* stream used by the handle API         */
+int shems_check_error(shems_env *env);                  /* syncs, reads + clears view.err          */
+
+/* step! on device buffers.  d_actions [n][2]; optional outputs: d_rewards [n] Float64,
+ * d_rewards_f32 [n] (the Float32 the replay buffer keeps, MPS:37 + gpu()), d_results [n][23],
+ * d_block_reward [ceil(n/256)] per-workgroup reward sums (wavefront reduction). */
+int shems_step_dev(const shems_view *v, const float *d_actions, int track_mode,
+                   double *d_rewards, float *d_rewards_f32, double *d_results,
+                   double *d_block_reward, void *stream);
+int shems_action_dev(const shems_view *v, const float *d_targets, int rule_based,
+                     float *d_out_b_ev, void *stream);
+int shems_reset_dev(const shems_view *v, int rng_minus1, const int32_t *d_idx0,
+                    const float *d_soc_b0, void *stream);
+int shems_reset_seeded_dev(const shems_view *v, uint64_t seed, uint32_t episode, void *stream);
+
+/* Whole-episode rollout without host round trips: `nsteps` x { a = policy; step! } in ONE launch,
+ * env state held in registers.  policy = SHEMS_ROLLOUT_RULE: a = action(env, track), track < 0
+ * (BASELINE config 1 at scale, MPS:62-71 + DDPG.jl:209-212); SHEMS_ROLLOUT_RANDOM: uniform random
+ * actions in [-1,1] -> scale_action (populate_memory, MPS:9-29), Philox keyed by (seed, env, step).
+ * d_returns [n] Float64 episode sums (DDPG.jl:223).  If ring != NULL every transition is appended
+ * to the replay ring (see shems_replay below) at slot (ring_pos + env*nsteps + t) mod capacity,
+ * i.e. in the reference's episode-major push order. */
+enum { SHEMS_ROLLOUT_RULE = 0, SHEMS_ROLLOUT_RANDOM = 1 };
+struct shems_replay;
+int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t seed,
+                      double *d_returns, const struct shems_replay *ring, int64_t ring_pos,
+                      void *stream);
+
+/* ------------------------------------------------------------ replay ring -- */
+/* memory = CircularBuffer{Any}(MEM_SIZE) of [s, a, r, s', done] (input.jl:139-140, MPS:46-47),
+ * kept in HBM as struct-of-arrays.  `a` is the UNSCALED policy output in [-1,1] (DDPG.jl:229). */
+typedef struct shems_replay {
+    int64_t  capacity;       /* MEM_SIZE                                   */
+    float   *s;              /* dev [capacity][9]                          */
+    float   *a;              /* dev [capacity][2]                          */
+    float   *r;              /* dev [capacity]    Float32(reward)          */
+    float   *s2;             /* dev [capacity][9]                          */
+    uint8_t *done;           /* dev [capacity]                             */
+} shems_replay;              /* the push position is host state and is passed by value */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHEMS_HIP_H */

@@ -1,0 +1,34 @@
+"""GPU-resident circular replay buffer (host-side bookkeeping; the data lives in HBM).
+
+Reference: `memory = CircularBuffer{Any}(MEM_SIZE)` of `[s, a, r, s', done]` (input.jl:139-140),
+`remember` (memory_plotting_saving.jl:46-47), `getData` (:31-42).  Here: struct-of-arrays device
+tensors (PyTorch is only the allocator) + a host push counter; kernels receive the raw pointers
+through `shems_replay` (include/shems_hip.h).
+"""
+from __future__ import annotations
+
+from . import _capi
+
+
+class ReplayRing:
+    def __init__(self, capacity, device="cuda:0"):
+        import torch
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        self.s = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
+        self.a = torch.zeros((self.capacity, _capi.NACTION), dtype=torch.float32, device=self.device)
+        self.r = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)
+        self.s2 = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
+        self.done = torch.zeros((self.capacity,), dtype=torch.uint8, device=self.device)
+        self.pushed = 0                      # total transitions ever pushed (host state)
+
+    def __len__(self):                       # length(memory)
+        return min(self.pushed, self.capacity)
+
+    @property
+    def pos(self):
+        return self.pushed % self.capacity
+
+    def struct(self):
+        return _capi.Replay(self.capacity, self.s.data_ptr(), self.a.data_ptr(), self.r.data_ptr(),
+                            self.s2.data_ptr(), self.done.data_ptr())

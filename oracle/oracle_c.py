@@ -1,0 +1,192 @@
+"""ctypes binding of oracle/libshems_oracle.so (the C restatement of shems_LU1.jl).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libshems_oracle.so")
+
+
+class Profile(C.Structure):
+    _fields_ = [("cap_ev", C.c_float), ("soc_max", C.c_float), ("rate_max", C.c_double),
+                ("disc_weight", C.c_double), ("disc_pot", C.c_double), ("penalty_weight", C.c_float)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("shems_oracle.c", "shems_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libshems_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_SO)
+    vp, i64, fp, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.orc_profile_for_charger.argtypes = [C.c_int, C.POINTER(Profile)]
+    L.orc_env_init.argtypes = [vp, i64, vp, i64, C.POINTER(Profile)]
+    L.orc_env_init.restype = None
+    L.orc_resolve_start.argtypes = [vp, i64, i64, i64, C.POINTER(C.c_int)]
+    L.orc_resolve_start.restype = i64
+    L.orc_reset.argtypes = [vp, C.c_int, i64, C.c_float]
+    L.orc_action_drl.argtypes = [vp, C.c_float, C.c_float, fp]
+    L.orc_action_drl.restype = None
+    L.orc_action_rule.argtypes = [vp, fp]
+    L.orc_action_rule.restype = None
+    L.orc_step.argtypes = [vp, fp, C.c_int, dp, dp]
+    L.orc_scale_action.argtypes = [C.c_float]
+    L.orc_scale_action.restype = C.c_float
+    L.orc_batch_step.argtypes = [vp, i64, vp, C.c_int, vp, vp, vp]
+    L.orc_batch_step_omp.argtypes = [vp, i64, vp, C.c_int, vp, vp]
+    L.orc_rule_episode.argtypes = [vp, i64, vp]
+    L.orc_rule_episode.restype = C.c_double
+    L.orc_batch_alloc.argtypes = [i64]
+    L.orc_batch_alloc.restype = vp
+    L.orc_batch_free.argtypes = [vp]
+    L.orc_batch_free.restype = None
+    L.orc_batch_at.argtypes = [vp, i64]
+    L.orc_batch_at.restype = vp
+    L.orc_env_idx.argtypes = [vp]
+    L.orc_env_idx.restype = i64
+    L.orc_env_step.argtypes = [vp]
+    L.orc_env_step.restype = i64
+    L.orc_env_get_state.argtypes = [vp, vp]
+    L.orc_env_get_state.restype = None
+    L.orc_env_set_state.argtypes = [vp, vp, i64, i64]
+    L.orc_env_set_state.restype = None
+    _lib = L
+    return L
+
+
+def profile(charger_id=98, disc_weight=None, disc_pot=None, penalty_weight=None):
+    p = Profile()
+    if lib().orc_profile_for_charger(charger_id, C.byref(p)) != 0:
+        raise KeyError(charger_id)
+    if disc_weight is not None:
+        p.disc_weight = float(np.float32(disc_weight))
+    if disc_pot is not None:
+        p.disc_pot = float(np.float32(disc_pot))
+    if penalty_weight is not None:
+        p.penalty_weight = float(np.float32(penalty_weight))
+    return p
+
+
+class Batch:
+    """n scalar oracle envs sharing tables (kept alive here)."""
+
+    def __init__(self, n, maxsteps, tables, profiles, table_of_env=None, profile_of_env=None):
+        L = lib()
+        self.n = int(n)
+        self.maxsteps = int(maxsteps)
+        self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in (tables if isinstance(tables, (list, tuple)) else [tables])]
+        self.profiles = list(profiles) if isinstance(profiles, (list, tuple)) else [profiles]
+        self.ptr = L.orc_batch_alloc(self.n)
+        to = np.zeros(self.n, np.int64) if table_of_env is None else np.asarray(table_of_env)
+        po = np.zeros(self.n, np.int64) if profile_of_env is None else np.asarray(profile_of_env)
+        for i in range(self.n):
+            t = self.tables[int(to[i])]
+            L.orc_env_init(L.orc_batch_at(self.ptr, i), self.maxsteps, t.ctypes.data, t.shape[0],
+                           C.byref(self.profiles[int(po[i])]))
+
+    def __del__(self):
+        try:
+            lib().orc_batch_free(self.ptr)
+        except Exception:
+            pass
+
+    def at(self, i):
+        return lib().orc_batch_at(self.ptr, i)
+
+    def reset(self, rng_is_minus1=True, idx0=None, soc_b0=None):
+        L = lib()
+        rc = 0
+        for i in range(self.n):
+            rc |= L.orc_reset(self.at(i), 1 if rng_is_minus1 else 0,
+                              1 if idx0 is None else int(idx0[i]),
+                              0.0 if soc_b0 is None else float(np.float32(soc_b0[i])))
+        return rc
+
+    def set_state(self, obs, idx, step=None):
+        L = lib()
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        for i in range(self.n):
+            L.orc_env_set_state(self.at(i), obs[i].ctypes.data, int(idx[i]), 0 if step is None else int(step[i]))
+
+    def state(self):
+        L = lib()
+        out = np.empty((self.n, 9), np.float32)
+        for i in range(self.n):
+            L.orc_env_get_state(self.at(i), out[i].ctypes.data)
+        return out
+
+    def idx(self):
+        L = lib()
+        return np.array([L.orc_env_idx(self.at(i)) for i in range(self.n)], np.int64)
+
+    def steps(self):
+        L = lib()
+        return np.array([L.orc_env_step(self.at(i)) for i in range(self.n)], np.int64)
+
+    def action_drl(self, targets):
+        L = lib()
+        targets = np.asarray(targets, np.float32)
+        out = np.empty((self.n, 2), np.float32)
+        for i in range(self.n):
+            L.orc_action_drl(self.at(i), float(targets[i, 0]), float(targets[i, 1]),
+                             out[i].ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def action_rule(self):
+        L = lib()
+        out = np.empty((self.n, 2), np.float32)
+        for i in range(self.n):
+            L.orc_action_rule(self.at(i), out[i].ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def step(self, actions, track_mode=0, want_results=False, omp=False):
+        L = lib()
+        actions = np.ascontiguousarray(actions, dtype=np.float32)
+        assert actions.shape == (self.n, 2)
+        rewards = np.empty(self.n, np.float64)
+        obs = np.empty((self.n, 9), np.float32)
+        if omp:
+            rc = L.orc_batch_step_omp(self.ptr, self.n, actions.ctypes.data, track_mode,
+                                      rewards.ctypes.data, obs.ctypes.data)
+            return rc, rewards, obs, None
+        res = np.empty((self.n, 23), np.float64) if want_results else None
+        rc = L.orc_batch_step(self.ptr, self.n, actions.ctypes.data, track_mode, rewards.ctypes.data,
+                              obs.ctypes.data, res.ctypes.data if want_results else None)
+        return rc, rewards, obs, res
+
+    def rule_episode(self, i, steps, want_results=False):
+        L = lib()
+        res = np.empty((steps, 23), np.float64) if want_results else None
+        tot = L.orc_rule_episode(self.at(i), steps, res.ctypes.data if want_results else None)
+        return tot, res
+
+
+def resolve_start(table, maxsteps, idx0):
+    t = np.ascontiguousarray(table, dtype=np.float32)
+    it = C.c_int(0)
+    r = lib().orc_resolve_start(t.ctypes.data, t.shape[0], maxsteps, int(idx0), C.byref(it))
+    return int(r), it.value
+
+
+def scale_action(a):
+    a = np.asarray(a, np.float32)
+    return np.array([lib().orc_scale_action(float(x)) for x in a.ravel()], np.float32).reshape(a.shape)

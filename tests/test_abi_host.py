@@ -1,0 +1,96 @@
+"""CPU tests: the C-ABI library loads and exports what include/shems_hip.h declares; host logic
+(tables, configs) behaves; without a GPU the product path fails loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import util as U
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    S = U.pkg()
+    L = S._capi.lib()
+    names = S._capi.exported_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/shems_hip.h but not exported by libshems_hip.so"
+    assert L.shems_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built_lib]).decode()
+    exported = set(re.findall(r" T (shems_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+    # nothing torch-typed crosses the boundary: the library does not link libtorch
+    deps = subprocess.check_output(["ldd", built_lib]).decode()
+    assert "torch" not in deps and "amdhip64" in deps
+
+
+def test_struct_layouts_match_header():
+    S = U.pkg()
+    assert C.sizeof(S._capi.Config) == 48
+    assert S._capi.Config.rate_max.offset == 8 and S._capi.Config.penalty_weight.offset == 32
+    assert S._capi.Config.table_row0.offset == 36 and S._capi.Config.nrow.offset == 40
+    assert C.sizeof(S._capi.View) == 80 and S._capi.View.obs.offset == 16
+    assert C.sizeof(S._capi.Replay) == 48
+    assert C.sizeof(U.HCConfig) == 48
+
+
+def test_gpu_code_object_is_gfx950(built_lib):
+    blob = open(built_lib, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob[:0]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: covered by the gpu tests")
+def test_no_device_fails_loudly(built_lib):
+    S = U.pkg()
+    with pytest.raises(S.ShemsError) as ei:
+        S.ShemsBatch(4, 72, S.tables.synthetic_table("train"))
+    assert ei.value.code == S._capi.ERR_NODEVICE and "no CPU path" in str(ei.value)
+
+
+def test_make_config_values():
+    S = U.pkg()
+    c = S.make_config(98, 0, 4320)
+    assert c.cap_ev == np.float32(35.816) and c.soc_max == np.float32(6.75) and c.rate_max == 3.3
+    assert c.disc_weight == float(np.float32(0.01)) and c.disc_pot == 2.0 and c.penalty_weight == np.float32(0.1)
+    for cid in U.CHARGER_IDS + [97]:
+        p = U.oracle_c.profile(cid)
+        k = S.make_config(cid, 0, 10)
+        assert (k.cap_ev, k.soc_max, k.rate_max) == (p.cap_ev, p.soc_max, p.rate_max)
+        q = U.onp.Profile(cid)
+        assert (np.float32(k.cap_ev), np.float32(k.soc_max)) == (q.ev_soc_max, q.b_soc_max)
+
+
+def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
+    T = U.tables_mod()
+    for split in ("train", "eval", "test"):
+        t = T.synthetic_table(split, 98)
+        assert t.shape == (T.SPLIT_ROWS[split], 8) and t.dtype == np.float32
+        h = t[:, 0]
+        assert h.min() == -1 and h.max() <= 71 and (h == np.round(h)).all()
+        zero = np.where(h[:-1] == 0)[0]
+        assert (h[zero + 1] == -1).all() and (t[zero + 1, 1] == 1).all()        # row after a 0 is -1 / soc 1
+        assert 0.25 < (h >= 0).mean() < 0.5
+        assert (t[h == -1, 1] == 1).all() and (t[:, 4] == np.float32(0.4)).all()
+        assert set(np.unique(t[:, 7])) <= {1.0, 2.0, 3.0, 4.0}
+        dec = np.where((h[1:] >= 0) & (h[:-1] >= 0))[0]
+        assert (h[dec + 1] == h[dec] - 1).all()                                  # countdown decrements
+    a, b = T.synthetic_table("train", 98), T.synthetic_table("train", 98)
+    assert (a == b).all() and not (a == T.synthetic_table("train", 4)).all()
+    p = tmp_path / "t.csv"
+    T.save_csv(p, a)
+    assert (U.bits32(T.load_csv(p)) == U.bits32(a)).all()
+    # 21-column reference schema with extra columns in a different order
+    hdr = "electkwh,PV_generation,chargekwh,h_countdown,soc_ev,month,day,hour,nday,d_res,hour_cos,hour_sin,month_cos,month_sin,spring,summer,autumn,winter,season,p_buy,p_sell"
+    with open(tmp_path / "r.csv", "w") as fh:
+        fh.write(hdr + "\n")
+        for r in a[:50]:
+            v = dict(zip(T.COLUMNS, r))
+            fh.write(",".join(repr(float(v.get(c, 0.0))) for c in hdr.split(",")) + "\n")
+    assert (T.load_csv(tmp_path / "r.csv") == a[:50]).all()
+    with open(tmp_path / "bad.csv", "w") as fh:
+        fh.write("electkwh,PV_generation\n1,2\n")
+    with pytest.raises(KeyError):
+        T.load_csv(tmp_path / "bad.csv")

@@ -1,0 +1,243 @@
+"""CPU tests of the oracle (test infrastructure): the C restatement and its NumPy twin against
+the known-answer vectors of SURVEY.md Appendix B, against each other, against the committed
+oracle goldens, and against the conservation invariants of SURVEY.md A.4.
+
+"Parity unpinned by the reference": none of these vectors was produced by the Julia code (Julia
+is not installed, the reference has no tests and its artefacts are LFS stubs)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import util as U
+from util import onp, oracle_c
+
+GOLD = os.path.join(U.ROOT, "tests", "golden")
+
+
+def _kats():
+    return json.load(open(os.path.join(GOLD, "kat_appendix_b.json")))["cases"]
+
+
+def _hex32(x):
+    return struct.pack(">f", float(np.float32(x))).hex()
+
+
+def _kat_table(k):
+    st, nx = k["state"], k["next"]
+    tab = np.zeros((2, 8), np.float32)
+    tab[0] = [k["h_cur"], st[1], st[3], st[4], 0.4, 1, 0, 1]
+    tab[1] = [nx[2], nx[3], nx[0], nx[1], 0.4, 1, 0, 1]
+    obs = np.array([st[0], st[1], st[2], st[3], st[4], 0.4, 1, 0, 1], np.float32)
+    return tab, obs
+
+
+def _check_kat(k, B, EV, reward, s2, res):
+    assert float(B) == float(np.float32(k["B"])), k["name"]
+    assert abs(float(EV) - k["EV"]) <= 1e-9 * max(1.0, abs(k["EV"])) or float(EV) == float(np.float32(k["EV"])), k["name"]
+    assert reward == pytest.approx(k["reward"], rel=1e-15, abs=1e-17), k["name"]
+    assert _hex32(s2[0]) == k["soc_b_hex"], k["name"]
+    if "soc_ev_hex" in k:
+        assert _hex32(s2[1]) == k["soc_ev_hex"], k["name"]
+    else:
+        assert float(s2[1]) == k["soc_ev"], k["name"]
+    if "profit" in k:
+        assert res[6] == pytest.approx(k["profit"], rel=1e-15)
+    if "discomfort" in k:
+        assert res[7] == k["discomfort"]
+    if "penalty" in k:
+        assert res[8] == pytest.approx(k["penalty"], rel=1e-15)
+
+
+@pytest.mark.parametrize("k", _kats(), ids=lambda k: k["name"])
+def test_kat_numpy_twin(k):
+    tab, obs = _kat_table(k)
+    e = onp.Env(72, tab, onp.Profile(98))
+    e.state[:] = obs
+    e.idx = 1
+    a = e.action_rule() if k["a"] is None else np.array(k["a"], np.float32)
+    r, s2, res = e.step_(a, track=(-0.5 if k["mode"] < 0 else 1))
+    _check_kat(k, res[20], res[3], float(r), s2, res)
+    assert e.idx == 2 and e.step == 1 and not e.finished()
+
+
+@pytest.mark.parametrize("k", _kats(), ids=lambda k: k["name"])
+def test_kat_c_oracle(k):
+    tab, obs = _kat_table(k)
+    b = oracle_c.Batch(1, 72, tab, oracle_c.profile(98))
+    b.set_state(obs[None], [1])
+    a = b.action_rule() if k["a"] is None else np.array([k["a"]], np.float32)
+    rc, r, s2, res = b.step(a, -1 if k["mode"] < 0 else 1, want_results=True)
+    assert rc == 0
+    _check_kat(k, res[0, 20], res[0, 3], float(r[0]), s2[0], res[0])
+    assert b.idx()[0] == 2 and b.steps()[0] == 1
+
+
+def test_c_vs_numpy_vs_hostcheck_bit_exact():
+    cases = U.single_step_cases(20241004, 6000)
+    prof = U.oracle_profile(98)
+    rc, oc, resc = U.run_oracle_c(cases, prof)
+    rh, oh, fl, bev = U.run_hostcheck(cases, prof)
+    assert (U.bits64(rc) == U.bits64(rh)).all()
+    assert (U.bits32(oc) == U.bits32(oh)).all()
+    assert (U.bits64(np.concatenate([resc[:, 9:18], resc[:, 6:9]], 1)) == U.bits64(fl)).all()
+    assert (U.bits32(resc[:, [20, 3]].astype(np.float32)) == U.bits32(bev)).all()
+    n = 2000
+    sub = {k: v[:n] for k, v in cases.items()}
+    rn, on_, resn = U.run_oracle_np(sub)
+    assert (U.bits64(rc[:n]) == U.bits64(rn)).all()
+    assert (U.bits32(oc[:n]) == U.bits32(on_)).all()
+    assert (U.bits64(resc[:n]) == U.bits64(resn)).all()
+    # the generator must actually exercise the branches
+    assert (resc[:, 20] < -0.01).mean() > 0.2 and (resc[:, 20] > 0.01).mean() > 0.1
+    assert (resc[:, 7] > 0).mean() > 0.03 and (resc[:, 8] > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("cid,w,pot,pen", [(4, 0.04, 2.0, 0.1), (6, 1.0, 1.0, 0.0), (9, 0.1, 1.0, 1.0), (1, 0.01, 1.5, 0.1)])
+def test_profiles_and_weight_sweep(cid, w, pot, pen):
+    cases = U.single_step_cases(cid, 1500)
+    prof = U.oracle_profile(cid, w, pot, pen)
+    rc, oc, resc = U.run_oracle_c(cases, prof)
+    rh, oh, fl, _ = U.run_hostcheck(cases, prof)
+    rn, on_, resn = U.run_oracle_np(cases, cid, w, pot, pen)
+    if pot in (1.0, 2.0):
+        assert (U.bits64(rc) == U.bits64(rh)).all() and (U.bits64(rc) == U.bits64(rn)).all()
+    else:   # general pow(): libm implementations may differ in the last ulp
+        np.testing.assert_allclose(rc, rh, rtol=1e-12)
+        np.testing.assert_allclose(rc, rn, rtol=1e-12)
+    assert (U.bits32(oc) == U.bits32(oh)).all() and (U.bits32(oc) == U.bits32(on_)).all()
+
+
+def test_invariants_a4():
+    cases = U.single_step_cases(7, 6000, rule_fraction=0.0)
+    prof = U.oracle_profile(98)
+    r, s2, res = U.run_oracle_c(cases, prof)
+    PV_DE, B_DE, GR_DE, PV_B, PV_GR, PV_EV, B_EV, GR_EV, EX_EV, GR_B, B_GR = (res[:, i] for i in range(9, 20))
+    d_e, g_e = cases["obs"][:, 3].astype(np.float64), cases["obs"][:, 4].astype(np.float64)
+    EV = res[:, 3]
+    eta = float(np.float32(0.95))
+    np.testing.assert_allclose(PV_DE + B_DE + GR_DE, d_e, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(PV_EV + B_EV + GR_EV, EV, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(PV_DE + PV_EV + PV_B / eta + PV_GR, g_e, rtol=0, atol=4e-6)
+    assert (GR_B == 0).all() and (B_GR == 0).all()
+    # energy never created: Soc_b' <= Soc_b + PV_B; never negative beyond rounding
+    assert (s2[:, 0] >= -1e-6).all()
+    # idx / c_ev bookkeeping
+    assert (res[:, 0] == 2).all()
+    assert (s2[:, 2] == cases["row_next"][:, 0]).all()
+    # departure resets Soc_ev to 1 when below
+    dep = (cases["obs"][:, 2] == 0) & (res[:, 7] > 0)
+    assert dep.any() and (s2[dep, 1] == 1.0).all()
+
+
+def test_clamp_semantics_lo_gt_hi():
+    # BD = clamp(-B, 0.001, hi) with hi < 0.001: Base.clamp gives hi when -B > hi, else lo
+    prof = U.oracle_profile(98)
+    obs = np.array([[5e-4, 1.0, -1, 1.0, 0.0, 0.4, 1, 0, 1]], np.float32)
+    row = np.array([[-1, 1, 1.0, 0.0, 0.4, 1, 0, 1]], np.float32)
+    for b_set, expect_bd in [(-0.5, None), (-0.0101, None)]:
+        cases = dict(obs=obs, row_cur=row, row_next=row, act=np.array([[b_set, 0.0]], np.float32), mode=np.array([-1], np.int32))
+        r, s2, res = U.run_oracle_c(cases, prof)
+        hi = float(np.float32(np.float32(np.float32(1) - np.float32(0.00003) - np.float32(1e-7)) * np.float32(5e-4)))
+        bd = hi if -b_set > hi else 0.001
+        assert res[0, 10] == pytest.approx(bd * float(np.float32(0.95)), rel=1e-15)   # B_DE = BD * eta
+
+
+def test_resolve_start_matches_table_and_hostcheck():
+    T = U.tables_mod()
+    tab = T.synthetic_table("train", 98)
+    tbl = T.episode_start_table(tab, 72)
+    H = U.hostcheck_lib()
+    for idx0 in list(range(1, 400)) + [4000, 4247, 4248]:
+        ref, it = oracle_c.resolve_start(tab, 72, idx0)
+        assert ref == tbl[idx0 - 1]
+        assert H.hc_resolve_start(tab.ctypes.data_as(C.POINTER(C.c_float)), tab.shape[0], 72, idx0) == ref
+        e = onp.Env(72, tab, onp.Profile(98))
+        assert e.resolve_start(idx0)[0] == ref
+        # the resolved window ends outside a transaction unless the loop gave up
+        if it <= 100 and ref < tab.shape[0] - 72:
+            assert tab[ref + 72 - 1, 0] == -1
+    # eval split: nrow - maxsteps = 1 => always idx = 1 (DDPG.jl:266-293 / SURVEY R17)
+    ev = T.synthetic_table("eval", 98)
+    assert oracle_c.resolve_start(ev, 1439, 1)[0] == 1
+
+
+def test_reset_rng_minus1_and_scale_action():
+    T = U.tables_mod()
+    tab = T.synthetic_table("train", 98)
+    b = oracle_c.Batch(2, 72, tab, oracle_c.profile(98))
+    assert b.reset(True) == 0
+    s = b.state()
+    assert (s[:, 0] == np.float32(3.375)).all() and (b.idx() == 1).all() and (b.steps() == 0).all()
+    assert (s[0, 1:] == tab[0, [1, 0, 2, 3, 4, 5, 6, 7]]).all()
+    a = np.array([-1, -0.5, 0, 0.3, 1, 0.1234567], np.float32)
+    want = ((a.astype(np.float64) + 1.0) * 0.5).astype(np.float32)
+    assert (oracle_c.scale_action(a) == want).all()
+    assert (onp.scale_action(a) == want).all()
+    H = U.hostcheck_lib()
+    H.hc_scale_action.restype = C.c_float
+    H.hc_scale_action.argtypes = [C.c_float]
+    assert all(H.hc_scale_action(float(x)) == float(w) for x, w in zip(a, want))
+
+
+def test_step_past_table_is_bounds_error():
+    tab = np.zeros((3, 8), np.float32)
+    tab[:, 0] = -1
+    b = oracle_c.Batch(1, 1, tab, oracle_c.profile(98))
+    b.reset(True)
+    a = np.zeros((1, 2), np.float32)
+    assert b.step(a)[0] == 0 and b.step(a)[0] == 0
+    assert b.step(a)[0] == -1 and b.idx()[0] == 3          # idx + 1 > nrow: Julia BoundsError
+    e = onp.Env(1, tab, onp.Profile(98)).reset(True)
+    e.step_(a[0]); e.step_(a[0])
+    with pytest.raises(IndexError):
+        e.step_(a[0])
+
+
+def test_oracle_goldens_and_rule_episode():
+    T = U.tables_mod()
+    g = np.load(os.path.join(GOLD, "oracle_golden.npz"))
+    tab = T.synthetic_table("train", 98)
+    assert (np.frombuffer(hashlib.sha256(tab.tobytes()).digest(), np.uint8) == g["table_sha"]).all(), \
+        "synthetic_table() changed: regenerate tests/golden with make_fixtures.py"
+    prof = oracle_c.profile(98)
+    b = oracle_c.Batch(1, 72, tab, prof)
+    total, res = b.rule_episode(0, 72, want_results=True)
+    assert total == float(g["rule_total"]) and (U.bits64(res) == U.bits64(g["rule_results"])).all()
+    # numpy twin runs the same episode
+    e = onp.Env(72, tab, onp.Profile(98)).reset(True)
+    tot = np.float64(0)
+    for t in range(72):
+        r, s2, rr = e.step_(e.action_rule(), track=-0.5)
+        tot += r
+        assert (U.bits64(rr) == U.bits64(res[t])).all()
+    assert float(tot) == total
+    # DRL goldens
+    n = 64
+    b2 = oracle_c.Batch(n, 72, tab, prof)
+    b2.reset(False, g["drl_idx0"], g["drl_soc0"])
+    assert (b2.idx() == g["drl_start_idx"]).all()
+    for t in range(72):
+        k = np.arange(n) * 72 + t
+        act = np.stack([((k * 2654435761) % 1000) / 999.0, ((k * 40503 + 7) % 1000) / 999.0], 1).astype(np.float32)
+        rc, r, obs, _ = b2.step(act, 0)
+        assert rc == 0 and (U.bits64(r) == U.bits64(g["drl_rewards"][t])).all()
+    assert (U.bits32(b2.state()) == U.bits32(g["drl_final_obs"])).all()
+
+
+def test_reconstructed_charger98_series_runs():
+    """The Charger98 test series reconstructed from the reference's MPC result file: first row is the
+    K1 state (Soc_b 3.375, d_e 2.128) and the rule-based controller runs all 2998 steps."""
+    T = U.tables_mod()
+    tab = T.load_csv(os.path.join(GOLD, "charger98_test_reconstructed.csv"))
+    assert tab.shape == (2999, 8) and tab[0, 2] == np.float32(2.128) and tab[1, 2] == np.float32(0.24)
+    arr = np.where((tab[1:, 0] >= 0) & (tab[:-1, 0] == -1))[0]
+    assert len(arr) == 35 and tab[:, 0].max() == 71          # SURVEY App. C statistics
+    b = oracle_c.Batch(1, 2998, tab, oracle_c.profile(98))
+    total, res = b.rule_episode(0, 2998, want_results=True)
+    assert np.isfinite(total) and b.idx()[0] == 2999
+    assert abs(res[0, 22] - 3.375) < 1e-12 and res[0, 10] == pytest.approx(2.128, abs=1e-6)   # K1: B_DE = 2.128
