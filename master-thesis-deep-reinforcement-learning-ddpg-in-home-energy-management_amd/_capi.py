@@ -101,6 +101,15 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64
+        # (torch/lib, SONAME libamdhip64.so.7).  If /opt/rocm's copy is mapped first and torch's
+        # second, the second HSA runtime finds no GPU.  Loading torch first makes our DT_NEEDED
+        # libamdhip64.so.7 resolve to the copy torch already mapped, so tensors, streams and our
+        # kernels share one runtime.  Without torch (e.g. a Julia host) /opt/rocm's runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         _declare(L)
         _lib = L
