@@ -172,6 +172,50 @@ typedef struct shems_replay {
     uint8_t *done;           /* dev [capacity]                             */
 } shems_replay;              /* the push position is host state and is passed by value */
 
+
+/* ------------------------------------------------------- policy (actor) -- */
+/* Network parameters are ONE flat float32 device array per network in Flux's own order and
+ * layout (Flux.params(Chain(Dense, Dense, Dense)) = W1, b1, W2, b2, W3, b3 with each W a
+ * column-major out x in Matrix, DDPG.jl:30-46):
+ *   actor  (9 -> 250 -> 500 -> 2, relu, relu, tanh):  W1[9][250] b1[250] W2[250][500] b2[500] W3[500][2] b3[2]  = 129 002
+ *   critic (11 -> 250 -> 500 -> 1, relu, relu, id):   W1[11][250] b1[250] W2[250][500] b2[500] W3[500][1] b3[1] = 129 001
+ * ([k][n] = C order of the Julia out x in column-major matrix: the out index is contiguous). */
+enum { SHEMS_L1 = 250, SHEMS_L2 = 500, SHEMS_ACTOR_PARAMS = 129002, SHEMS_CRITIC_PARAMS = 129001 };
+
+typedef struct shems_act_params {
+    const float *actor;      /* dev [129002]                                                        */
+    const float *s_min;      /* dev [9]  normalize(): (s - s_min) / (s_max - s_min + 1f-8), MPS:55-57 */
+    const float *s_max;      /* dev [9]                                                             */
+    float    noise_mu;       /* gn = GNoise(mu, sigma_act, .)  input.jl:198-202, 235                */
+    float    noise_sigma;
+    int32_t  train;          /* act(...; train): 1 = add Gaussian noise (DDPG.jl:159-160, 172)      */
+    uint32_t tick;           /* counter word of the noise stream (the reference's rng_step, DDPG.jl:197) */
+    uint64_t seed;           /* Philox key                                                          */
+} shems_act_params;
+
+/* Which transitions of a vector step enter the replay ring: envs i with ((i - offset) mod n) < count
+ * are stored at slot (pos + ((i - offset) mod n)) mod capacity.  count = 0 stores nothing. */
+typedef struct shems_ring_window {
+    int64_t pos;
+    int64_t count;
+    int64_t offset;
+} shems_ring_window;
+
+/* act(): a = clamp(actor(normalize(s)) + noise, -1, 1) for m observations (DDPG.jl:148-176).
+ * d_obs [m][9] -> d_a [m][2] (UNSCALED action in [-1, 1]).  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64_t m, float *d_a,
+                            void *stream);
+
+/* One fused vector step of episode! (DDPG.jl:195-234) for every env of the view, in ONE launch:
+ *   s = env.state; a = act(normalize(s)); step!(env, s, scale_action(a)); remember(s, a, r, s', false).
+ * Optional outputs: d_a [n][2] unscaled actions, d_rewards [n] f64, d_rewards_f32 [n],
+ * d_block_reward [grid] per-workgroup reward sums.  ring/window may be NULL (evaluation episodes). */
+int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
+                       float *d_rewards_f32, double *d_block_reward, const shems_replay *ring,
+                       const shems_ring_window *window, void *stream);
+/* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
+int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,127 @@
+"""GPU tests of the fused actor kernel (fp32 MFMA) against the NumPy oracle (float64 reference of
+the same network) and, for the fused step, against the C env oracle driven by the emitted actions.
+
+Tolerance: the reference's act() runs Flux/CUBLAS fp32 GEMMs whose summation order is not pinned
+("parity unpinned" for network arithmetic); the kernel's fp32 MFMA result must agree with a float64
+evaluation of the same weights to 1e-5 absolute on actions in [-1, 1] (north_star: 1e-5 relative)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import util as U
+from util import oracle_c
+import ddpg_oracle as DO
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def _mods():
+    torch = pytest.importorskip("torch")
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    return torch, S, D
+
+
+def _rand_obs(rng, n):
+    tab = U.tables_mod().synthetic_table("train", 98)
+    rows = tab[rng.integers(0, tab.shape[0], n)]
+    obs = np.empty((n, 9), np.float32)
+    obs[:, 0] = rng.random(n) * 6.75
+    obs[:, 1] = rows[:, 1]; obs[:, 2] = rows[:, 0]; obs[:, 3] = rows[:, 2]; obs[:, 4] = rows[:, 3]
+    obs[:, 5] = rows[:, 4]; obs[:, 6] = rows[:, 5]; obs[:, 7] = rows[:, 6]; obs[:, 8] = rows[:, 7]
+    return obs
+
+
+def test_init_matches_oracle_and_layout():
+    torch, S, D = _mods()
+    for which, (i, o) in enumerate([(9, 2), (11, 1)]):
+        a = D.init_params(1231, i, o, which)
+        assert (a == DO.init_params(1231, i, o, which)).all() and a.size == DO.n_params(i, o)
+        W1, b1, W2, b2, W3, b3 = DO.split(a, i, o)
+        lim = np.sqrt(24.0 / (i + 250)) / 2
+        assert abs(W1).max() <= lim * 1.0001 and abs(W1).max() > 0.9 * lim and not b1.any()
+        assert abs(W3).max() <= 3e-3 + 1e-9 and W3.std() > 1e-3
+
+
+@pytest.mark.parametrize("m", [1, 31, 120, 8192, 16384 + 77, 65536])
+def test_actor_forward_matches_float64_reference(m):
+    torch, S, D = _mods()
+    rng = np.random.default_rng(m)
+    ag = D.Agent(seed=1231)
+    # make the last layer big enough that tanh is exercised over its range
+    p = D.init_params(1231, 9, 2, 0)
+    p[128000:129000] *= 40.0
+    p[129000:] = [0.3, -0.2]
+    p[2250:2500] = rng.normal(0, 0.1, 250)        # non-zero biases
+    p[127500:128000] = rng.normal(0, 0.1, 500)
+    ag.set_params(actor=p)
+    obs = _rand_obs(rng, m)
+    s_min, s_max = obs.min(0) - 0.01, obs.max(0) + 0.5
+    s_max[5] = s_min[5]                            # constant feature (p_buy): denominator = 1f-8 path
+    ag.set_norm(s_min, s_max)
+    out = ag.act(torch.from_numpy(obs).cuda(), train=False).cpu().numpy()
+    ref = DO.act(p, obs, s_min.astype(np.float32), s_max.astype(np.float32), False, dtype=np.float64)
+    assert out.shape == (m, 2) and np.isfinite(out).all()
+    assert np.abs(out - ref).max() < ATOL
+    assert np.abs(out).max() > 0.3                # not a degenerate all-zero check
+    # train=True adds the Philox/Box-Muller noise and clamps
+    outn = ag.act(torch.from_numpy(obs).cuda(), train=True, tick=17).cpu().numpy()
+    refn = DO.act(p, obs, s_min.astype(np.float32), s_max.astype(np.float32), True, seed=1231, tick=17, dtype=np.float64)
+    assert np.abs(outn - refn).max() < 5e-6 + ATOL and outn.min() >= -1 and outn.max() <= 1
+    if m >= 8192:
+        z = (outn - out)[np.abs(outn) < 0.999] / 0.1
+        assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+
+
+def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
+    torch, S, D = _mods()
+    ReplayRing = importlib.import_module(U.PKG_NAME + ".replay").ReplayRing
+    T = S.tables
+    n = 20000                                      # ragged vs BM = 32
+    tab = T.synthetic_table("train", 98)
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    ref = oracle_c.Batch(n, 72, tab, oracle_c.profile(98))
+    ag = D.Agent(seed=77)
+    p = D.init_params(77, 9, 2, 0)
+    p[128000:129000] *= 60.0
+    ag.set_params(actor=p)
+    env.reset_(5, episode=0)
+    st0 = env.state
+    ag.set_norm(st0.min(0), st0.max(0))
+    ref.set_state(st0, env.idx)
+    ring = ReplayRing(5000)
+    a_out = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    rew = torch.empty(n, dtype=torch.float64, device="cuda")
+    rew32 = torch.empty(n, dtype=torch.float32, device="cuda")
+    blk = torch.zeros(ag.act_step_blocks(n), dtype=torch.float64, device="cuda")
+    pos = 0
+    for t in range(6):
+        pre = env.state
+        win = D.RingWindow(pos % ring.capacity, 333, (t * 333) % n)
+        ag.act_step(env, train=True, tick=t, a_out=a_out, rewards=rew, rewards_f32=rew32, block_reward=blk, ring=ring, window=win)
+        env.check_error()
+        a = a_out.cpu().numpy()
+        # (1) the action is act() of the pre-step observation
+        want = DO.act(p, pre, st0.min(0), st0.max(0), True, seed=77, tick=t, dtype=np.float64)
+        assert np.abs(a - want).max() < 5e-6 + ATOL
+        # (2) given that action, the transition is the oracle's, bit for bit
+        rc, r_ref, o_ref, _ = ref.step(oracle_c.scale_action(a), 0)
+        assert rc == 0
+        r = rew.cpu().numpy()
+        assert (U.bits64(r) == U.bits64(r_ref)).all() and (U.bits32(env.state) == U.bits32(o_ref)).all()
+        assert (rew32.cpu().numpy() == r_ref.astype(np.float32)).all()
+        bm = n // blk.numel() if n % blk.numel() == 0 else None
+        assert abs(blk.sum().item() - r.sum()) < 1e-9 * max(1.0, abs(r).sum())
+        # (3) the ring window
+        rel = (np.arange(n) - (t * 333) % n) % n
+        sel = np.where(rel < 333)[0]
+        slots = (pos + rel[sel]) % ring.capacity
+        assert (U.bits32(ring.s.cpu().numpy()[slots]) == U.bits32(pre[sel])).all()
+        assert (U.bits32(ring.s2.cpu().numpy()[slots]) == U.bits32(o_ref[sel])).all()
+        assert (U.bits32(ring.a.cpu().numpy()[slots]) == U.bits32(a[sel])).all()
+        assert (ring.r.cpu().numpy()[slots] == r_ref[sel].astype(np.float32)).all()
+        pos += 333
+    assert (env.idx == ref.idx()).all() and (env.step == 6).all()
+    env.close()
