@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=720)
     ap.add_argument("--warmup", type=int, default=72)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--mode", default="auto", choices=["auto", "train", "env"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env"])
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -95,6 +95,56 @@ class EnvWorkload:
 
     def extra(self):
         return {}
+
+
+class PolicyWorkload(EnvWorkload):
+    """act + step! + remember fused (no DDPG update): one k_act launch per vector step."""
+
+    name = "policy"
+    dtype = "f32"
+
+    def __init__(self, S, torch, n, seed):
+        super().__init__(S, torch, n, seed)
+        D = importlib.import_module(PKG + ".ddpg")
+        self.D = D
+        self.agent = D.Agent(seed=seed)
+        st = self.env.state
+        self.agent.set_norm(st.min(0), st.max(0))
+        self.ring = D.ReplayRing(D.MEM_SIZE)
+        self.win_count = min(n, D.MEM_SIZE // EP_LEN)          # SURVEY 8(d): rotating window of 333 envs
+        self.pushed = 0
+
+    def _launch(self, tick):
+        win = self.D.RingWindow(self.pushed % self.ring.capacity, self.win_count, (tick * self.win_count) % self.n)
+        self.agent.act_step(self.env, train=True, tick=tick, rewards_f32=self.rew32, ring=self.ring, window=win)
+        self.pushed += self.win_count
+
+    def step(self):
+        if self.t and self.t % EP_LEN == 0:
+            self.episode += 1
+            v = self.env.view()
+            self.S._capi.check(self.S._capi.lib().shems_reset_seeded_dev(C.byref(v), self.seed, self.episode, self.env._stream()))
+        self._launch(self.t)
+        self.t += 1
+
+    def kernel_pass(self, reps):
+        torch = self.torch
+        reps = min(reps, 200)
+        self.env.reset_(self.seed, episode=1000)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            if i and i % (EP_LEN - 1) == 0:
+                self.env.reset_(self.seed, episode=1000 + i)
+            a.record()
+            self._launch(i)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ms) / len(ms)
+        flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n       # SURVEY 8(d): 256 500 FLOP per env-step
+        return dict(kernel="shems::k_act<TM>", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
 
 def cpu_baseline(n_envs, budget_s=12.0):
@@ -165,7 +215,9 @@ def main():
         if train_mod is None and mode == "train":
             raise SystemExit("train mode requested but the DDPG path is not built")
         mode = "train" if train_mod is not None else "env"
-    if mode == "train":
+    if mode == "policy":
+        wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
+    elif mode == "train":
         wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist)
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)

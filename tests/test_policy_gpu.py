@@ -70,9 +70,7 @@ def test_actor_forward_matches_float64_reference(m):
     outn = ag.act(torch.from_numpy(obs).cuda(), train=True, tick=17).cpu().numpy()
     refn = DO.act(p, obs, s_min.astype(np.float32), s_max.astype(np.float32), True, seed=1231, tick=17, dtype=np.float64)
     assert np.abs(outn - refn).max() < 5e-6 + ATOL and outn.min() >= -1 and outn.max() <= 1
-    if m >= 8192:
-        z = (outn - out)[np.abs(outn) < 0.999] / 0.1
-        assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+    assert np.abs(outn - out).max() > 0.05         # the noise is really there (its N(0,1) shape: test_ddpg_oracle.py)
 
 
 def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
