@@ -216,6 +216,47 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 
+
+/* -------------------------------------------------------- DDPG update -- */
+/* replay() (DDPG.jl:121-145) split at the two points where data-parallel replicas exchange
+ * gradients.  Batch <= 128 (BATCH_SIZE = 120 in the tuned config).  All pointers are
+ * device memory; `ws` is a scratch block of shems_ddpg_workspace_floats() floats (zero it once).
+ *   shems_ddpg_critic_grad : getData (sample WITH replacement, MPS:31-42) -> normalize ->
+ *                            a' = actor_target(s'), q' = critic_target([s';a']), y = r + gamma(1-done)q'
+ *                            -> d mse(critic([s;a]), y) / d critic  into grad_critic [129001]
+ *   (all-reduce grad_critic across replicas here)
+ *   shems_ddpg_critic_apply: ADAM(eta_crit) on critic, then soft_update!(critic_target, critic; tau)
+ *   shems_ddpg_actor_grad  : d(-mean(critic([s; actor(s)]))) / d actor  into grad_actor [129002]
+ *   (all-reduce grad_actor here)
+ *   shems_ddpg_actor_apply : ADAM(eta_act) on actor, then soft_update!(actor_target, actor; tau)
+ * ADAM is Flux 0.12.1's: m,v float32 arrays, scalars in Float64, bias-correction powers beta^t are
+ * host state passed by value (bp1 = beta1^t, bp2 = beta2^t for the t-th step, t >= 1). */
+typedef struct shems_ddpg {
+    float *actor, *critic, *actor_t, *critic_t;     /* [129002] [129001] [129002] [129001]        */
+    float *m_actor, *v_actor, *m_critic, *v_critic; /* ADAM moments                                */
+    float *grad_actor, *grad_critic;                /* gradient outputs (sum over the local batch / batch) */
+    const float *s_min, *s_max;                     /* [9]                                         */
+    float *ws;                                      /* workspace                                   */
+    float *losses;                                  /* [2] out: critic mse, actor loss (-mean q)   */
+    float gamma, tau;
+    int32_t batch;                                  /* BATCH_SIZE (<= 128)                         */
+    int32_t reserved;
+} shems_ddpg;
+
+int shems_ddpg_workspace_floats(int64_t *out);
+int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len,
+                           uint64_t seed, uint32_t tick, void *stream);
+int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
+                            void *stream);
+int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream);
+int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
+                           void *stream);
+/* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
+int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
+/* min_max_buffer (MPS:50-53): minimum/maximum of s over a bootstrap sample of `count` ring entries. */
+int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed,
+                     float *d_s_min, float *d_s_max, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,12 @@ class ActParams(C.Structure):          # shems_act_params
                 ("tick", C.c_uint32), ("seed", C.c_uint64)]
 
 
+class DdpgArgs(C.Structure):           # shems_ddpg
+    _fields_ = [(n, C.c_void_p) for n in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic",
+                                          "v_critic", "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")] + \
+               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RingWindow(C.Structure):         # shems_ring_window
     _fields_ = [("pos", C.c_int64), ("count", C.c_int64), ("offset", C.c_int64)]
 
@@ -51,6 +57,17 @@ def _declare():
     L.shems_act_step_dev.restype = C.c_int
     L.shems_act_step_grid.argtypes = [i64, C.POINTER(i64)]
     L.shems_act_step_grid.restype = C.c_int
+    PD = C.POINTER(DdpgArgs)
+    L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
+    L.shems_ddpg_critic_grad.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, vp]
+    L.shems_ddpg_critic_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+    L.shems_ddpg_actor_grad.argtypes = [PD, vp]
+    L.shems_ddpg_actor_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+    L.shems_ddpg_sample_indices.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, i64, vp]
+    L.shems_minmax_dev.argtypes = [C.POINTER(_capi.Replay), i64, i64, C.c_uint64, vp, vp, vp]
+    for fn in ("shems_ddpg_workspace_floats", "shems_ddpg_critic_grad", "shems_ddpg_critic_apply", "shems_ddpg_actor_grad",
+               "shems_ddpg_actor_apply", "shems_ddpg_sample_indices", "shems_minmax_dev"):
+        getattr(L, fn).restype = C.c_int
     L._ddpg_declared = True
     return L
 
@@ -110,6 +127,22 @@ class Agent:
         self.s_min = torch.zeros(STATE, dtype=torch.float32, device=self.device)
         self.s_max = torch.ones(STATE, dtype=torch.float32, device=self.device)
         self.tick = 0
+        # learner state: ADAM moments (opt_act = ADAM(eta_act), opt_crit = ADAM(eta_crit), input.jl:126-127)
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.m_actor, self.v_actor, self.m_critic, self.v_critic = z(N_ACTOR), z(N_ACTOR), z(N_CRITIC), z(N_CRITIC)
+        self.grad_actor, self.grad_critic = z(N_ACTOR), z(N_CRITIC)
+        nws = C.c_int64(0)
+        _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
+        self.ws = z(nws.value)
+        self.losses = z(2)
+        self.gamma, self.tau = GAMMA, TAU
+        self.eta_act, self.eta_crit = float(f32(ETA_ACT)), float(f32(ETA_CRIT))
+        self.batch = BATCH_SIZE
+        self.bp_actor = [0.9, 0.999]               # Flux ADAM state beta^t (Float64), advanced after every step
+        self.bp_critic = [0.9, 0.999]
+        self.updates = 0
+        self.dist = None                           # torch.distributed module when replicas exchange gradients
+        self.world = 1
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -157,6 +190,60 @@ class Agent:
         _capi.check(self.L.shems_act_step_dev(C.byref(v), C.byref(p), ptr(a_out), ptr(rewards), ptr(rewards_f32),
                                               ptr(block_reward), C.byref(rs) if rs is not None else None,
                                               C.byref(window) if window is not None else None, self._stream()))
+
+    # ---------------------------------------------------------------- learner
+    def _ddpg_args(self):
+        return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
+                        self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
+                        self.grad_actor.data_ptr(), self.grad_critic.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
+                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch, 0)
+
+    def enable_data_parallel(self, dist):
+        """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
+        self.dist = dist
+        self.world = dist.get_world_size()
+        for t in (self.actor, self.critic, self.actor_t, self.critic_t):
+            dist.broadcast(t, src=0)               # identical initial weights on every replica
+
+    def _allreduce(self, g):
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(g)                # sum over replicas; the 1/world is folded into ADAM's grad_scale
+
+    def replay(self, ring, tick=None):
+        """replay(; rng_rpl) (DDPG.jl:121-145): one DDPG update from `ring`."""
+        d = self._ddpg_args()
+        st = self._stream()
+        rs = ring.struct()
+        tick = self.updates if tick is None else tick
+        _capi.check(self.L.shems_ddpg_critic_grad(C.byref(d), C.byref(rs), len(ring), self.seed, int(tick) & 0xFFFFFFFF, st))
+        self._allreduce(self.grad_critic)
+        gs = 1.0 / self.world
+        _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+        self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
+        _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
+        self._allreduce(self.grad_actor)
+        _capi.check(self.L.shems_ddpg_actor_apply(C.byref(d), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs, st))
+        self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
+        self.updates += 1
+
+    def sample_indices(self, tick, ring_len):
+        out = np.empty(self.batch, np.int64)
+        _capi.check(self.L.shems_ddpg_sample_indices(self.seed, int(tick) & 0xFFFFFFFF, self.batch, int(ring_len),
+                                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def min_max_buffer(self, ring, count=None, seed=None):
+        """s_min, s_max = min_max_buffer(MIN_EXP_SIZE) (MPS:50-53, main script :30): extrema of s over a
+        bootstrap sample (with replacement) of `count` ring entries; with several replicas the 9-float
+        extrema are all-reduced (min / max)."""
+        rs = ring.struct()
+        count = len(ring) if count is None else int(count)
+        _capi.check(self.L.shems_minmax_dev(C.byref(rs), len(ring), count, self.seed if seed is None else int(seed),
+                                            C.c_void_p(self.s_min.data_ptr()), C.c_void_p(self.s_max.data_ptr()), self._stream()))
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(self.s_min, op=self.dist.ReduceOp.MIN)
+            self.dist.all_reduce(self.s_max, op=self.dist.ReduceOp.MAX)
+        return self.s_min, self.s_max
 
     def act_step_blocks(self, n):
         out = C.c_int64(0)

@@ -1,0 +1,153 @@
+"""GPU tests of the DDPG update kernels (replay(), DDPG.jl:121-145) against the NumPy oracle.
+
+"Parity unpinned" by the reference for this arithmetic (Flux/Zygote/CUBLAS, un-vendored; no
+reference tests): the oracle is pinned to PyTorch autograd in tests/test_ddpg_oracle.py, and the
+kernels are held to it here.  Tolerances: gradients 2e-4 of the largest |g| of the tensor (fp32
+accumulation order differs between MFMA tiles, wave reductions and BLAS); ADAM / soft update are
+checked element-wise at 1e-7 by feeding the kernel's own gradient through the oracle's formulas."""
+import importlib
+
+import numpy as np
+import pytest
+
+import util as U
+import ddpg_oracle as DO
+import philox_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=11, cap=24000, boost=30.0):
+    torch = pytest.importorskip("torch")
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    rng = np.random.default_rng(seed)
+    tab = S.tables.synthetic_table("train", 98)
+    ring = D.ReplayRing(cap)
+    rows = tab[rng.integers(0, tab.shape[0] - 1, cap)]
+    s = np.empty((cap, 9), np.float32)
+    s[:, 0] = rng.random(cap) * 6.75
+    s[:, 1:] = rows[:, [1, 0, 2, 3, 4, 5, 6, 7]]
+    s2 = s.copy()
+    s2[:, 0] = np.clip(s[:, 0] + rng.normal(0, 1, cap), 0, 6.75)
+    s2[:, 3:5] = rng.random((cap, 2)) * 5
+    a = (rng.random((cap, 2)) * 2 - 1).astype(np.float32)
+    r = (rng.normal(-1, 2, cap)).astype(np.float32)
+    done = np.zeros(cap, np.uint8)
+    done[rng.random(cap) < 0.05] = 1           # the reference never sets done, the formula still has the term
+    for t, v in ((ring.s, s), (ring.a, a), (ring.r, r), (ring.s2, s2), (ring.done, done)):
+        t.copy_(torch.from_numpy(v))
+    ring.pushed = cap
+    ag = D.Agent(seed=seed)
+    pa, pc = D.init_params(seed, 9, 2, 0), D.init_params(seed, 11, 1, 1)
+    pa[128000:129000] *= boost                 # lift the 3e-3 heads so every gradient path is exercised
+    pc[128250:128750] *= boost
+    pa[2250:2500] = rng.normal(0, 0.05, 250); pc[2750:3000] = rng.normal(0, 0.05, 250)
+    ag.set_params(actor=pa, critic=pc)
+    s_min, s_max = s.min(0), s.max(0)
+    ag.set_norm(s_min, s_max)
+    host = dict(s=s, a=a, r=r, s2=s2, done=done, s_min=s_min, s_max=s_max, pa=pa, pc=pc)
+    return torch, S, D, ag, ring, host
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def test_sampler_matches_oracle_philox():
+    torch, S, D, ag, ring, h = _setup()
+    for tick in (0, 3, 999):
+        idx = ag.sample_indices(tick, 24000)
+        assert (idx == DO.sample_indices(ag.seed, tick, 120, 24000)).all()
+    assert len(np.unique(np.concatenate([ag.sample_indices(t, 24000) for t in range(50)]))) > 5000
+
+
+def test_one_update_matches_oracle():
+    torch, S, D, ag, ring, h = _setup()
+    tick = 3
+    idx = ag.sample_indices(tick, len(ring))
+    L = DO.Learner(h["pa"], h["pc"], h["s_min"], h["s_max"])
+    s, a, r, s2, done = (h[k][idx] for k in ("s", "a", "r", "s2", "done"))
+    y = L.targets(r, s2, done.astype(bool))
+    gc_ref, lc_ref = L.critic_grad(s, a, y)
+
+    ag.replay(ring, tick=tick)
+    torch.cuda.synchronize()
+    ws = ag.ws.cpu().numpy()
+    # gathered + normalised minibatch
+    XT = ws[0:9 * 128].reshape(9, 128)
+    np.testing.assert_allclose(XT[:, :120].T, DO.normalize(s, h["s_min"], h["s_max"]), rtol=0, atol=1e-6)
+    assert not XT[:, 120:].any()
+    Y = ws[128 * 22:128 * 23][:120]           # WS_Y = (9 + 9 + 2 + 1 + 1) * 128
+    np.testing.assert_allclose(Y, y, rtol=2e-5, atol=2e-5)
+    gc = ag.grad_critic.cpu().numpy()
+    assert _rel(gc, gc_ref) < 2e-4 and np.abs(gc_ref).max() > 1e-3
+    losses = ag.losses.cpu().numpy()
+    assert abs(losses[0] - lc_ref) < 1e-4 * max(1.0, abs(lc_ref))
+
+    # ADAM + soft update, element-wise, from the kernel's own gradient
+    opt = DO.Adam(len(gc), DO.ETA_CRIT)
+    pc1 = opt.step(h["pc"], gc)
+    crit = ag.critic.cpu().numpy()
+    np.testing.assert_allclose(crit, pc1, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ag.critic_t.cpu().numpy(), DO.soft_update(h["pc"], crit), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ag.m_critic.cpu().numpy(), opt.m, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(ag.v_critic.cpu().numpy(), opt.v, rtol=1e-6, atol=1e-15)
+
+    # actor gradient is taken through the UPDATED critic (DDPG.jl:137-140): give the oracle the kernel's critic
+    L.critic = crit
+    ga_ref, la_ref = L.actor_grad(s)
+    ga = ag.grad_actor.cpu().numpy()
+    assert _rel(ga, ga_ref) < 2e-4 and np.abs(ga_ref).max() > 1e-5
+    assert abs(losses[1] - la_ref) < 1e-4 * max(1.0, abs(la_ref))
+    opt_a = DO.Adam(len(ga), DO.ETA_ACT)
+    pa1 = opt_a.step(h["pa"], ga)
+    act = ag.actor.cpu().numpy()
+    np.testing.assert_allclose(act, pa1, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ag.actor_t.cpu().numpy(), DO.soft_update(h["pa"], act), rtol=0, atol=1e-7)
+    # every gradient entry is written each update (no stale region): second update with a fresh batch changes all blocks
+    g_before = ga.copy()
+    ag.replay(ring, tick=tick + 1)
+    g_after = ag.grad_actor.cpu().numpy()
+    for lo, hi in ((0, 2250), (2250, 2500), (2500, 127500), (127500, 128000), (128000, 129000), (129000, 129002)):
+        assert (g_after[lo:hi] != g_before[lo:hi]).mean() > 0.3, (lo, hi)
+
+
+def test_second_step_uses_advanced_beta_powers():
+    torch, S, D, ag, ring, h = _setup(seed=5)
+    opt = DO.Adam(D.N_CRITIC, DO.ETA_CRIT)
+    p = h["pc"].copy()
+    for t in range(3):
+        ag.replay(ring, tick=t)
+        g = ag.grad_critic.cpu().numpy()
+        p_prev = p
+        p = opt.step(p, g)
+        # the kernel's critic was produced from the kernel's own previous critic: compare the step
+        crit = ag.critic.cpu().numpy()
+        np.testing.assert_allclose(crit, p, rtol=0, atol=2e-7)
+        p = crit
+    assert ag.updates == 3 and abs(ag.bp_critic[0] - 0.9 ** 4) < 1e-15
+
+
+def test_training_on_fixed_ring_reduces_critic_loss():
+    torch, S, D, ag, ring, h = _setup(seed=2, boost=1.0)
+    first = last = None
+    for t in range(60):
+        ag.replay(ring, tick=t % 4)            # revisit 4 minibatches
+        if t < 4:
+            first = (first or 0) + ag.losses[0].item() / 4
+        if t >= 56:
+            last = (last or 0) + ag.losses[0].item() / 4
+    assert np.isfinite(last) and last < 0.6 * first
+    assert torch.isfinite(ag.actor).all() and torch.isfinite(ag.critic).all()
+
+
+def test_min_max_buffer_bootstrap():
+    torch, S, D, ag, ring, h = _setup(seed=9, cap=5000)
+    ag.min_max_buffer(ring, count=5000, seed=77)
+    q = np.arange((5000 + 3) // 4, dtype=np.uint64)
+    xs = philox_np.philox4x32_10(q & 0xFFFFFFFF, q >> np.uint64(32), 0xFFFFFFFF, philox_np.STREAM_SAMPLE, 77, 0)
+    idx = (np.stack(xs, 1).reshape(-1)[:5000] % np.uint32(5000)).astype(np.int64)
+    assert (ag.s_min.cpu().numpy() == h["s"][idx].min(0)).all()
+    assert (ag.s_max.cpu().numpy() == h["s"][idx].max(0)).all()
+    assert len(np.unique(idx)) < 5000           # with replacement
