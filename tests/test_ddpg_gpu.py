@@ -131,14 +131,18 @@ def test_second_step_uses_advanced_beta_powers():
 
 def test_training_on_fixed_ring_reduces_critic_loss():
     torch, S, D, ag, ring, h = _setup(seed=2, boost=1.0)
+    # a learnable reward (the random one of _setup has an irreducible variance of 4)
+    r = (0.4 * (h["s"][:, 4] - h["s"][:, 3]) + h["a"][:, 1] - 0.5 * h["s"][:, 0]).astype(np.float32)
+    ring.r.copy_(torch.from_numpy(r))
     first = last = None
-    for t in range(60):
+    n_up = 160
+    for t in range(n_up):
         ag.replay(ring, tick=t % 4)            # revisit 4 minibatches
         if t < 4:
             first = (first or 0) + ag.losses[0].item() / 4
-        if t >= 56:
+        if t >= n_up - 4:
             last = (last or 0) + ag.losses[0].item() / 4
-    assert np.isfinite(last) and last < 0.6 * first
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)
     assert torch.isfinite(ag.actor).all() and torch.isfinite(ag.critic).all()
 
 
