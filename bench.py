@@ -277,6 +277,8 @@ def main():
             "cpu_baseline": cpu,
         }
         out.update(wl.extra())
+        if mode == "train":
+            out["updates_per_sec"] = args.updates * args.steps / dt      # complete replay() equivalents (B = 120)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -152,13 +152,15 @@ int shems_reset_seeded_dev(const shems_view *v, uint64_t seed, uint32_t episode,
  * (BASELINE config 1 at scale, MPS:62-71 + DDPG.jl:209-212); SHEMS_ROLLOUT_RANDOM: uniform random
  * actions in [-1,1] -> scale_action (populate_memory, MPS:9-29), Philox keyed by (seed, env, step).
  * d_returns [n] Float64 episode sums (DDPG.jl:223).  If ring != NULL every transition is appended
- * to the replay ring (see shems_replay below) at slot (ring_pos + env*nsteps + t) mod capacity,
- * i.e. in the reference's episode-major push order. */
+ * of the first `ring_envs` envs (0 = all) is appended to the replay ring (see shems_replay below) at
+ * slot (ring_pos + env*nsteps + t) mod capacity, i.e. in the reference's episode-major push order;
+ * pushes that a later push of the same launch would overwrite (order < ring_envs*nsteps - capacity)
+ * are skipped, so the ring content is deterministic (= what the CircularBuffer would hold). */
 enum { SHEMS_ROLLOUT_RULE = 0, SHEMS_ROLLOUT_RANDOM = 1 };
 struct shems_replay;
 int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t seed,
                       double *d_returns, const struct shems_replay *ring, int64_t ring_pos,
-                      void *stream);
+                      int64_t ring_envs, void *stream);
 
 /* ------------------------------------------------------------ replay ring -- */
 /* memory = CircularBuffer{Any}(MEM_SIZE) of [s, a, r, s', done] (input.jl:139-140, MPS:46-47),
@@ -209,10 +211,10 @@ int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64
 /* One fused vector step of episode! (DDPG.jl:195-234) for every env of the view, in ONE launch:
  *   s = env.state; a = act(normalize(s)); step!(env, s, scale_action(a)); remember(s, a, r, s', false).
  * Optional outputs: d_a [n][2] unscaled actions, d_rewards [n] f64, d_rewards_f32 [n],
- * d_block_reward [grid] per-workgroup reward sums.  ring/window may be NULL (evaluation episodes). */
+ * d_block_reward [grid] per-workgroup reward sums, d_returns_acc [n] f64 += reward (reward_eps, DDPG.jl:223).  ring/window may be NULL (evaluation episodes). */
 int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
-                       float *d_rewards_f32, double *d_block_reward, const shems_replay *ring,
-                       const shems_ring_window *window, void *stream);
+                       float *d_rewards_f32, double *d_block_reward, double *d_returns_acc,
+                       const shems_replay *ring, const shems_ring_window *window, void *stream);
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(shems_view v, int rng_minus1, 
 // return (and, optionally, the replay transitions) leave the chip.
 __global__ __launch_bounds__(kBlock) void k_rollout(shems_view v, int policy, int nsteps, uint64_t seed,
                                                     double *__restrict__ returns, shems_replay ring,
-                                                    int64_t ring_pos, int use_ring)
+                                                    int64_t ring_pos, int64_t ring_envs, int64_t first_kept)
 {
     __shared__ float tile[kBlock * SHEMS_NSTATE];
     const int64_t base = (int64_t)blockIdx.x * kBlock;
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(shems_view v, int policy, in
             ok = env_advance(c, v.tables, obs, idx, step, a0, a1, mode, reward, f, B, EV, Bt, EVt);
             if (!ok) { raise(v.err, SHEMS_ERR_INDEX); break; }
             total += reward;
-            if (use_ring) {                      // remember(s, a, r, s', done)  MPS:46-47, episode-major slots
-                const int64_t slot = (ring_pos + i * (int64_t)nsteps + t) % ring.capacity;
+            const int64_t ord = i * (int64_t)nsteps + t;
+            if (i < ring_envs && ord >= first_kept) {   // remember(s, a, r, s', done)  MPS:46-47, episode-major slots
+                const int64_t slot = (ring_pos + ord) % ring.capacity;
                 float *ps = ring.s + slot * SHEMS_NSTATE, *p2 = ring.s2 + slot * SHEMS_NSTATE;
 #pragma unroll
                 for (int k = 0; k < SHEMS_NSTATE; ++k) { ps[k] = pre[k]; p2[k] = obs[k]; }
@@ -278,7 +279,7 @@ int shems_reset_seeded_dev(const shems_view *v, uint64_t seed, uint32_t episode,
 }
 
 int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t seed, double *d_returns,
-                      const shems_replay *ring, int64_t ring_pos, void *stream)
+                      const shems_replay *ring, int64_t ring_pos, int64_t ring_envs, void *stream)
 {
     if (int rc = check_view(v)) return rc;
     if (nsteps < 0 || (policy != SHEMS_ROLLOUT_RULE && policy != SHEMS_ROLLOUT_RANDOM))
@@ -290,8 +291,14 @@ int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t 
             return set_error(SHEMS_ERR_ARG, "shems_rollout_dev: incomplete replay ring");
         r = *ring;
     }
+    int64_t n_ring = 0, first_kept = 0;
+    if (ring) {
+        n_ring = (ring_envs <= 0 || ring_envs > v->n_envs) ? v->n_envs : ring_envs;
+        first_kept = n_ring * (int64_t)nsteps - ring->capacity;
+        if (first_kept < 0) first_kept = 0;
+    }
     hipLaunchKernelGGL(k_rollout, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, policy,
-                       (int)nsteps, seed, d_returns, r, ring_pos, ring ? 1 : 0);
+                       (int)nsteps, seed, d_returns, r, ring_pos, n_ring, first_kept);
     return hip_ok(hipGetLastError(), "k_rollout launch");
 }
 

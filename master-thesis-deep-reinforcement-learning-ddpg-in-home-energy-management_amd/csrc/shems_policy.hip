@@ -54,6 +54,7 @@ struct ActArgs {
     double *rewards;
     float *rewards_f32;
     double *block_reward;
+    double *returns_acc;
     shems_replay ring;
     shems_ring_window win;
     int do_step;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
                 v.step[i] = step;
                 if (A.rewards) A.rewards[i] = reward;
                 if (A.rewards_f32) A.rewards_f32[i] = (float)reward;
+                if (A.returns_acc) A.returns_acc[i] += reward;
                 if (A.use_ring) {
                     int64_t rel = i - A.win.offset;
                     rel %= v.n_envs;
@@ -354,8 +356,8 @@ int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64
 }
 
 int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
-                       float *d_rewards_f32, double *d_block_reward, const shems_replay *ring,
-                       const shems_ring_window *window, void *stream)
+                       float *d_rewards_f32, double *d_block_reward, double *d_returns_acc,
+                       const shems_replay *ring, const shems_ring_window *window, void *stream)
 {
     if (int rc = check_act(p, "shems_act_step_dev")) return rc;
     if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1)
@@ -364,6 +366,7 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
     std::memset(&a, 0, sizeof a);
     a.v = *v; a.p = *p; a.obs = v->obs; a.m = v->n_envs; a.a_out = d_a;
     a.rewards = d_rewards; a.rewards_f32 = d_rewards_f32; a.block_reward = d_block_reward;
+    a.returns_acc = d_returns_acc;
     a.do_step = 1;
     if (ring && window && window->count > 0) {
         if (ring->capacity <= 0 || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done)

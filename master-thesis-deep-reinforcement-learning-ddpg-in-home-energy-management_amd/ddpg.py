@@ -18,6 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
+from .parallel import GradSync, shard_envs  # noqa: F401
 from .replay import ReplayRing
 
 L1, L2, STATE, ACTION = 250, 500, 9, 2
@@ -52,7 +53,7 @@ def _declare():
     vp, i64 = C.c_void_p, C.c_int64
     L.shems_actor_forward_dev.argtypes = [C.POINTER(ActParams), vp, i64, vp, vp]
     L.shems_actor_forward_dev.restype = C.c_int
-    L.shems_act_step_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), vp, vp, vp, vp,
+    L.shems_act_step_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), vp, vp, vp, vp, vp,
                                      C.POINTER(_capi.Replay), C.POINTER(RingWindow), vp]
     L.shems_act_step_dev.restype = C.c_int
     L.shems_act_step_grid.argtypes = [i64, C.POINTER(i64)]
@@ -110,12 +111,13 @@ def init_params(seed, in_dim, out_dim, which):
 class Agent:
     """The DDPG learner state on one GPU (one replica under data parallelism)."""
 
-    def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0):
+    def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None):
         import torch
         self.torch = torch
         self.L = _declare()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.seed = int(seed)
+        self.seed = int(seed)                      # network initialisation (identical on every replica)
+        self.rng_seed = self.seed if rng_seed is None else int(rng_seed)   # noise / minibatch streams (per replica)
         self.sigma, self.mu = float(sigma), float(mu)
         a = init_params(self.seed, STATE, ACTION, 0)
         c = init_params(self.seed, STATE + ACTION, 1, 1)
@@ -141,8 +143,7 @@ class Agent:
         self.bp_actor = [0.9, 0.999]               # Flux ADAM state beta^t (Float64), advanced after every step
         self.bp_critic = [0.9, 0.999]
         self.updates = 0
-        self.dist = None                           # torch.distributed module when replicas exchange gradients
-        self.world = 1
+        self.sync = GradSync(None)                 # replicas exchange gradients through this (RCCL)
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -167,7 +168,7 @@ class Agent:
     def _act_params(self, train, tick, actor=None):
         a = self.actor if actor is None else actor
         return ActParams(a.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(), self.mu, self.sigma,
-                         1 if train else 0, int(tick) & 0xFFFFFFFF, self.seed)
+                         1 if train else 0, int(tick) & 0xFFFFFFFF, self.rng_seed)
 
     def act(self, obs, train=True, tick=None, out=None):
         """act(normalize(s); train): obs [M][9] cuda float32 -> a [M][2] in [-1, 1] (unscaled)."""
@@ -181,14 +182,14 @@ class Agent:
         return out
 
     def act_step(self, env, train=True, tick=None, a_out=None, rewards=None, rewards_f32=None, block_reward=None,
-                 ring=None, window=None):
+                 returns_acc=None, ring=None, window=None):
         """One fused vector step: s = env.state; a = act(s); step!(env, s, scale_action(a)); remember(...)."""
         v = env.view()
         p = self._act_params(train, self.tick if tick is None else tick)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         rs = ring.struct() if ring is not None else None
         _capi.check(self.L.shems_act_step_dev(C.byref(v), C.byref(p), ptr(a_out), ptr(rewards), ptr(rewards_f32),
-                                              ptr(block_reward), C.byref(rs) if rs is not None else None,
+                                              ptr(block_reward), ptr(returns_acc), C.byref(rs) if rs is not None else None,
                                               C.byref(window) if window is not None else None, self._stream()))
 
     # ---------------------------------------------------------------- learner
@@ -200,14 +201,11 @@ class Agent:
 
     def enable_data_parallel(self, dist):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
-        self.dist = dist
-        self.world = dist.get_world_size()
-        for t in (self.actor, self.critic, self.actor_t, self.critic_t):
-            dist.broadcast(t, src=0)               # identical initial weights on every replica
+        self.sync = GradSync(dist)
+        self.sync.broadcast(self.actor, self.critic, self.actor_t, self.critic_t)   # identical initial weights
 
     def _allreduce(self, g):
-        if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(g)                # sum over replicas; the 1/world is folded into ADAM's grad_scale
+        self.sync.sum_(g)                          # sum over replicas; the 1/world is folded into ADAM's grad_scale
 
     def replay(self, ring, tick=None):
         """replay(; rng_rpl) (DDPG.jl:121-145): one DDPG update from `ring`."""
@@ -215,9 +213,9 @@ class Agent:
         st = self._stream()
         rs = ring.struct()
         tick = self.updates if tick is None else tick
-        _capi.check(self.L.shems_ddpg_critic_grad(C.byref(d), C.byref(rs), len(ring), self.seed, int(tick) & 0xFFFFFFFF, st))
+        _capi.check(self.L.shems_ddpg_critic_grad(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF, st))
         self._allreduce(self.grad_critic)
-        gs = 1.0 / self.world
+        gs = self.sync.grad_scale
         _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
         self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
         _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
@@ -228,7 +226,7 @@ class Agent:
 
     def sample_indices(self, tick, ring_len):
         out = np.empty(self.batch, np.int64)
-        _capi.check(self.L.shems_ddpg_sample_indices(self.seed, int(tick) & 0xFFFFFFFF, self.batch, int(ring_len),
+        _capi.check(self.L.shems_ddpg_sample_indices(self.rng_seed, int(tick) & 0xFFFFFFFF, self.batch, int(ring_len),
                                                      out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -238,14 +236,176 @@ class Agent:
         extrema are all-reduced (min / max)."""
         rs = ring.struct()
         count = len(ring) if count is None else int(count)
-        _capi.check(self.L.shems_minmax_dev(C.byref(rs), len(ring), count, self.seed if seed is None else int(seed),
+        _capi.check(self.L.shems_minmax_dev(C.byref(rs), len(ring), count, self.rng_seed if seed is None else int(seed),
                                             C.c_void_p(self.s_min.data_ptr()), C.c_void_p(self.s_max.data_ptr()), self._stream()))
-        if self.dist is not None and self.world > 1:
-            self.dist.all_reduce(self.s_min, op=self.dist.ReduceOp.MIN)
-            self.dist.all_reduce(self.s_max, op=self.dist.ReduceOp.MAX)
+        self.sync.minmax_(self.s_min, self.s_max)
         return self.s_min, self.s_max
 
     def act_step_blocks(self, n):
         out = C.c_int64(0)
         _capi.check(self.L.shems_act_step_grid(int(n), C.byref(out)))
         return out.value
+
+
+    # ------------------------------------------------------------- training loop
+    def populate_memory(self, env, ring, seed=None):
+        """populate_memory (MPS:9-29): fill the ring to capacity with uniform random actions.  The
+        reference runs ceil(MEM/72) sequential 72-step episodes; here that many envs of the batch run
+        them in ONE launch (shems_rollout_dev) and push in the reference's episode-major order."""
+        seed = self.rng_seed if seed is None else int(seed)
+        nsteps = env.maxsteps
+        n_ep = -(-ring.capacity // nsteps)                    # episodes until length(memory) >= MIN_EXP_SIZE
+        while len(ring) < ring.capacity:
+            env.reset_(seed, episode=0x7FFF0000 + ring.pushed // max(1, nsteps))
+            env.rollout("random", nsteps, seed=seed + ring.pushed, ring=ring, ring_envs=min(env.n, n_ep))
+        return ring
+
+    def episode_(self, env, ring=None, train=True, num_steps=None, rng_ep=0, episode=0, updates_per_step=1,
+                 window_count=None):
+        """episode!(env; train, rng_ep) (DDPG.jl:186-242) for every env of the batch at once.  Returns the
+        per-env episode returns (float64 device tensor).  train=True: exploration noise, replay insert
+        of a rotating window of envs and `updates_per_step` x replay() per vector step."""
+        t = self.torch
+        num_steps = env.maxsteps if num_steps is None else int(num_steps)
+        if rng_ep == -1:
+            env.reset_(-1)
+        else:
+            env.reset_(rng_ep, episode=episode)
+        returns = t.zeros(env.n, dtype=t.float64, device=self.device)
+        if train and ring is None:
+            raise ValueError("training episodes need a replay ring")
+        if window_count is None and ring is not None:
+            window_count = min(env.n, max(1, ring.capacity // num_steps))       # SURVEY.md 8(d) replay-capacity note
+        for step in range(num_steps):
+            tick = (int(episode) * 4096 + step) & 0xFFFFFFFF
+            win = None
+            if train:
+                win = RingWindow(ring.pos, window_count, (self.tick * window_count) % env.n)
+            self.act_step(env, train=train, tick=tick, returns_acc=returns, ring=ring if train else None, window=win)
+            if train:
+                ring.pushed += window_count
+                for _ in range(updates_per_step):
+                    self.replay(ring)
+            self.tick += 1
+        return returns
+
+    def run_episodes(self, env_train, env_eval, ring, num_ep, test_every=100, test_runs=100, seed=None,
+                     updates_per_step=1, on_eval=None):
+        """run_episodes (DDPG.jl:244-298): train episodes, an evaluation sweep every `test_every` episodes
+        (when i % test_every == 1) and a snapshot of the best-scoring actor.  Returns
+        (total_reward [num_ep], score_mean [ceil(num_ep/test_every)], best_run, best_actor)."""
+        seed = self.seed if seed is None else int(seed)
+        total_reward = np.zeros(num_ep, np.float32)
+        score_mean = np.zeros(-(-num_ep // test_every), np.float64)
+        best_score, best_run, best_actor = -100000.0, 0, None
+        for i in range(1, num_ep + 1):
+            ret = self.episode_(env_train, ring, train=True, rng_ep=seed, episode=i, updates_per_step=updates_per_step)
+            total_reward[i - 1] = self.sync.mean_scalar(ret.mean().item(), env_train.n)
+            if i % test_every == 1:
+                idx = -(-i // test_every)
+                # the eval env has nrow - maxsteps = 1 => every test episode starts at idx 1 and differs in Soc_b only
+                score = self.episode_(env_eval, None, train=False, num_steps=EP_LENGTH_TRAIN, rng_ep=123, episode=idx)
+                score_mean[idx - 1] = self.sync.mean_scalar(score.mean().item(), env_eval.n)
+                if score_mean[idx - 1] > best_score:
+                    best_score, best_run = score_mean[idx - 1], i
+                    best_actor = self.actor.detach().cpu().numpy().copy()
+                if on_eval:
+                    on_eval(i, total_reward[i - 1], score_mean[idx - 1])
+        return total_reward, score_mean, best_run, best_actor
+
+
+class TrainWorkload:
+    """bench.py's "train" step: the body of the reference's episode! loop for all envs of a rank at once --
+    act + noise + scale_action + step! + remember (one fused launch) and `updates` x replay() (15 launches
+    each, 2 gradient all-reduces when several GPUs train one model)."""
+
+    name = "train"
+    dtype = "f32"
+    EP_LEN = EP_LENGTH_TRAIN
+
+    def __init__(self, S, torch, n, seed, updates=1, dist=None):
+        self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
+        self.tab = S.tables.synthetic_table("train", 98)
+        self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
+                                device=torch.cuda.current_device()).use_torch_stream()
+        self.env_seed = int(seed)
+        self.agent = Agent(seed=1231, rng_seed=self.env_seed)   # same initial weights on every rank (config: seed 1231)
+        if dist is not None:
+            self.agent.enable_data_parallel(dist)
+        self.ring = ReplayRing(MEM_SIZE)
+        self.agent.populate_memory(self.env, self.ring, seed=self.env_seed)          # MAIN:28
+        self.agent.min_max_buffer(self.ring, MEM_SIZE, seed=self.env_seed)           # MAIN:30
+        self.win = min(self.n, MEM_SIZE // self.EP_LEN)
+        self.rew32 = torch.empty(self.n, dtype=torch.float32, device="cuda")
+        self.t = 0
+        self.episode = 1
+        self.env.reset_(self.env_seed, episode=self.episode)
+
+    def _act(self, tick):
+        w = RingWindow(self.ring.pos, self.win, (tick * self.win) % self.n)
+        self.agent.act_step(self.env, train=True, tick=tick, rewards_f32=self.rew32, ring=self.ring, window=w)
+        self.ring.pushed += self.win
+
+    def step(self):
+        if self.t and self.t % self.EP_LEN == 0:
+            self.episode += 1
+            v = self.env.view()
+            _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, self.episode, self.env._stream()))
+        self._act(self.t)
+        for _ in range(self.updates):
+            self.agent.replay(self.ring)
+        self.t += 1
+
+    def finish(self):
+        self.env.check_error()
+        if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
+            raise RuntimeError("non-finite network parameters after the timed steps")
+
+    def kernel_pass(self, reps):
+        """HIP-event timing of the dominant kernel (the fused actor/step launch) on its own stream."""
+        torch = self.torch
+        reps = min(reps, 200)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        self.env.reset_(self.env_seed, episode=100000)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            if i and i % (self.EP_LEN - 1) == 0:
+                self.env.reset_(self.env_seed, episode=100000 + i)
+            a.record()
+            self._act(i)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ms) / len(ms)
+        # one replay() alone, for the updates/sec breakdown
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nup = 50
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nup):
+            self.agent.replay(self.ring)
+        e1.record()
+        torch.cuda.synchronize()
+        self.update_us = e0.elapsed_time(e1) * 1e3 / nup
+        flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # SURVEY.md 8(d): 256 500 FLOP / env-step
+        return dict(kernel="shems::k_act<TM>", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
+
+    def extra(self):
+        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE,
+                "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
+                "update_mflop": 307.8}
+
+
+def smoke():
+    """One tiny train iteration on cuda:0: populate, normalise, 3 fused steps + updates; finite + oracle-checked."""
+    import importlib
+    import torch
+    pkg = importlib.import_module(__name__.rsplit(".", 1)[0])
+    wl = TrainWorkload(pkg, torch, 2048, seed=7, updates=1)
+    before = wl.agent.actor.clone()
+    for _ in range(3):
+        wl.step()
+    wl.finish()
+    assert not torch.equal(before, wl.agent.actor), "actor did not move"
+    assert len(wl.ring) == MEM_SIZE

@@ -187,7 +187,7 @@ class ShemsBatch:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def rollout(self, policy, nsteps, seed=0, ring=None):
+    def rollout(self, policy, nsteps, seed=0, ring=None, ring_envs=0):
         """`nsteps` x { a = policy(env); step! } in one launch (shems_rollout_dev).  policy: "rule"
         (action(env, track), track < 0) or "random" (populate_memory's uniform actions).  Returns the
         per-env episode returns as a float64 device tensor; pushes into `ring` if given."""
@@ -198,9 +198,9 @@ class ShemsBatch:
         rs = ring.struct() if ring is not None else None
         _capi.check(self._L.shems_rollout_dev(C.byref(v), pol, int(nsteps), int(seed) & ((1 << 64) - 1),
                                               C.c_void_p(ret.data_ptr()), C.byref(rs) if rs is not None else None,
-                                              ring.pos if ring is not None else 0, self._stream()))
+                                              ring.pos if ring is not None else 0, int(ring_envs), self._stream()))
         if ring is not None:
-            ring.pushed += self.n * int(nsteps)
+            ring.pushed += (self.n if ring_envs <= 0 else min(self.n, int(ring_envs))) * int(nsteps)
         return ret
 
     def step_dev(self, actions, track=0, rewards=None, rewards_f32=None, results=None, block_reward=None):

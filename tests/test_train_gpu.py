@@ -1,0 +1,78 @@
+"""GPU tests of the vectorised training loop (populate_memory, min_max_buffer, episode!, run_episodes)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import util as U
+from util import oracle_c
+import philox_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    torch = pytest.importorskip("torch")
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    return torch, S, D
+
+
+def test_populate_memory_fills_ring_in_reference_push_order():
+    torch, S, D = _mods()
+    tab = S.tables.synthetic_table("train", 98)
+    n = 1000
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    ag = D.Agent(seed=3)
+    ring = D.ReplayRing(D.MEM_SIZE)
+    ag.populate_memory(env, ring, seed=42)
+    assert len(ring) == D.MEM_SIZE and ring.pushed == 334 * 72            # ceil(24000/72) episodes, as the reference loop
+    # replay the same 334 episodes on the CPU oracle: slot (e*72 + t) mod 24000, the first 48 pushes overwritten
+    ref = oracle_c.Batch(334, 72, tab, oracle_c.profile(98))
+    env2 = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])])
+    env2.reset_(42, episode=0x7FFF0000)
+    ref.set_state(env2.state[:334], env2.idx[:334])
+    S_, A_, R_, S2_ = (t.cpu().numpy() for t in (ring.s, ring.a, ring.r, ring.s2))
+    for t in range(72):
+        raw = philox_np.random_actions(42, t, n)[:334]
+        pre = ref.state()
+        _, r, o, _ = ref.step(oracle_c.scale_action(raw), 0)
+        order = np.arange(334) * 72 + t
+        keep = order >= 48
+        slots = order[keep] % D.MEM_SIZE
+        assert (U.bits32(S_[slots]) == U.bits32(pre[keep])).all() and (U.bits32(S2_[slots]) == U.bits32(o[keep])).all()
+        assert (U.bits32(A_[slots]) == U.bits32(raw[keep])).all() and (R_[slots] == r[keep].astype(np.float32)).all()
+    mn, mx = ag.min_max_buffer(ring, D.MEM_SIZE, seed=1)
+    assert (mn.cpu().numpy() >= S_.min(0)).all() and (mx.cpu().numpy() <= S_.max(0)).all()
+    assert mn[5].item() == mx[5].item() == np.float32(0.4)                # constant p_buy normalises to 0
+    env.close(); env2.close()
+
+
+def test_episode_returns_match_stepwise_rewards_and_eval_is_deterministic():
+    torch, S, D = _mods()
+    tab = S.tables.synthetic_table("train", 98)
+    ev = S.tables.synthetic_table("eval", 98)
+    n = 512
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    env_eval = S.ShemsBatch(100, 1439, [ev], [S.make_config(98, 0, ev.shape[0])]).use_torch_stream()
+    ag = D.Agent(seed=5)
+    ring = D.ReplayRing(D.MEM_SIZE)
+    ag.populate_memory(env, ring)
+    ag.min_max_buffer(ring)
+    # deterministic evaluation: same seed => same returns; all start at idx = 1 (nrow - maxsteps = 1)
+    r1 = ag.episode_(env_eval, None, train=False, num_steps=72, rng_ep=123, episode=1).cpu().numpy()
+    assert (env_eval.idx == 73).all() and (env_eval.step == 72).all()
+    r2 = ag.episode_(env_eval, None, train=False, num_steps=72, rng_ep=123, episode=1).cpu().numpy()
+    assert (r1 == r2).all() and len(np.unique(r1)) > 50                    # differ through the drawn Soc_b only
+    # a training episode: returns accumulate the per-step rewards; ring advances by window * steps; nets move
+    a0 = ag.actor.clone()
+    pushed0, upd0 = ring.pushed, ag.updates
+    ret = ag.episode_(env, ring, train=True, rng_ep=9, episode=1, updates_per_step=1).cpu().numpy()
+    assert ring.pushed - pushed0 == 72 * min(n, D.MEM_SIZE // 72) and ag.updates - upd0 == 72
+    assert np.isfinite(ret).all() and not torch.equal(a0, ag.actor)
+    env.check_error()
+    # run_episodes bookkeeping (eval on episode 1, i % test_every == 1)
+    tr, sm, best_run, best_actor = ag.run_episodes(env, env_eval, ring, num_ep=3, test_every=2, test_runs=100)
+    assert tr.shape == (3,) and sm.shape == (2,) and best_run in (1, 3) and best_actor.shape == (D.N_ACTOR,)
+    assert np.isfinite(tr).all() and np.isfinite(sm).all()
+    env.close(); env_eval.close()
