@@ -2,18 +2,24 @@
 // gfx950 kernels: GPU-resident minibatch sampling/gather, target pass, critic forward/backward,
 // actor forward/backward through the critic, Flux-style ADAM and the soft target updates.
 //
-// Shapes (BATCH = 120, padded to BP = 128 columns; pad columns carry zero error signals):
-// everything is FEATURE-major "[k][m]" (sample index contiguous), as in shems_policy.hip, so the
-// 250x500 layer runs on v_mfma_f32_32x32x2_f32 with the weights as the A operand straight out of
-// Flux's [in][out] layout.  At batch 120 the update is launch/latency bound (307.8 MFLOP, ~2 us at
-// the fp32 MFMA peak), so the design goal is few, wide launches: 32x32 output tiles, one per wave,
-// operands read from L2 (the whole working set is < 6 MB), 15 launches per update:
-//   prep(sample+gather+normalize+3x layer-1) -> L2fwd(actor_t) -> head(a', layer-1 critic_t)
-//   -> L2fwd(critic_t, critic, actor) -> head(y, q, dq, dW3, D2) -> L2bwd(critic: dW2 || dH1)
-//   -> L1bwd(critic)            [all-reduce]  -> adam+soft(critic)
-//   -> head(a_pi, layer-1 critic) -> L2fwd(critic on [s; a_pi], emits D2) -> L2bwd(dH1)
-//   -> head(da, d3, dW3, D2 actor) -> L2bwd(actor: dW2 || dH1) -> L1bwd(actor)
-//                               [all-reduce]  -> adam+soft(actor)
+// Shapes: BATCH = 120 padded to BP = 128 columns (pad columns carry zero error signals); everything
+// is FEATURE-major "[k][m]" (sample index contiguous) as in shems_policy.hip, so the 250x500 layer
+// runs on v_mfma_f32_32x32x2_f32 with the weights as the A operand straight out of Flux's [in][out]
+// layout.  At batch 120 one update is 307.8 MFLOP (~2 us at the fp32 MFMA peak): it is bound by
+// dependent-launch boundaries (~1.5 us each) and by L2/Infinity-Cache latency, not by the matrix
+// pipe.  Design rules that follow from the first measured version (profiles/r01_train_v1_*):
+//   * no single-workgroup latency chains: every phase is spread over 16-64 workgroups;
+//   * operands are staged into LDS with wide, independent loads (one latency per phase), never
+//     fetched per MFMA k-step;
+//   * nothing derivable is stored: layer-1 activations, their relu masks and the back-propagated
+//     layer-2 error D2 = (W3 d3) .* (h2 > 0) are recomputed inside the kernels that consume them;
+//   * cross-workgroup reductions go through partial slabs summed in a fixed order (bitwise
+//     reproducible; no float atomics).
+// 13 launches per update:
+//   prep -> fwd(actor_t) -> fwd(critic_t | critic | actor) -> head(loss) -> bwd(critic) -> l1bwd(critic)
+//   [all-reduce] adam+soft(critic)
+//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> head(actor) -> bwd(actor) -> l1bwd(actor)
+//   [all-reduce] adam+soft(actor)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -27,17 +33,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BP = 128;            // padded batch (columns)
 constexpr int H1N = SHEMS_L1, H2N = SHEMS_L2;
-constexpr int H1P = 256, H2P = 512;
 constexpr int SIN = 9, AIN = 2, CIN = 11;
+constexpr int NT = 16;             // n-tiles of 32 over the 500 (512) layer-2 outputs
+constexpr int KT = 8;              // k-tiles of 32 over the 250 (256) layer-1 outputs
+constexpr int NQ = 4;              // quarters of the n range for the input-gradient tiles
+constexpr int NQW = H2N / NQ;      // 125 n per quarter
 
-// ---- parameter block offsets (Flux order W1 b1 W2 b2 W3 b3) -------------------------------------
 __host__ __device__ constexpr int off_b1(int in) { return in * H1N; }
 __host__ __device__ constexpr int off_w2(int in) { return in * H1N + H1N; }
 __host__ __device__ constexpr int off_b2(int in) { return off_w2(in) + H1N * H2N; }
 __host__ __device__ constexpr int off_w3(int in) { return off_b2(in) + H2N; }
 __host__ __device__ constexpr int off_b3(int in, int out) { return off_w3(in) + H2N * out; }
 
-// ---- workspace carve -----------------------------------------------------------------------------
+// ---- workspace carve (floats) --------------------------------------------------------------------
 constexpr int64_t WS_XT = 0;                         // [9][BP]  normalize(s)
 constexpr int64_t WS_X2T = WS_XT + SIN * BP;          // [9][BP]  normalize(s')
 constexpr int64_t WS_AT = WS_X2T + SIN * BP;          // [2][BP]  stored (unscaled) actions
@@ -45,215 +53,21 @@ constexpr int64_t WS_R = WS_AT + AIN * BP;            // [BP]
 constexpr int64_t WS_DONE = WS_R + BP;
 constexpr int64_t WS_Y = WS_DONE + BP;
 constexpr int64_t WS_Q = WS_Y + BP;
-constexpr int64_t WS_DQ = WS_Q + BP;
-constexpr int64_t WS_API = WS_DQ + BP;                // [2][BP]  a_pi = actor(s)
-constexpr int64_t WS_D3A = WS_API + AIN * BP;         // [2][BP]  dL/d(pre-tanh) of the actor head
-constexpr int64_t WS_IDX = WS_D3A + AIN * BP;         // [BP]     sampled ring slots (as int32)
-constexpr int64_t WS_SLOT0 = WS_IDX + BP;
-constexpr int64_t SL_H1 = 0;                          // [250][BP]
-constexpr int64_t SL_H1T = SL_H1 + H1N * BP;          // [BP][256]
-constexpr int64_t SL_H2 = SL_H1T + BP * H1P;          // [500][BP]
-constexpr int64_t SL_D2 = SL_H2 + H2N * BP;           // [500][BP]
-constexpr int64_t SL_D2T = SL_D2 + H2N * BP;          // [BP][512]
-constexpr int64_t SL_D1 = SL_D2T + BP * H2P;          // [250][BP]
-constexpr int64_t SL_SIZE = SL_D1 + H1N * BP;
+constexpr int64_t WS_API = WS_Q + BP;                 // [2][BP]  a_pi = actor(s)
+constexpr int64_t WS_D3C = WS_API + AIN * BP;         // [1][BP]  dq of the critic loss
+constexpr int64_t WS_D3Q = WS_D3C + BP;               // [1][BP]  -1/B (actor loss through the critic)
+constexpr int64_t WS_D3A = WS_D3Q + BP;               // [2][BP]  error at the actor's pre-tanh output
+constexpr int64_t WS_IDX = WS_D3A + AIN * BP;         // [BP]     sampled ring slots (int32)
+constexpr int64_t WS_DAP = WS_IDX + BP;               // [KT][NQ][2][BP]  partial d loss / d a_pi
+constexpr int64_t WS_SLOT0 = WS_DAP + KT * NQ * AIN * BP;
+constexpr int64_t SL_H2 = 0;                          // [500][BP]          relu(W2' h1 + b2)
+constexpr int64_t SL_P3 = SL_H2 + H2N * BP;           // [NT][2][BP]        per-n-tile partial sums of layer 3
+constexpr int64_t SL_D1P = SL_P3 + NT * 2 * BP;       // [NQ][250][BP]      partial (unmasked) error at layer 1
+constexpr int64_t SL_SIZE = SL_D1P + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
 constexpr int64_t WS_FLOATS = WS_SLOT0 + N_SLOTS * SL_SIZE;
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
-
-// ---- layer 1 for a k-range: H1[k][m] = relu(b1[k] + sum_j W1[j][k] x[j][m]) -----------------------
-// x is an LDS image [in][BP].  Optionally also writes the transposed copy H1T[m][k].
-__device__ __forceinline__ void layer1_range(const float *__restrict__ P, int in, const float *x, int k0, int k1,
-                                             float *__restrict__ H1, float *__restrict__ H1T)
-{
-    const int nk = k1 - k0;
-    for (int e = threadIdx.x; e < nk * BP; e += blockDim.x) {
-        const int kl = e / BP, m = e - kl * BP, k = k0 + kl;
-        float acc = P[off_b1(in) + k];
-        for (int j = 0; j < in; ++j) acc = fmaf(P[j * H1N + k], x[j * BP + m], acc);
-        const float h = fmaxf(acc, 0.0f);
-        H1[k * BP + m] = h;
-        if (H1T) H1T[m * H1P + k] = h;
-    }
-}
-
-// ---- kernel A: sample + gather + normalize + layer 1 of actor_t(s'), critic([s;a]), actor(s) --------
-__global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed,
-                                              uint32_t tick)
-{
-    __shared__ float xs[CIN * BP];     // rows 0..8 normalize(s), rows 9..10 a
-    __shared__ float x2[SIN * BP];     // normalize(s')
-    const int t = threadIdx.x;
-    float *ws = d.ws;
-    if (t < BP) {
-        const int m = t;
-        float s[SIN], s2[SIN], a0 = 0.f, a1 = 0.f, r = 0.f, dn = 0.f;
-        int64_t j = 0;
-        const bool live = m < d.batch;
-        if (live) {
-            // StatsBase.sample(rng, memory, BATCH) -- with replacement (MPS:33)
-            const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
-            const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
-            j = (int64_t)(w % (uint32_t)ring_len);
-#pragma unroll
-            for (int k = 0; k < SIN; ++k) { s[k] = ring.s[j * SIN + k]; s2[k] = ring.s2[j * SIN + k]; }
-            a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
-            r = ring.r[j];
-            dn = ring.done[j] ? 1.0f : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < SIN; ++k) {
-            const float den = (d.s_max[k] - d.s_min[k]) + 1e-8f;                 // MPS:56
-            xs[k * BP + m] = live ? (s[k] - d.s_min[k]) / den : 0.0f;
-            x2[k * BP + m] = live ? (s2[k] - d.s_min[k]) / den : 0.0f;
-        }
-        xs[9 * BP + m] = a0;
-        xs[10 * BP + m] = a1;
-        if (blockIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < SIN; ++k) { ws[WS_XT + k * BP + m] = xs[k * BP + m]; ws[WS_X2T + k * BP + m] = x2[k * BP + m]; }
-            ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
-            ws[WS_R + m] = r; ws[WS_DONE + m] = dn;
-            reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = live ? (int32_t)j : -1;
-        }
-    }
-    __syncthreads();
-    const int per = (H1N + gridDim.x - 1) / gridDim.x;
-    const int k0 = blockIdx.x * per, k1 = min(H1N, k0 + per);
-    if (k0 < k1) {
-        layer1_range(d.actor_t, SIN, x2, k0, k1, slot(ws, SLOT_ACTOR_T) + SL_H1, nullptr);
-        layer1_range(d.critic, CIN, xs, k0, k1, slot(ws, SLOT_CRITIC) + SL_H1, slot(ws, SLOT_CRITIC) + SL_H1T);
-        layer1_range(d.actor, SIN, xs, k0, k1, slot(ws, SLOT_ACTOR) + SL_H1, slot(ws, SLOT_ACTOR) + SL_H1T);
-    }
-}
-
-// ---- kernel B: layer 2 forward, one 32(n) x 32(m) tile per wave ------------------------------------
-struct L2FwdJob {
-    const float *P;        // parameter block of the network
-    int in;                // its input width (9 or 11)
-    const float *H1;       // [250][BP]
-    float *H2;             // [500][BP]  relu(W2' h1 + b2)
-    float *D2, *D2T;       // optional: D2[n][m] = d2_scale * W3[n][0] * (h2 > 0) for m < batch (critic inside the actor loss)
-    float d2_scale;
-};
-struct L2FwdArgs { L2FwdJob job[3]; int batch; };
-
-__global__ __launch_bounds__(256) void k_l2fwd(L2FwdArgs A)
-{
-    const L2FwdJob J = A.job[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.x * 32, m0 = wave * 32;
-    const float *__restrict__ W2 = J.P + off_w2(J.in);
-    const float *__restrict__ pa = W2 + n0 + li;            // A[i = n][k] = W2[k][n0 + i]  (n >= 500 reads b2: discarded)
-    const float *__restrict__ pb = J.H1 + m0 + li;          // B[k][j = m] = H1[k][m0 + j]
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll 5
-    for (int ks = 0; ks < H1N / 2; ++ks) {
-        const int k = 2 * ks + lh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k * H2N], pb[k * BP], acc, 0, 0, 0);
-    }
-    const float *b2 = J.P + off_b2(J.in), *W3 = J.P + off_w3(J.in);
-    const int m = m0 + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < H2N) {
-            const float h = fmaxf(acc[r] + b2[n], 0.0f);
-            J.H2[n * BP + m] = h;
-            if (J.D2) {
-                const float dv = (h > 0.0f && m < A.batch) ? J.d2_scale * W3[n] : 0.0f;
-                J.D2[n * BP + m] = dv;
-                J.D2T[m * H2P + n] = dv;
-            }
-        }
-    }
-}
-
-// ---- kernel D: layer 2 backward tiles --------------------------------------------------------------
-//   W tiles (8 x 16): gW2[k][n] = sum_m H1T[m][k] * D2T[m][n]                       (K = BP)
-//   I tiles (8 x 4) : D1[k][m]  = (sum_n W2[k][n] * D2[n][m]) * (H1[k][m] > 0)       (K = 500)
-struct L2BwdArgs {
-    const float *H1T, *D2T; float *gW2;        // W part (gW2 = null: skip)
-    const float *W2, *D2, *H1; float *D1;      // I part
-    int n_w_tiles;                             // 128 or 0
-};
-
-__global__ __launch_bounds__(256) void k_l2bwd(L2BwdArgs A)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    if (tile < A.n_w_tiles) {
-        const int k0 = (tile >> 4) * 32, n0 = (tile & 15) * 32;
-        const float *__restrict__ pa = A.H1T + k0 + li;     // A[i = k][kk = m] = H1T[m][k0 + i]
-        const float *__restrict__ pb = A.D2T + n0 + li;     // B[kk = m][j = n] = D2T[m][n0 + j]
-#pragma unroll 8
-        for (int ms = 0; ms < BP / 2; ++ms) {
-            const int m = 2 * ms + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m * H1P], pb[m * H2P], acc, 0, 0, 0);
-        }
-        const int n = n0 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (k < H1N && n < H2N) A.gW2[k * H2N + n] = acc[r];
-        }
-    } else {
-        const int t = tile - A.n_w_tiles;
-        if (t >= 32) return;
-        const int k0 = (t >> 2) * 32, m0 = (t & 3) * 32;
-        const int krow = min(k0 + li, H1N - 1);              // rows >= 250 do not exist: clamp, discard later
-        const float *__restrict__ pa = A.W2 + (int64_t)krow * H2N;   // A[i = k][kk = n] = W2[k0 + i][n]
-        const float *__restrict__ pb = A.D2 + m0 + li;               // B[kk = n][j = m] = D2[n][m0 + j]
-#pragma unroll 8
-        for (int ns = 0; ns < H2N / 2; ++ns) {
-            const int n = 2 * ns + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[n], pb[n * BP], acc, 0, 0, 0);
-        }
-        const int m = m0 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (k < H1N) A.D1[k * BP + m] = A.H1[k * BP + m] > 0.0f ? acc[r] : 0.0f;
-        }
-    }
-}
-
-// ---- kernel C: the heads (layer 3 and everything that hangs off it), one 1024-thread workgroup ------
-enum { HEAD_TARGET_ACTOR = 0, HEAD_ACTOR = 1, HEAD_CRITIC_LOSS = 2, HEAD_ACTOR_BWD = 3 };
-
-// out[o][m] = sum_n W3[n][o] * H2[n][m] for o < OUT, all 128 m.  8 n-groups x 128 m threads, LDS reduce.
-template <int OUT>
-__device__ __forceinline__ void layer3_all(const float *__restrict__ W3, const float *__restrict__ H2, float *red /*[8][OUT][BP]*/,
-                                           float *out /*[OUT][BP] in LDS*/)
-{
-    const int g = threadIdx.x >> 7, m = threadIdx.x & 127;
-    float acc[OUT];
-#pragma unroll
-    for (int o = 0; o < OUT; ++o) acc[o] = 0.0f;
-    const int na = g * 63, nb = min(H2N, na + 63);
-    for (int n = na; n < nb; ++n) {
-        const float h = H2[n * BP + m];
-#pragma unroll
-        for (int o = 0; o < OUT; ++o) acc[o] = fmaf(W3[n * OUT + o], h, acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < OUT; ++o) red[(g * OUT + o) * BP + m] = acc[o];
-    __syncthreads();
-    if (threadIdx.x < OUT * BP) {
-        const int o = threadIdx.x / BP, mm = threadIdx.x - o * BP;
-        float s = 0.0f;
-#pragma unroll
-        for (int gg = 0; gg < 8; ++gg) s += red[(gg * OUT + o) * BP + mm];
-        out[o * BP + mm] = s;
-    }
-    __syncthreads();
-}
 
 __device__ __forceinline__ float wave_sum(float x)
 {
@@ -262,156 +76,406 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
-// gW3[n][o] = sum_m H2[n][m] * d3[o][m] (wave per n), D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (H2 > 0), D2T.
-template <int OUT>
-__device__ __forceinline__ void head_backward(const float *__restrict__ W3, const float *__restrict__ H2, const float *d3 /*LDS [OUT][BP]*/,
-                                              float *__restrict__ gW3, float *__restrict__ D2, float *__restrict__ D2T)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int n = wave; n < H2N; n += 16) {
-        const float h0 = H2[n * BP + lane], h1 = H2[n * BP + 64 + lane];
-#pragma unroll
-        for (int o = 0; o < OUT; ++o) {
-            const float s = wave_sum(h0 * d3[o * BP + lane] + h1 * d3[o * BP + 64 + lane]);
-            if (lane == 0) gW3[n * OUT + o] = s;
-        }
-    }
-    for (int e = threadIdx.x; e < H2N * BP; e += blockDim.x) {
-        const int n = e / BP, m = e - n * BP;
-        float v = 0.0f;
-#pragma unroll
-        for (int o = 0; o < OUT; ++o) v = fmaf(W3[n * OUT + o], d3[o * BP + m], v);
-        v = H2[e] > 0.0f ? v : 0.0f;
-        D2[e] = v;
-        D2T[m * H2P + n] = v;
-    }
-}
+// Where a network input [in][BP] comes from: rows 0..8 = a normalised-state block, rows 9..10 (critics) either the
+// stored actions or tanh(b3 + sum of the layer-3 partials of an actor pass).
+struct XSrc {
+    const float *X;        // [9][BP]
+    const float *A;        // [2][BP] stored actions, or null
+    const float *P3;       // [NT][2][BP] actor partials, or null
+    const float *b3;       // actor b3 (with P3)
+    float *publish;        // optional [2][BP]: where workgroup 0 stores the computed action
+};
 
-__global__ __launch_bounds__(1024) void k_head(shems_ddpg d, int mode)
+template <int IN>
+__device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
 {
-    __shared__ float red[8 * 2 * BP];
-    __shared__ float xa[CIN * BP];
-    __shared__ float o3[2 * BP];
-    __shared__ float d3[2 * BP];
-    __shared__ float sred[16];
-    float *ws = d.ws;
-    const int t = threadIdx.x;
-    const float invB = 1.0f / (float)d.batch;
-
-    if (mode == HEAD_TARGET_ACTOR || mode == HEAD_ACTOR) {
-        const bool tgt = mode == HEAD_TARGET_ACTOR;
-        const float *P = tgt ? d.actor_t : d.actor;
-        const float *H2 = slot(ws, tgt ? SLOT_ACTOR_T : SLOT_ACTOR) + SL_H2;
-        layer3_all<2>(P + off_w3(SIN), H2, red, o3);
-        const float *X = ws + (tgt ? WS_X2T : WS_XT);
-        for (int e = t; e < SIN * BP; e += blockDim.x) xa[e] = X[e];
-        if (t < 2 * BP) {
-            const int o = t / BP;
-            const float a = tanhf(o3[t] + P[off_b3(SIN, 2) + o]);                 // Dense(500, 2, tanh)
-            xa[SIN * BP + t] = a;
-            if (!tgt) ws[WS_API + t] = a;
-        }
-        __syncthreads();
-        const float *PC = tgt ? d.critic_t : d.critic;
-        float *S = slot(ws, tgt ? SLOT_CRITIC_T : SLOT_CRITIC2);
-        layer1_range(PC, CIN, xa, 0, H1N, S + SL_H1, nullptr);                    // vcat(s_norm, a) -> Dense(11, 250, relu)
-    } else if (mode == HEAD_CRITIC_LOSS) {
-        layer3_all<1>(d.critic_t + off_w3(CIN), slot(ws, SLOT_CRITIC_T) + SL_H2, red, o3);        // q'
-        layer3_all<1>(d.critic + off_w3(CIN), slot(ws, SLOT_CRITIC) + SL_H2, red, o3 + BP);       // q
-        float sq = 0.0f;
-        if (t < BP) {
-            const float q2 = o3[t] + d.critic_t[off_b3(CIN, 1)];
-            const float q = o3[BP + t] + d.critic[off_b3(CIN, 1)];
-            const float y = ws[WS_R + t] + d.gamma * (1.0f - ws[WS_DONE + t]) * q2;               // DDPG.jl:133
-            const bool live = t < d.batch;
-            const float diff = live ? q - y : 0.0f;
-            ws[WS_Y + t] = y; ws[WS_Q + t] = q;
-            const float dq = 2.0f * diff * invB;                                                  // d mse / d q
-            ws[WS_DQ + t] = dq;
-            d3[t] = dq;
-            sq = diff * diff;
-        }
-        // loss = mean((q - y)^2), gb3 = sum(dq)
-        float s1 = wave_sum(sq), s2 = wave_sum(t < BP ? d3[t < BP ? t : 0] : 0.0f);
-        if (t < BP && (t & 63) == 0) { sred[t >> 6] = s1; sred[4 + (t >> 6)] = s2; }
-        __syncthreads();
-        if (t == 0) {
-            d.losses[0] = (sred[0] + sred[1]) * invB;
-            d.grad_critic[off_b3(CIN, 1)] = sred[4] + sred[5];
-        }
-        float *S = slot(ws, SLOT_CRITIC);
-        head_backward<1>(d.critic + off_w3(CIN), S + SL_H2, d3, d.grad_critic + off_w3(CIN), S + SL_D2, S + SL_D2T);
-    } else {   // HEAD_ACTOR_BWD
-        // da[o][m] = sum_k W1c[9 + o][k] * D1c[k][m]   (critic input gradient, action rows only)
-        {
-            const int g = t >> 7, m = t & 127;
-            const float *D1 = slot(ws, SLOT_CRITIC2) + SL_D1;
-            const float *W1 = d.critic;
-            float a0 = 0.0f, a1 = 0.0f;
-            const int ka = g * 32, kb = min(H1N, ka + 32);
-            for (int k = ka; k < kb; ++k) {
-                const float v = D1[k * BP + m];
-                a0 = fmaf(W1[9 * H1N + k], v, a0);
-                a1 = fmaf(W1[10 * H1N + k], v, a1);
+    for (int e = threadIdx.x; e < SIN * BP; e += blockDim.x) xs[e] = s.X[e];
+    if (IN == CIN) {
+        for (int e = threadIdx.x; e < AIN * BP; e += blockDim.x) {
+            float a;
+            if (s.A) {
+                a = s.A[e];
+            } else {
+                const int o = e / BP, m = e - o * BP;
+                float acc = s.b3[o];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc += s.P3[(t * 2 + o) * BP + m];
+                a = tanhf(acc);                                   // Dense(500, 2, tanh)
+                if (publisher && s.publish) s.publish[e] = a;
             }
-            red[(g * 2 + 0) * BP + m] = a0;
-            red[(g * 2 + 1) * BP + m] = a1;
+            xs[SIN * BP + e] = a;
         }
-        // q of the critic inside the actor loss (for the reported loss only)
-        __syncthreads();
-        if (t < 2 * BP) {
-            float s = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) s += red[(g * 2 + t / BP) * BP + (t & 127)];
-            const float a = ws[WS_API + t];
-            d3[t] = s * (1.0f - a * a);                      // through tanh
-            ws[WS_D3A + t] = d3[t];
-        }
-        __syncthreads();
-        layer3_all<1>(d.critic + off_w3(CIN), slot(ws, SLOT_CRITIC2) + SL_H2, red, o3);
-        float qs = (t < d.batch) ? o3[t] + d.critic[off_b3(CIN, 1)] : 0.0f;
-        float g0 = t < BP ? d3[t] : 0.0f, g1 = t < BP ? d3[BP + t] : 0.0f;
-        qs = wave_sum(qs); g0 = wave_sum(g0); g1 = wave_sum(g1);
-        if (t < BP && (t & 63) == 0) { sred[t >> 6] = qs; sred[4 + (t >> 6)] = g0; sred[8 + (t >> 6)] = g1; }
-        __syncthreads();
-        if (t == 0) {
-            d.losses[1] = -(sred[0] + sred[1]) * invB;       // loss_act = -mean(critic(vcat(s, actor(s))))
-            d.grad_actor[off_b3(SIN, 2) + 0] = sred[4] + sred[5];
-            d.grad_actor[off_b3(SIN, 2) + 1] = sred[8] + sred[9];
-        }
-        float *S = slot(ws, SLOT_ACTOR);
-        head_backward<2>(d.actor + off_w3(SIN), S + SL_H2, d3, d.grad_actor + off_w3(SIN), S + SL_D2, S + SL_D2T);
     }
 }
 
-// ---- kernel E: layer-1 / bias gradients ---------------------------------------------------------------
-//   gW1[j][k] = sum_m x[j][m] D1[k][m],  gb1[k] = sum_m D1[k][m],  gb2[n] = sum_m D2[n][m]
-__global__ __launch_bounds__(1024) void k_l1bwd(const float *__restrict__ X /*[9][BP]*/, const float *__restrict__ XA /*[2][BP] or null*/,
-                                                int in, const float *__restrict__ D1, const float *__restrict__ D2,
-                                                float *__restrict__ grad)
+// h1[k][m] = relu(b1[k] + sum_j W1[j][k] x[j][m]) with W1/b1 in LDS (w1: [IN][250] then b1[250]).
+template <int IN>
+__device__ __forceinline__ float h1_at(const float *w1, const float *xs, int k, int m)
+{
+    float acc = w1[IN * H1N + k];
+#pragma unroll
+    for (int j = 0; j < IN; ++j) acc = fmaf(w1[j * H1N + k], xs[j * BP + m], acc);
+    return fmaxf(acc, 0.0f);
+}
+
+// ---- kernel A: sample + gather + normalize -----------------------------------------------------------
+__global__ __launch_bounds__(128) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick)
+{
+    const int m = threadIdx.x;
+    float *ws = d.ws;
+    float s[SIN], s2[SIN], a0 = 0.f, a1 = 0.f, r = 0.f, dn = 0.f;
+    int64_t j = -1;
+    const bool live = m < d.batch;
+    if (live) {
+        // StatsBase.sample(rng, memory, BATCH) -- with replacement (MPS:33)
+        const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
+        j = (int64_t)(w % (uint32_t)ring_len);
+#pragma unroll
+        for (int k = 0; k < SIN; ++k) { s[k] = ring.s[j * SIN + k]; s2[k] = ring.s2[j * SIN + k]; }
+        a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
+        r = ring.r[j];
+        dn = ring.done[j] ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < SIN; ++k) {
+        const float lo = d.s_min[k], den = (d.s_max[k] - lo) + 1e-8f;                 // MPS:56
+        ws[WS_XT + k * BP + m] = live ? (s[k] - lo) / den : 0.0f;
+        ws[WS_X2T + k * BP + m] = live ? (s2[k] - lo) / den : 0.0f;
+    }
+    ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
+    ws[WS_R + m] = r; ws[WS_DONE + m] = dn;
+    ws[WS_D3Q + m] = live ? -1.0f / (float)d.batch : 0.0f;                            // d(-mean q)/dq
+    reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = (int32_t)j;
+}
+
+// ---- kernel B: layers 1+2 forward for one 32-wide n-tile and all 128 columns --------------------------
+struct FwdJob {
+    const float *P;        // parameter block
+    int in;                // 9 (actor nets) or 11 (critic nets)
+    int out;               // 2 or 1
+    XSrc x;
+    float *H2;             // [500][BP] or null (target nets: nothing downstream needs it)
+    float *P3;             // [NT][2][BP] layer-3 partials of this n-tile
+};
+struct FwdArgs { FwdJob job[3]; };
+
+constexpr int FWD_KC = 126;                                   // k rows per phase (63 MFMA pairs), 2 phases
+constexpr int FWD_LDS = (FWD_KC * BP + FWD_KC * 32 + CIN * BP + CIN * H1N + H1N) * 4;
+
+template <int IN>
+__device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
+{
+    float *Hc = smem;                          // [126][BP]
+    float *Wc = Hc + FWD_KC * BP;              // [126][32]
+    float *xs = Wc + FWD_KC * 32;              // [IN][BP]
+    float *w1 = xs + CIN * BP;                 // W1 [IN][250], b1 [250]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const float *__restrict__ P = J.P;
+
+    build_x<IN>(J.x, xs, blockIdx.x == 0);
+    for (int e = tid; e < (IN * H1N + H1N) / 2; e += 256)
+        reinterpret_cast<float2 *>(w1)[e] = reinterpret_cast<const float2 *>(P)[e];
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float *__restrict__ W2 = P + off_w2(IN);
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        const int k0 = ph * FWD_KC, kn = ph == 0 ? FWD_KC : H1N - FWD_KC;      // 126 + 124 rows
+        // stage W2[k0..][n0..n0+31] (rows of 128 B) -- 8 float4 per row; columns >= 500 of the last tile read the
+        // next row / b2 (in bounds) and only feed output rows that are discarded
+        for (int e = tid; e < kn * 8; e += 256) {
+            const int kl = e >> 3, c = e & 7;
+            reinterpret_cast<float4 *>(Wc)[e] = *reinterpret_cast<const float4 *>(W2 + (int64_t)(k0 + kl) * H2N + n0 + 4 * c);
+        }
+        for (int e = tid; e < kn * BP; e += 256) {
+            const int kl = e >> 7, m = e & 127;
+            Hc[e] = h1_at<IN>(w1, xs, k0 + kl, m);
+        }
+        __syncthreads();
+        const float *pa = Wc + li, *pb = Hc + wave * 32 + li;
+#pragma unroll 9
+        for (int s = 0; s < kn / 2; ++s) {
+            const int kk = 2 * s + lh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * 32], pb[kk * BP], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
+    const float *b2 = P + off_b2(IN), *W3 = P + off_w3(IN);
+    const int m = wave * 32 + li;
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < H2N) {
+            const float h = fmaxf(acc[r] + b2[n], 0.0f);
+            if (J.H2) J.H2[n * BP + m] = h;
+            if (J.out == 2) { p0 = fmaf(h, W3[2 * n], p0); p1 = fmaf(h, W3[2 * n + 1], p1); }
+            else p0 = fmaf(h, W3[n], p0);
+        }
+    }
+    p0 += __shfl_xor(p0, 32, 64);
+    p1 += __shfl_xor(p1, 32, 64);
+    if (lh == 0) {
+        J.P3[(blockIdx.x * 2 + 0) * BP + m] = p0;
+        J.P3[(blockIdx.x * 2 + 1) * BP + m] = p1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fwd(FwdArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdJob &J = A.job[blockIdx.y];
+    if (J.in == SIN) fwd_body<SIN>(J, smem); else fwd_body<CIN>(J, smem);
+}
+
+// ---- kernel C: critic loss head (1 workgroup) ------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_head_loss(shems_ddpg d)
+{
+    __shared__ float red[4];
+    float *ws = d.ws;
+    const int m = threadIdx.x;
+    const float *Pt = slot(ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(ws, SLOT_CRITIC) + SL_P3;
+    float q2 = d.critic_t[off_b3(CIN, 1)], q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { q2 += Pt[(t * 2) * BP + m]; q += Pc[(t * 2) * BP + m]; }
+    const float y = ws[WS_R + m] + d.gamma * (1.0f - ws[WS_DONE + m]) * q2;            // DDPG.jl:133
+    const bool live = m < d.batch;
+    const float diff = live ? q - y : 0.0f;
+    const float dq = 2.0f * diff / (float)d.batch;                                       // d mse / d q
+    ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq;
+    const float s1 = wave_sum(diff * diff), s2 = wave_sum(dq);
+    if ((m & 63) == 0) { red[m >> 6] = s1; red[2 + (m >> 6)] = s2; }
+    __syncthreads();
+    if (m == 0) {
+        d.losses[0] = (red[0] + red[1]) / (float)d.batch;                                // Flux.mse
+        d.grad_critic[off_b3(CIN, 1)] = red[2] + red[3];
+    }
+}
+
+// ---- kernel D: layer-2 backward ---------------------------------------------------------------------------
+// D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (h2[n][m] > 0) is generated while staging, never stored.
+//   W workgroups (kt, nq): gW2[32 k][128 n] = sum_m h1[k][m] D2[n][m]; kt == 0 also emits gb2 and gW3.
+//   I workgroups (kt, nq): D1part[nq][32 k][128 m] = sum_{n in quarter} W2[k][n] D2[n][m]; for the critic inside the
+//                          actor loss they also emit the partial action gradient (through the layer-1 relu mask).
+struct BwdArgs {
+    const float *P;        // parameter block of the network being differentiated
+    int in, out;
+    XSrc x;                // its input (for the layer-1 recompute)
+    const float *H2;       // [500][BP]
+    const float *d3;       // [out][BP] error at the layer-3 pre-activation
+    float *grad;           // gradient block (W part) or null
+    float *D1P;            // [NQ][250][BP]
+    float *DAP;            // [KT][NQ][2][BP] or null
+    int n_w;               // number of W workgroups (32 or 0)
+};
+
+constexpr int BWD_LDS = (BP * 129 + 32 * 128 + CIN * BP + CIN * H1N + H1N + AIN * BP) * 4;
+
+template <int IN>
+__device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
+{
+    float *Bt = smem;                          // W: [128 m][129] D2^T panel;  I: [126 n][128 m] D2 panel
+    float *At = Bt + BP * 129;                 // W: [128 m][32 k] h1^T panel; I: [32 k][127] W2 panel
+    float *xs = At + 32 * 128;                 // [IN][BP]
+    float *w1 = xs + CIN * BP;                 // W1, b1
+    float *d3 = w1 + (CIN * H1N + H1N);        // [2][BP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const float *__restrict__ P = A.P;
+    const float *__restrict__ W3 = P + off_w3(IN);
+    const bool is_w = (int)blockIdx.x < A.n_w;
+    const int b = is_w ? blockIdx.x : blockIdx.x - A.n_w;
+    const int kt = b >> 2, nq = b & 3;
+
+    build_x<IN>(A.x, xs, false);
+    for (int e = tid; e < (IN * H1N + H1N) / 2; e += 256)
+        reinterpret_cast<float2 *>(w1)[e] = reinterpret_cast<const float2 *>(P)[e];
+    for (int e = tid; e < A.out * BP; e += 256) d3[e] = A.d3[e];
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    if (is_w) {
+        const int nbase = nq * 128;
+        // D2^T panel: Bt[m][nl] for the 128 n of this workgroup (n >= 500 -> 0)
+        for (int e = tid; e < 128 * BP; e += 256) {
+            const int nl = e >> 7, m = e & 127, n = nbase + nl;
+            float v = 0.0f;
+            if (n < H2N) {
+                const float g = A.out == 2 ? fmaf(W3[2 * n + 1], d3[BP + m], W3[2 * n] * d3[m]) : W3[n] * d3[m];
+                v = A.H2[n * BP + m] > 0.0f ? g : 0.0f;
+            }
+            Bt[m * 129 + nl] = v;
+        }
+        // h1^T panel: At[m][kl] for the 32 k of this workgroup (k >= 250 -> 0)
+        for (int e = tid; e < 32 * BP; e += 256) {
+            const int kl = e >> 7, m = e & 127, k = kt * 32 + kl;
+            At[m * 32 + kl] = k < H1N ? h1_at<IN>(w1, xs, k, m) : 0.0f;
+        }
+        __syncthreads();
+        const float *pa = At + li, *pb = Bt + wave * 32 + li;
+#pragma unroll 8
+        for (int s = 0; s < BP / 2; ++s) {
+            const int mm = 2 * s + lh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[mm * 32], pb[mm * 129], acc, 0, 0, 0);
+        }
+        float *gW2 = A.grad + off_w2(IN);
+        const int n = nbase + wave * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r];
+        }
+        if (kt == 0) {
+            // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]   (4 workgroups cover the 500 rows)
+            if (tid < 128 && nbase + tid < H2N) {
+                float s = 0.0f;
+                for (int m = 0; m < BP; ++m) s += Bt[m * 129 + tid];
+                A.grad[off_b2(IN) + nbase + tid] = s;
+            }
+            for (int nl = wave; nl < 128; nl += 4) {
+                const int nn = nbase + nl;
+                if (nn >= H2N) break;
+                const float h0 = A.H2[nn * BP + lane], h1 = A.H2[nn * BP + 64 + lane];
+                for (int o = 0; o < A.out; ++o) {
+                    const float s = wave_sum(h0 * d3[o * BP + lane] + h1 * d3[o * BP + 64 + lane]);
+                    if (lane == 0) A.grad[off_w3(IN) + nn * A.out + o] = s;
+                }
+            }
+        }
+    } else {
+        const int nb = nq * NQW;                // 125 n, padded with one zero row to 63 MFMA pairs
+        for (int e = tid; e < 126 * BP; e += 256) {
+            const int nl = e >> 7, m = e & 127, n = nb + nl;
+            float v = 0.0f;
+            if (nl < NQW) {
+                const float g = A.out == 2 ? fmaf(W3[2 * n + 1], d3[BP + m], W3[2 * n] * d3[m]) : W3[n] * d3[m];
+                v = A.H2[n * BP + m] > 0.0f ? g : 0.0f;
+            }
+            Bt[e] = v;
+        }
+        const float *__restrict__ W2 = P + off_w2(IN);
+        for (int e = tid; e < 32 * 126; e += 256) {
+            const int kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
+            At[kl * 127 + nl] = (k < H1N && nl < NQW) ? W2[(int64_t)k * H2N + nb + nl] : 0.0f;
+        }
+        __syncthreads();
+        const float *pa = At + li * 127, *pb = Bt + wave * 32 + li;
+#pragma unroll 9
+        for (int s = 0; s < 63; ++s) {
+            const int nn = 2 * s + lh;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[nn], pb[nn * BP], acc, 0, 0, 0);
+        }
+        const int m = wave * 32 + li;
+        float *D1 = A.D1P + (int64_t)nq * H1N * BP;
+        float da0 = 0.0f, da1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (k < H1N) {
+                D1[k * BP + m] = acc[r];
+                if (A.DAP && IN == CIN) {
+                    const float v = h1_at<IN>(w1, xs, k, m) > 0.0f ? acc[r] : 0.0f;
+                    da0 = fmaf(w1[9 * H1N + k], v, da0);       // W1[9 + o][k]: the action rows of the critic's first layer
+                    da1 = fmaf(w1[10 * H1N + k], v, da1);
+                }
+            }
+        }
+        if (A.DAP && IN == CIN) {
+            da0 += __shfl_xor(da0, 32, 64);
+            da1 += __shfl_xor(da1, 32, 64);
+            if (lh == 0) {
+                float *o = A.DAP + (int64_t)((kt * NQ + nq) * 2) * BP;
+                o[m] = da0; o[BP + m] = da1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd(BwdArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (A.in == SIN) bwd_body<SIN>(A, smem); else bwd_body<CIN>(A, smem);
+}
+
+// ---- kernel E: layer-1 gradients, one wave per hidden unit k --------------------------------------------------
+//   D1[k][m] = (h1[k][m] > 0) * sum_q D1part[q][k][m];  gb1[k] = sum_m D1;  gW1[j][k] = sum_m x[j][m] D1[k][m]
+template <int IN>
+__device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
+                                           float *__restrict__ grad, float *xs)
+{
+    build_x<IN>(x, xs, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= H1N) return;
+    float w[IN];
+#pragma unroll
+    for (int j = 0; j < IN; ++j) w[j] = P[j * H1N + k];
+    const float b = P[off_b1(IN) + k];
+    float dv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = lane + 64 * h;
+        float pre = b;
+#pragma unroll
+        for (int j = 0; j < IN; ++j) pre = fmaf(w[j], xs[j * BP + m], pre);
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s += D1P[((int64_t)q * H1N + k) * BP + m];
+        dv[h] = pre > 0.0f ? s : 0.0f;
+    }
+    const float sb = wave_sum(dv[0] + dv[1]);
+    if (lane == 0) grad[off_b1(IN) + k] = sb;
+#pragma unroll
+    for (int j = 0; j < IN; ++j) {
+        const float s = wave_sum(xs[j * BP + lane] * dv[0] + xs[j * BP + 64 + lane] * dv[1]);
+        if (lane == 0) grad[j * H1N + k] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad)
 {
     __shared__ float xs[CIN * BP];
-    for (int e = threadIdx.x; e < SIN * BP; e += blockDim.x) xs[e] = X[e];
-    if (XA) for (int e = threadIdx.x; e < AIN * BP; e += blockDim.x) xs[SIN * BP + e] = XA[e];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // one wave per k (coalesced D1 rows), 16 waves
-    for (int k = wave; k < H1N; k += 16) {
-        const float v0 = D1[k * BP + lane], v1 = D1[k * BP + 64 + lane];
-        const float sb = wave_sum(v0 + v1);
-        if (lane == 0) grad[off_b1(in) + k] = sb;
-        for (int j = 0; j < in; ++j) {
-            const float s = wave_sum(xs[j * BP + lane] * v0 + xs[j * BP + 64 + lane] * v1);
-            if (lane == 0) grad[j * H1N + k] = s;
-        }
+    if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad, xs); else l1bwd_body<CIN>(P, x, D1P, grad, xs);
+}
+
+// ---- kernel F: actor head backward (1 workgroup): da -> d3a, actor loss, gb3 ------------------------------------
+__global__ __launch_bounds__(256) void k_head_actor(shems_ddpg d)
+{
+    __shared__ float red[8];
+    float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+    float da = 0.0f;
+#pragma unroll 8
+    for (int p = 0; p < KT * NQ; ++p) da += ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
+    const float a = ws[WS_API + t];
+    const float d3 = da * (1.0f - a * a);                       // through tanh
+    ws[WS_D3A + t] = d3;
+    float q = 0.0f;
+    if (o == 0 && m < d.batch) {
+        const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
+        q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) q += Pq[(tt * 2) * BP + m];
     }
-    for (int n = wave; n < H2N; n += 16) {
-        const float s = wave_sum(D2[n * BP + lane] + D2[n * BP + 64 + lane]);
-        if (lane == 0) grad[off_b2(in) + n] = s;
+    const float sg = wave_sum(d3), sq = wave_sum(q);
+    if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
+    __syncthreads();
+    if (t == 0) {
+        d.grad_actor[off_b3(SIN, 2) + 0] = red[0] + red[1];
+        d.grad_actor[off_b3(SIN, 2) + 1] = red[2] + red[3];
+        d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
     }
 }
 
-// ---- kernel F: Flux 0.12.1 ADAM + soft target update ------------------------------------------------------
+// ---- kernel G: Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------
 //   mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2 ; delta = mt/(1-bp1) / (sqrt(vt/(1-bp2)) + eps) * eta ; p -= delta
 //   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32)
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
@@ -420,19 +484,19 @@ __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const 
                                                    double bp1, double bp2, double gscale, float tau)
 {
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float gf = (float)((double)g[i] * gscale);            // averaged gradient, as the replicas would hold it
-        const float m1 = (float)(b1 * (double)mt[i] + (1.0 - b1) * (double)gf);
-        const float v1 = (float)(b2 * (double)vt[i] + (1.0 - b2) * ((double)gf * (double)gf));
-        const float delta = (float)((double)m1 / (1.0 - bp1) / (sqrt((double)v1 / (1.0 - bp2)) + eps) * eta);
-        const float pn = p[i] - delta;
-        mt[i] = m1; vt[i] = v1; p[i] = pn;
-        const float one_m_tau = 1.0f - tau;
-        target[i] = one_m_tau * target[i] + tau * pn;
-    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gf = (float)((double)g[i] * gscale);            // averaged gradient, as every replica holds it
+    const float m1 = (float)(b1 * (double)mt[i] + (1.0 - b1) * (double)gf);
+    const float v1 = (float)(b2 * (double)vt[i] + (1.0 - b2) * ((double)gf * (double)gf));
+    const float delta = (float)((double)m1 / (1.0 - bp1) / (sqrt((double)v1 / (1.0 - bp2)) + eps) * eta);
+    const float pn = p[i] - delta;
+    mt[i] = m1; vt[i] = v1; p[i] = pn;
+    const float one_m_tau = 1.0f - tau;
+    target[i] = one_m_tau * target[i] + tau * pn;
 }
 
-// ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------
+// ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_minmax(shems_replay ring, int64_t ring_len, int64_t count, uint64_t seed,
                                                  float *s_min, float *s_max)
 {
@@ -470,6 +534,16 @@ __global__ __launch_bounds__(1024) void k_minmax(shems_replay ring, int64_t ring
     }
 }
 
+static int set_lds_attrs()
+{
+    static bool done = false;
+    if (done) return SHEMS_OK;
+    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS), "attr k_fwd")) return rc;
+    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS), "attr k_bwd")) return rc;
+    done = true;
+    return SHEMS_OK;
+}
+
 }  // namespace shems
 
 using namespace shems;
@@ -480,7 +554,9 @@ static int check_ddpg(const shems_ddpg *d, const char *fn)
         !d->v_critic || !d->grad_actor || !d->grad_critic || !d->s_min || !d->s_max || !d->ws || !d->losses)
         return set_error(SHEMS_ERR_ARG, "%s: shems_ddpg has a NULL buffer", fn);
     if (d->batch < 1 || d->batch > BP) return set_error(SHEMS_ERR_ARG, "%s: batch must be in 1..128 (got %d)", fn, d->batch);
-    return SHEMS_OK;
+    for (const float *p : {d->actor, d->critic, d->actor_t, d->critic_t})
+        if (((uintptr_t)p & 15) != 0) return set_error(SHEMS_ERR_ARG, "%s: parameter blocks must be 16-byte aligned", fn);
+    return set_lds_attrs();
 }
 
 extern "C" {
@@ -511,23 +587,25 @@ int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad: bad replay ring / length");
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_prep, dim3(10), dim3(256), 0, st, *d, *ring, ring_len, seed, tick);
-    L2FwdArgs f;
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(128), 0, st, *d, *ring, ring_len, seed, tick);
+    const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
+    const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
+    const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
+    const XSrc x_sa{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr};
+    FwdArgs f;
     std::memset(&f, 0, sizeof f);
-    f.batch = d->batch;
-    f.job[0] = L2FwdJob{d->actor_t, SIN, slot(ws, SLOT_ACTOR_T) + SL_H1, slot(ws, SLOT_ACTOR_T) + SL_H2, nullptr, nullptr, 0.f};
-    hipLaunchKernelGGL(k_l2fwd, dim3(16, 1), dim3(256), 0, st, f);
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, st, *d, (int)HEAD_TARGET_ACTOR);
-    f.job[0] = L2FwdJob{d->critic_t, CIN, slot(ws, SLOT_CRITIC_T) + SL_H1, slot(ws, SLOT_CRITIC_T) + SL_H2, nullptr, nullptr, 0.f};
-    f.job[1] = L2FwdJob{d->critic, CIN, slot(ws, SLOT_CRITIC) + SL_H1, slot(ws, SLOT_CRITIC) + SL_H2, nullptr, nullptr, 0.f};
-    f.job[2] = L2FwdJob{d->actor, SIN, slot(ws, SLOT_ACTOR) + SL_H1, slot(ws, SLOT_ACTOR) + SL_H2, nullptr, nullptr, 0.f};
-    hipLaunchKernelGGL(k_l2fwd, dim3(16, 3), dim3(256), 0, st, f);
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, st, *d, (int)HEAD_CRITIC_LOSS);
+    f.job[0] = FwdJob{d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
+    hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
+    f.job[0] = FwdJob{d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
+    f.job[1] = FwdJob{d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
+    f.job[2] = FwdJob{d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
+    hipLaunchKernelGGL(k_fwd, dim3(NT, 3), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_head_loss, dim3(1), dim3(128), 0, st, *d);
     float *S = slot(ws, SLOT_CRITIC);
-    L2BwdArgs b{S + SL_H1T, S + SL_D2T, d->grad_critic + off_w2(CIN), d->critic + off_w2(CIN), S + SL_D2, S + SL_H1, S + SL_D1, 128};
-    hipLaunchKernelGGL(k_l2bwd, dim3(40), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3(1), dim3(1024), 0, st, (const float *)(ws + WS_XT), (const float *)(ws + WS_AT), (int)CIN,
-                       (const float *)(S + SL_D1), (const float *)(S + SL_D2), d->grad_critic);
+    const BwdArgs b{d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ), dim3(256), BWD_LDS, st, b);
+    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
+                       (const float *)(S + SL_D1P), d->grad_critic);
     return hip_ok(hipGetLastError(), "ddpg critic_grad launches");
 }
 
@@ -535,7 +613,7 @@ static int adam_launch(float *p, const float *g, float *m, float *v, float *targ
                        double gscale, float tau, hipStream_t st)
 {
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    hipLaunchKernelGGL(k_adam_soft, dim3(128), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau);
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -551,21 +629,23 @@ int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
     if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, st, *d, (int)HEAD_ACTOR);
+    // critic (already updated, DDPG.jl:137-140) on [s; a_pi], a_pi = tanh(b3 + partials of the actor pass)
+    const XSrc x_spi{ws + WS_XT, nullptr, slot(ws, SLOT_ACTOR) + SL_P3, d->actor + off_b3(SIN, 2), ws + WS_API};
+    const XSrc x_spi_ro{ws + WS_XT, ws + WS_API, nullptr, nullptr, nullptr};
+    const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
     float *C2 = slot(ws, SLOT_CRITIC2);
-    L2FwdArgs f;
+    FwdArgs f;
     std::memset(&f, 0, sizeof f);
-    f.batch = d->batch;
-    f.job[0] = L2FwdJob{d->critic, CIN, C2 + SL_H1, C2 + SL_H2, C2 + SL_D2, C2 + SL_D2T, -1.0f / (float)d->batch};
-    hipLaunchKernelGGL(k_l2fwd, dim3(16, 1), dim3(256), 0, st, f);
-    L2BwdArgs bi{nullptr, nullptr, nullptr, d->critic + off_w2(CIN), C2 + SL_D2, C2 + SL_H1, C2 + SL_D1, 0};
-    hipLaunchKernelGGL(k_l2bwd, dim3(8), dim3(256), 0, st, bi);
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, st, *d, (int)HEAD_ACTOR_BWD);
+    f.job[0] = FwdJob{d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
+    hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
+    const BwdArgs bi{d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0};
+    hipLaunchKernelGGL(k_bwd, dim3(KT * NQ), dim3(256), BWD_LDS, st, bi);
+    hipLaunchKernelGGL(k_head_actor, dim3(1), dim3(256), 0, st, *d);
     float *S = slot(ws, SLOT_ACTOR);
-    L2BwdArgs b{S + SL_H1T, S + SL_D2T, d->grad_actor + off_w2(SIN), d->actor + off_w2(SIN), S + SL_D2, S + SL_H1, S + SL_D1, 128};
-    hipLaunchKernelGGL(k_l2bwd, dim3(40), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3(1), dim3(1024), 0, st, (const float *)(ws + WS_XT), (const float *)nullptr, (int)SIN,
-                       (const float *)(S + SL_D1), (const float *)(S + SL_D2), d->grad_actor);
+    const BwdArgs b{d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ), dim3(256), BWD_LDS, st, b);
+    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
+                       (const float *)(S + SL_D1P), d->grad_actor);
     return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
 }
 
