@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libshems_hip.so")
+LIB_PATH = os.environ.get("SHEMS_HIP_LIB") or os.path.join(HERE, "libshems_hip.so")   # override: A/B builds of the library
 
 OK, ERR_ARG, ERR_HIP, ERR_INDEX, ERR_NOMEM, ERR_NODEVICE, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 NSTATE, NACTION, NCOL, NRESULT = 9, 2, 8, 23

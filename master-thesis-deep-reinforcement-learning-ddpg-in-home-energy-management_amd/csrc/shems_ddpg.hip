@@ -15,10 +15,10 @@
 //     layer-2 error D2 = (W3 d3) .* (h2 > 0) are recomputed inside the kernels that consume them;
 //   * cross-workgroup reductions go through partial slabs summed in a fixed order (bitwise
 //     reproducible; no float atomics).
-// 13 launches per update:
-//   prep -> fwd(actor_t) -> fwd(critic_t | critic | actor) -> head(loss) -> bwd(critic) -> l1bwd(critic)
+// 11 launches per update (the loss / actor heads run in the prologue of the bwd workgroups):
+//   prep -> fwd(actor_t) -> fwd(critic_t | critic | actor) -> bwd(critic) -> l1bwd(critic)
 //   [all-reduce] adam+soft(critic)
-//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> head(actor) -> bwd(actor) -> l1bwd(actor)
+//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> bwd(actor) -> l1bwd(actor)
 //   [all-reduce] adam+soft(actor)
 #include <hip/hip_runtime.h>
 
@@ -59,12 +59,14 @@ constexpr int64_t WS_D3Q = WS_D3C + BP;               // [1][BP]  -1/B (actor lo
 constexpr int64_t WS_D3A = WS_D3Q + BP;               // [2][BP]  error at the actor's pre-tanh output
 constexpr int64_t WS_IDX = WS_D3A + AIN * BP;         // [BP]     sampled ring slots (int32)
 constexpr int64_t WS_DAP = WS_IDX + BP;               // [KT][NQ][2][BP]  partial d loss / d a_pi
-constexpr int64_t WS_SLOT0 = WS_DAP + KT * NQ * AIN * BP;
+constexpr int64_t WS_W1T = WS_DAP + KT * NQ * AIN * BP;   // [4 nets][12][256] packed layer-1 images (see w1m below)
+constexpr int64_t WS_SLOT0 = WS_W1T + 4 * 12 * 256;
 constexpr int64_t SL_H2 = 0;                          // [500][BP]          relu(W2' h1 + b2)
 constexpr int64_t SL_P3 = SL_H2 + H2N * BP;           // [NT][2][BP]        per-n-tile partial sums of layer 3
 constexpr int64_t SL_D1P = SL_P3 + NT * 2 * BP;       // [NQ][250][BP]      partial (unmasked) error at layer 1
 constexpr int64_t SL_SIZE = SL_D1P + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
+__host__ __device__ inline float *w1t_of(float *ws, int net) { return ws + WS_W1T + (int64_t)net * 12 * 256; }   // net = SLOT_* < 4
 constexpr int64_t WS_FLOATS = WS_SLOT0 + N_SLOTS * SL_SIZE;
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
@@ -89,7 +91,18 @@ struct XSrc {
 template <int IN>
 __device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
 {
-    for (int e = threadIdx.x; e < SIN * BP; e += blockDim.x) xs[e] = s.X[e];
+    {   // 1152 floats, all loads in flight at once (blockDim = 256)
+        float v[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; v[it] = s.X[min(e, SIN * BP - 1)]; }   // clamped, never predicated:
+        // a guarded load becomes a branch + its own s_waitcnt, which serialises the batch
+#pragma unroll
+        for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; if (e < SIN * BP) xs[e] = v[it]; }
+    }
+    if (threadIdx.x < BP) xs[11 * BP + threadIdx.x] = 1.0f;                     // bias row
+    if (IN == SIN) {
+        xs[9 * BP + threadIdx.x] = 0.0f;                                          // rows 9, 10 (2 * BP == blockDim)
+    }
     if (IN == CIN) {
         for (int e = threadIdx.x; e < AIN * BP; e += blockDim.x) {
             float a;
@@ -108,21 +121,58 @@ __device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*
     }
 }
 
-// h1[k][m] = relu(b1[k] + sum_j W1[j][k] x[j][m]) with W1/b1 in LDS (w1: [IN][250] then b1[250]).
-template <int IN>
-__device__ __forceinline__ float h1_at(const float *w1, const float *xs, int k, int m)
+// Layer 1 also runs on the matrix pipe: pre[k][m] = sum_j w1m[j][k] * xs[j][m] with K = 12 = 6 MFMA k-steps, where
+//   w1m [12][256] = rows 0..in-1: W1[j][k]; row 11: b1[k]; everything else (rows in..10, columns 250..255) zero
+//   xs  [12][BP]  = rows 0..in-1: the network input; row 11: 1.0 (bias); rows in..10 zero.
+// The packed image w1m lives in the workspace (k_prep builds it for all four networks at the start of every update, the
+// critic's ADAM launch refreshes the critic's); staging it is a straight 12 KB float4 copy, three loads per thread.
+constexpr int W1K = 12, W1C = 256;
+__device__ __forceinline__ void stage_w1m(const float *__restrict__ g, float *l)
 {
-    float acc = w1[IN * H1N + k];
+    float4 v[3];
 #pragma unroll
-    for (int j = 0; j < IN; ++j) acc = fmaf(w1[j * H1N + k], xs[j * BP + m], acc);
-    return fmaxf(acc, 0.0f);
+    for (int it = 0; it < 3; ++it) v[it] = reinterpret_cast<const float4 *>(g)[it * 256 + threadIdx.x];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) reinterpret_cast<float4 *>(l)[it * 256 + threadIdx.x] = v[it];
+}
+__device__ __forceinline__ void pack_w1m(const float *__restrict__ P, int in, float *__restrict__ g)
+{
+    float v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {                       // thread = column k (blockDim 256), unconditional clamped loads
+        const int k = min((int)threadIdx.x, H1N - 1);
+        v[j] = P[(j == W1K - 1 ? in : min(j, in - 1)) * H1N + k];          // row `in` of the block is b1
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+        g[j * W1C + threadIdx.x] = ((j < in || j == W1K - 1) && (int)threadIdx.x < H1N) ? v[j] : 0.0f;
+}
+// One 32(k) x 32(m) tile of layer-1 pre-activations, D layout (row k = (r&3)+8(r>>2)+4*lh, column m = lane&31).
+__device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int kbase, int mbase, int li, int lh)
+{
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < W1K / 2; ++s) {
+        const int j = 2 * s + lh;
+        t = __builtin_amdgcn_mfma_f32_32x32x2f32(w1m[j * W1C + kbase + li], xs[j * BP + mbase + li], t, 0, 0, 0);
+    }
+    return t;
 }
 
 // ---- kernel A: sample + gather + normalize -----------------------------------------------------------
-__global__ __launch_bounds__(128) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick)
+__global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick)
 {
-    const int m = threadIdx.x;
     float *ws = d.ws;
+    if (blockIdx.x > 0) {          // workgroups 1..4: packed layer-1 images of actor_t, critic_t, critic, actor
+        const int net = blockIdx.x - 1;
+        const float *P = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
+        pack_w1m(P, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(ws, net));
+        return;
+    }
+    const int m = threadIdx.x;
+    if (m >= BP) return;
     float s[SIN], s2[SIN], a0 = 0.f, a1 = 0.f, r = 0.f, dn = 0.f;
     int64_t j = -1;
     const bool live = m < d.batch;
@@ -151,6 +201,7 @@ __global__ __launch_bounds__(128) void k_prep(shems_ddpg d, shems_replay ring, i
 
 // ---- kernel B: layers 1+2 forward for one 32-wide n-tile and all 128 columns --------------------------
 struct FwdJob {
+    const float *w1t;      // packed layer-1 image [250][12] of this network
     const float *P;        // parameter block
     int in;                // 9 (actor nets) or 11 (critic nets)
     int out;               // 2 or 1
@@ -161,63 +212,106 @@ struct FwdJob {
 struct FwdArgs { FwdJob job[3]; };
 
 constexpr int FWD_KC = 126;                                   // k rows per phase (63 MFMA pairs), 2 phases
-constexpr int FWD_LDS = (FWD_KC * BP + FWD_KC * 32 + CIN * BP + CIN * H1N + H1N) * 4;
+constexpr int FWD_LDS = (128 * BP + 128 * 32 + W1K * BP + W1K * W1C + 96) * 4;
 
+#ifdef ABL_STAMP
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { stamps[2*(i)] = __builtin_amdgcn_s_memtime(); stamps[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define STAMP(i)
+#endif
 template <int IN>
 __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
 {
-    float *Hc = smem;                          // [126][BP]
-    float *Wc = Hc + FWD_KC * BP;              // [126][32]
-    float *xs = Wc + FWD_KC * 32;              // [IN][BP]
-    float *w1 = xs + CIN * BP;                 // W1 [IN][250], b1 [250]
+#ifdef ABL_STAMP
+    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(const_cast<float *>(J.P3) + 100000);   // unused part of the slot
+#endif
+    STAMP(0);
+    float *Hc = smem;                          // [128][BP]  relu(layer 1) rows of the current phase
+    float *Wc = Hc + 128 * BP;                 // [128][32]  W2 panel of the current phase
+    float *xs = Wc + 128 * 32;                 // [12][BP]
+    float *w1 = xs + W1K * BP;                 // w1m [12][256]
+    float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * 32;
     const float *__restrict__ P = J.P;
 
+    float epv = 0.0f;
+    if (tid < 96) {                            // epilogue constants: in flight while the inputs are staged
+        const int nl = tid / 3, c = tid - nl * 3, nc = min(n0 + nl, H2N - 1);
+        epv = c == 0 ? P[off_b2(IN) + nc] : P[off_w3(IN) + nc * J.out + min(c - 1, J.out - 1)];
+        if (n0 + nl >= H2N || c - 1 >= J.out) epv = 0.0f;
+    }
     build_x<IN>(J.x, xs, blockIdx.x == 0);
-    for (int e = tid; e < (IN * H1N + H1N) / 2; e += 256)
-        reinterpret_cast<float2 *>(w1)[e] = reinterpret_cast<const float2 *>(P)[e];
+    stage_w1m(J.w1t, w1);
+    if (tid < 96) ep[tid] = epv;
     __syncthreads();
+    STAMP(1);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const float *__restrict__ W2 = P + off_w2(IN);
+    const int mbase = wave * 32;
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         const int k0 = ph * FWD_KC, kn = ph == 0 ? FWD_KC : H1N - FWD_KC;      // 126 + 124 rows
-        // stage W2[k0..][n0..n0+31] (rows of 128 B) -- 8 float4 per row; columns >= 500 of the last tile read the
-        // next row / b2 (in bounds) and only feed output rows that are discarded
-        for (int e = tid; e < kn * 8; e += 256) {
-            const int kl = e >> 3, c = e & 7;
-            reinterpret_cast<float4 *>(Wc)[e] = *reinterpret_cast<const float4 *>(W2 + (int64_t)(k0 + kl) * H2N + n0 + 4 * c);
+        // W2[k0..][n0..n0+31] (rows of 128 B, 8 float4 each): all loads issued before the first store.  Columns >= 500 of the
+        // last tile read the next row / b2 (in bounds) and only feed output rows that are discarded.
+        float4 wv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 256 + tid, kl = e >> 3, c = e & 7;
+            const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)(k0 + min(kl, kn - 1)) * H2N + n0 + 4 * c);
+            wv[it] = kl < kn ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int e = tid; e < kn * BP; e += 256) {
-            const int kl = e >> 7, m = e & 127;
-            Hc[e] = h1_at<IN>(w1, xs, k0 + kl, m);
+        STAMP(2 + 5 * ph);
+        // layer 1 on the matrix pipe: this wave's 32 columns x 128 rows (rows past 249 come out as relu(0) = 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x16 t = l1_tile(w1, xs, k0 + 32 * q, mbase, li, lh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Hc[(32 * q + (r & 3) + 8 * (r >> 2) + 4 * lh) * BP + mbase + li] = fmaxf(t[r], 0.0f);
         }
+        STAMP(3 + 5 * ph);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) reinterpret_cast<float4 *>(Wc)[it * 256 + tid] = wv[it];
         __syncthreads();
-        const float *pa = Wc + li, *pb = Hc + wave * 32 + li;
-#pragma unroll 9
-        for (int s = 0; s < kn / 2; ++s) {
-            const int kk = 2 * s + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * 32], pb[kk * BP], acc, 0, 0, 0);
+        STAMP(4 + 5 * ph);
+        // 63 MFMA pairs, operand fetch software-pipelined one group (9 pairs) ahead.  In the second phase the last pair
+        // multiplies the zero rows 124/125 of Wc.
+        const float *pa = Wc + li, *pb = Hc + mbase + li;
+        float ac[9], bc[9], an[9], bn[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) { ac[u] = pa[(2 * u + lh) * 32]; bc[u] = pb[(2 * u + lh) * BP]; }
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            if (g < 6) {
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int kk = 2 * ((g + 1) * 9 + u) + lh;
+                    an[u] = pa[kk * 32]; bn[u] = pb[kk * BP];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
         }
+        STAMP(5 + 5 * ph);
         __syncthreads();
+        STAMP(6 + 5 * ph);
     }
     // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
-    const float *b2 = P + off_b2(IN), *W3 = P + off_w3(IN);
-    const int m = wave * 32 + li;
+    const int m = mbase + li;
     float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < H2N) {
-            const float h = fmaxf(acc[r] + b2[n], 0.0f);
-            if (J.H2) J.H2[n * BP + m] = h;
-            if (J.out == 2) { p0 = fmaf(h, W3[2 * n], p0); p1 = fmaf(h, W3[2 * n + 1], p1); }
-            else p0 = fmaf(h, W3[n], p0);
-        }
+        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nl;
+        const float h = n < H2N ? fmaxf(acc[r] + ep[nl * 3], 0.0f) : 0.0f;
+        if (J.H2 && n < H2N) J.H2[n * BP + m] = h;
+        p0 = fmaf(h, ep[nl * 3 + 1], p0);
+        p1 = fmaf(h, ep[nl * 3 + 2], p1);
     }
     p0 += __shfl_xor(p0, 32, 64);
     p1 += __shfl_xor(p1, 32, 64);
@@ -225,36 +319,80 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
         J.P3[(blockIdx.x * 2 + 0) * BP + m] = p0;
         J.P3[(blockIdx.x * 2 + 1) * BP + m] = p1;
     }
+    STAMP(12);
 }
 
-__global__ __launch_bounds__(256) void k_fwd(FwdArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const FwdJob &J = A.job[blockIdx.y];
     if (J.in == SIN) fwd_body<SIN>(J, smem); else fwd_body<CIN>(J, smem);
 }
 
-// ---- kernel C: critic loss head (1 workgroup) ------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_head_loss(shems_ddpg d)
+// ---- critic loss head, evaluated in the prologue of every bwd(critic) workgroup (cheaper than a launch boundary) --------
+// d3[0][m] = dq[m] = 2 (q - y) / B into LDS; workgroup 0 also publishes y, q, the loss and gb3.
+__device__ __forceinline__ void head_loss(const shems_ddpg &d, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
 {
-    __shared__ float red[4];
     float *ws = d.ws;
-    const int m = threadIdx.x;
-    const float *Pt = slot(ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(ws, SLOT_CRITIC) + SL_P3;
-    float q2 = d.critic_t[off_b3(CIN, 1)], q = d.critic[off_b3(CIN, 1)];
+    const int t = threadIdx.x, m = t & 127;
+    float dq = 0.0f, diff = 0.0f;
+    if (t < BP) {
+        const float *Pt = slot(ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(ws, SLOT_CRITIC) + SL_P3;
+        float pt[NT], pc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { q2 += Pt[(t * 2) * BP + m]; q += Pc[(t * 2) * BP + m]; }
-    const float y = ws[WS_R + m] + d.gamma * (1.0f - ws[WS_DONE + m]) * q2;            // DDPG.jl:133
-    const bool live = m < d.batch;
-    const float diff = live ? q - y : 0.0f;
-    const float dq = 2.0f * diff / (float)d.batch;                                       // d mse / d q
-    ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq;
-    const float s1 = wave_sum(diff * diff), s2 = wave_sum(dq);
-    if ((m & 63) == 0) { red[m >> 6] = s1; red[2 + (m >> 6)] = s2; }
-    __syncthreads();
-    if (m == 0) {
-        d.losses[0] = (red[0] + red[1]) / (float)d.batch;                                // Flux.mse
-        d.grad_critic[off_b3(CIN, 1)] = red[2] + red[3];
+        for (int i = 0; i < NT; ++i) { pt[i] = Pt[(i * 2) * BP + m]; pc[i] = Pc[(i * 2) * BP + m]; }
+        float q2 = d.critic_t[off_b3(CIN, 1)], q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { q2 += pt[i]; q += pc[i]; }
+        const float y = ws[WS_R + m] + d.gamma * (1.0f - ws[WS_DONE + m]) * q2;            // DDPG.jl:133
+        diff = m < d.batch ? q - y : 0.0f;
+        dq = 2.0f * diff / (float)d.batch;                                                  // d mse / d q
+        if (publisher) { ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq; }
+    }
+    d3[t] = t < BP ? dq : 0.0f;
+    if (publisher) {
+        const float s1 = wave_sum(diff * diff), s2 = wave_sum(dq);
+        if ((t & 63) == 0) { red[t >> 6] = s1; red[4 + (t >> 6)] = s2; }
+        __syncthreads();
+        if (t == 0) {
+            d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
+            d.grad_critic[off_b3(CIN, 1)] = red[4] + red[5];
+        }
+    }
+}
+
+// ---- actor head backward, evaluated in the prologue of every bwd(actor) workgroup ------------------------------------
+// d3[o][m] = (sum of the 32 partial d loss / d a_pi) * (1 - a_pi^2); workgroup 0 publishes d3, the actor loss and gb3.
+__device__ __forceinline__ void head_actor(const shems_ddpg &d, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
+{
+    float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+    float pv[KT * NQ];
+#pragma unroll
+    for (int p = 0; p < KT * NQ; ++p) pv[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
+    const float a = ws[WS_API + t];
+    float da = 0.0f;
+#pragma unroll
+    for (int p = 0; p < KT * NQ; ++p) da += pv[p];
+    const float g = da * (1.0f - a * a);                       // through tanh
+    d3[t] = g;
+    if (publisher) {
+        ws[WS_D3A + t] = g;
+        float q = 0.0f;
+        if (o == 0 && m < d.batch) {
+            const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
+            q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) q += Pq[(i * 2) * BP + m];
+        }
+        const float sg = wave_sum(g), sq = wave_sum(q);
+        if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
+        __syncthreads();
+        if (t == 0) {
+            d.grad_actor[off_b3(SIN, 2) + 0] = red[0] + red[1];
+            d.grad_actor[off_b3(SIN, 2) + 1] = red[2] + red[3];
+            d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
+        }
     }
 }
 
@@ -264,6 +402,7 @@ __global__ __launch_bounds__(128) void k_head_loss(shems_ddpg d)
 //   I workgroups (kt, nq): D1part[nq][32 k][128 m] = sum_{n in quarter} W2[k][n] D2[n][m]; for the critic inside the
 //                          actor loss they also emit the partial action gradient (through the layer-1 relu mask).
 struct BwdArgs {
+    const float *w1t;      // packed layer-1 image of that network
     const float *P;        // parameter block of the network being differentiated
     int in, out;
     XSrc x;                // its input (for the layer-1 recompute)
@@ -272,31 +411,60 @@ struct BwdArgs {
     float *grad;           // gradient block (W part) or null
     float *D1P;            // [NQ][250][BP]
     float *DAP;            // [KT][NQ][2][BP] or null
-    int n_w;               // number of W workgroups (32 or 0)
+    int n_w;               // number of W workgroups (32 or 0); when > 0, 8 more "G" workgroups emit gb2 and gW3
+    int head;              // how d3 is obtained: 0 = read A.d3, 1 = critic loss head, 2 = actor head
+    shems_ddpg dd;         // for the heads
 };
+enum { BWD_NG = 8 };
 
-constexpr int BWD_LDS = (BP * 129 + 32 * 128 + CIN * BP + CIN * H1N + H1N + AIN * BP) * 4;
+constexpr int BWD_LDS = (BP * 129 + 33 * 128 + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8) * 4;
+
+// D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
+__device__ __forceinline__ float d2_val(float h2, int out, float w3a, float w3b, float d3a, float d3b)
+{
+    const float g = out == 2 ? fmaf(w3b, d3b, w3a * d3a) : w3a * d3a;
+    return h2 > 0.0f ? g : 0.0f;
+}
 
 template <int IN>
 __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 {
     float *Bt = smem;                          // W: [128 m][129] D2^T panel;  I: [126 n][128 m] D2 panel
-    float *At = Bt + BP * 129;                 // W: [128 m][32 k] h1^T panel; I: [32 k][127] W2 panel
-    float *xs = At + 32 * 128;                 // [IN][BP]
-    float *w1 = xs + CIN * BP;                 // W1, b1
-    float *d3 = w1 + (CIN * H1N + H1N);        // [2][BP]
+    float *At = Bt + BP * 129;                 // W: [128 m][33] h1^T panel; I: [32 k][127] W2 panel
+    float *xs = At + 33 * 128;                 // [12][BP]
+    float *w1 = xs + W1K * BP;                 // w1m [12][256]
+    float *d3 = w1 + W1K * W1C;                // [2][BP]
+    float *w3s = d3 + AIN * BP;                // W3 [512][2] (out == 1: [.][0] only), zero beyond row 499
+    float *red = w3s + 2 * 512;                // [8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const float *__restrict__ P = A.P;
     const float *__restrict__ W3 = P + off_w3(IN);
-    const bool is_w = (int)blockIdx.x < A.n_w;
-    const int b = is_w ? blockIdx.x : blockIdx.x - A.n_w;
+    const int n_g = A.n_w > 0 ? (int)BWD_NG : 0;
+    const bool is_w = (int)blockIdx.x < A.n_w, is_g = !is_w && (int)blockIdx.x < A.n_w + n_g;
+    const int b = is_w ? blockIdx.x : blockIdx.x - A.n_w - n_g;
     const int kt = b >> 2, nq = b & 3;
+    const int mcol = tid & 127, half = tid >> 7;
 
     build_x<IN>(A.x, xs, false);
-    for (int e = tid; e < (IN * H1N + H1N) / 2; e += 256)
-        reinterpret_cast<float2 *>(w1)[e] = reinterpret_cast<const float2 *>(P)[e];
-    for (int e = tid; e < A.out * BP; e += 256) d3[e] = A.d3[e];
+    stage_w1m(A.w1t, w1);
+    if (A.head == 1) head_loss(A.dd, d3, red, blockIdx.x == 0);
+    else if (A.head == 2) head_actor(A.dd, d3, red, blockIdx.x == 0);
+    else { const float t = A.d3[min(tid, A.out * BP - 1)]; d3[tid] = tid < A.out * BP ? t : 0.0f; }   // AIN * BP == 256 == blockDim
+    {   // W3 -> LDS as [n][2] (second column 0 for the critic), 4 independent loads per thread
+        float v[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 256 + tid, n = e >> 1, o = e & 1;
+            v[it] = W3[min(n, H2N - 1) * A.out + min(o, A.out - 1)];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 256 + tid, n = e >> 1, o = e & 1;
+            w3s[e] = (n < H2N && o < A.out) ? v[it] : 0.0f;
+        }
+    }
     __syncthreads();
+    const float d3a = d3[mcol], d3b = d3[BP + mcol];
 
     f32x16 acc;
 #pragma unroll
@@ -304,27 +472,31 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 
     if (is_w) {
         const int nbase = nq * 128;
-        // D2^T panel: Bt[m][nl] for the 128 n of this workgroup (n >= 500 -> 0)
-        for (int e = tid; e < 128 * BP; e += 256) {
-            const int nl = e >> 7, m = e & 127, n = nbase + nl;
-            float v = 0.0f;
-            if (n < H2N) {
-                const float g = A.out == 2 ? fmaf(W3[2 * n + 1], d3[BP + m], W3[2 * n] * d3[m]) : W3[n] * d3[m];
-                v = A.H2[n * BP + m] > 0.0f ? g : 0.0f;
+        // D2^T panel Bt[m][nl], nl = 2*it + half: 64 rows per thread, H2 loads issued 32 at a time (W3 comes from LDS)
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            float hv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) hv[u] = A.H2[min(nbase + 2 * (blk * 32 + u) + half, H2N - 1) * BP + mcol];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int nl = 2 * (blk * 32 + u) + half, n = nbase + nl;       // rows >= 500: W3 image is zero there
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
+                Bt[mcol * 129 + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
             }
-            Bt[m * 129 + nl] = v;
         }
-        // h1^T panel: At[m][kl] for the 32 k of this workgroup (k >= 250 -> 0)
-        for (int e = tid; e < 32 * BP; e += 256) {
-            const int kl = e >> 7, m = e & 127, k = kt * 32 + kl;
-            At[m * 32 + kl] = k < H1N ? h1_at<IN>(w1, xs, k, m) : 0.0f;
+        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe
+        {
+            const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
         }
         __syncthreads();
         const float *pa = At + li, *pb = Bt + wave * 32 + li;
 #pragma unroll 8
         for (int s = 0; s < BP / 2; ++s) {
             const int mm = 2 * s + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[mm * 32], pb[mm * 129], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[mm * 33], pb[mm * 129], acc, 0, 0, 0);
         }
         float *gW2 = A.grad + off_w2(IN);
         const int n = nbase + wave * 32 + li;
@@ -333,38 +505,63 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r];
         }
-        if (kt == 0) {
-            // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]   (4 workgroups cover the 500 rows)
-            if (tid < 128 && nbase + tid < H2N) {
-                float s = 0.0f;
-                for (int m = 0; m < BP; ++m) s += Bt[m * 129 + tid];
-                A.grad[off_b2(IN) + nbase + tid] = s;
+    } else if (is_g) {
+        // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: 8 workgroups x 64 rows, one wave per row, 8 rows in flight
+        const int g = blockIdx.x - A.n_w;
+        const float e0a = d3[lane], e0b = d3[64 + lane], e1a = d3[BP + lane], e1b = d3[BP + 64 + lane];
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            float h0[8], h1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int nc = min(g * 64 + wave + 4 * (blk * 8 + u), H2N - 1);
+                h0[u] = A.H2[nc * BP + lane];
+                h1[u] = A.H2[nc * BP + 64 + lane];
             }
-            for (int nl = wave; nl < 128; nl += 4) {
-                const int nn = nbase + nl;
-                if (nn >= H2N) break;
-                const float h0 = A.H2[nn * BP + lane], h1 = A.H2[nn * BP + 64 + lane];
-                for (int o = 0; o < A.out; ++o) {
-                    const float s = wave_sum(h0 * d3[o * BP + lane] + h1 * d3[o * BP + 64 + lane]);
-                    if (lane == 0) A.grad[off_w3(IN) + nn * A.out + o] = s;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int nn = g * 64 + wave + 4 * (blk * 8 + u);
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * min(nn, H2N - 1));
+                const float s0 = wave_sum(h0[u] * e0a + h1[u] * e0b);
+                const float s1 = wave_sum(h0[u] * e1a + h1[u] * e1b);
+                const float sb = wave_sum(d2_val(h0[u], 2, w.x, w.y, e0a, e1a) + d2_val(h1[u], 2, w.x, w.y, e0b, e1b));
+                if (lane == 0 && nn < H2N) {
+                    A.grad[off_w3(IN) + nn * A.out] = s0;
+                    if (A.out == 2) A.grad[off_w3(IN) + nn * 2 + 1] = s1;
+                    A.grad[off_b2(IN) + nn] = sb;
                 }
             }
         }
     } else {
         const int nb = nq * NQW;                // 125 n, padded with one zero row to 63 MFMA pairs
-        for (int e = tid; e < 126 * BP; e += 256) {
-            const int nl = e >> 7, m = e & 127, n = nb + nl;
-            float v = 0.0f;
-            if (nl < NQW) {
-                const float g = A.out == 2 ? fmaf(W3[2 * n + 1], d3[BP + m], W3[2 * n] * d3[m]) : W3[n] * d3[m];
-                v = A.H2[n * BP + m] > 0.0f ? g : 0.0f;
+        // D2 panel Bt[nl][m], nl = 2*it + half, it < 63 (row 125 = 0)
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            float hv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) hv[u] = A.H2[(nb + min(2 * (blk * 32 + u) + half, NQW - 1)) * BP + mcol];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int nl = 2 * (blk * 32 + u) + half;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * (nb + min(nl, NQW - 1)));
+                if (nl < 126) Bt[nl * BP + mcol] = nl < NQW ? d2_val(hv[u], 2, w.x, w.y, d3a, d3b) : 0.0f;
             }
-            Bt[e] = v;
         }
+        // W2 panel At[kl][nl] (row stride 127): 32 x 126 elements, 16 loads in flight per thread
         const float *__restrict__ W2 = P + off_w2(IN);
-        for (int e = tid; e < 32 * 126; e += 256) {
-            const int kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
-            At[kl * 127 + nl] = (k < H1N && nl < NQW) ? W2[(int64_t)k * H2N + nb + nl] : 0.0f;
+        {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = min(u * 256 + tid, 32 * 126 - 1), kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
+                const float t = W2[(int64_t)min(k, H1N - 1) * H2N + nb + min(nl, NQW - 1)];
+                wv[u] = (k < H1N && nl < NQW) ? t : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = u * 256 + tid, kl = e / 126, nl = e - kl * 126;
+                if (e < 32 * 126) At[kl * 127 + nl] = wv[u];
+            }
         }
         __syncthreads();
         const float *pa = At + li * 127, *pb = Bt + wave * 32 + li;
@@ -376,15 +573,17 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         const int m = wave * 32 + li;
         float *D1 = A.D1P + (int64_t)nq * H1N * BP;
         float da0 = 0.0f, da1 = 0.0f;
+        f32x16 pre;                             // layer-1 pre-activations of this (k-tile, m-tile): the relu mask, in acc's layout
+        if (A.DAP && IN == CIN) pre = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (k < H1N) {
                 D1[k * BP + m] = acc[r];
                 if (A.DAP && IN == CIN) {
-                    const float v = h1_at<IN>(w1, xs, k, m) > 0.0f ? acc[r] : 0.0f;
-                    da0 = fmaf(w1[9 * H1N + k], v, da0);       // W1[9 + o][k]: the action rows of the critic's first layer
-                    da1 = fmaf(w1[10 * H1N + k], v, da1);
+                    const float v = pre[r] > 0.0f ? acc[r] : 0.0f;
+                    da0 = fmaf(w1[9 * W1C + k], v, da0);       // W1[9 + o][k]: the action rows of the critic's first layer
+                    da1 = fmaf(w1[10 * W1C + k], v, da1);
                 }
             }
         }
@@ -399,7 +598,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
     }
 }
 
-__global__ __launch_bounds__(256) void k_bwd(BwdArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_bwd(BwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (A.in == SIN) bwd_body<SIN>(A, smem); else bwd_body<CIN>(A, smem);
@@ -442,37 +641,8 @@ __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XS
 
 __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad)
 {
-    __shared__ float xs[CIN * BP];
+    __shared__ float xs[W1K * BP];
     if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad, xs); else l1bwd_body<CIN>(P, x, D1P, grad, xs);
-}
-
-// ---- kernel F: actor head backward (1 workgroup): da -> d3a, actor loss, gb3 ------------------------------------
-__global__ __launch_bounds__(256) void k_head_actor(shems_ddpg d)
-{
-    __shared__ float red[8];
-    float *ws = d.ws;
-    const int t = threadIdx.x, o = t >> 7, m = t & 127;
-    float da = 0.0f;
-#pragma unroll 8
-    for (int p = 0; p < KT * NQ; ++p) da += ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
-    const float a = ws[WS_API + t];
-    const float d3 = da * (1.0f - a * a);                       // through tanh
-    ws[WS_D3A + t] = d3;
-    float q = 0.0f;
-    if (o == 0 && m < d.batch) {
-        const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
-        q = d.critic[off_b3(CIN, 1)];
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) q += Pq[(tt * 2) * BP + m];
-    }
-    const float sg = wave_sum(d3), sq = wave_sum(q);
-    if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
-    __syncthreads();
-    if (t == 0) {
-        d.grad_actor[off_b3(SIN, 2) + 0] = red[0] + red[1];
-        d.grad_actor[off_b3(SIN, 2) + 1] = red[2] + red[3];
-        d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
-    }
 }
 
 // ---- kernel G: Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------
@@ -481,7 +651,7 @@ __global__ __launch_bounds__(256) void k_head_actor(shems_ddpg d)
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
 __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mt,
                                                    float *__restrict__ vt, float *__restrict__ target, int n, double eta,
-                                                   double bp1, double bp2, double gscale, float tau)
+                                                   double bp1, double bp2, double gscale, float tau, float *__restrict__ w1t_g, int in)
 {
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,6 +664,10 @@ __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const 
     mt[i] = m1; vt[i] = v1; p[i] = pn;
     const float one_m_tau = 1.0f - tau;
     target[i] = one_m_tau * target[i] + tau * pn;
+    if (w1t_g && i < in * H1N + H1N) {       // keep the packed layer-1 image of the updated network current
+        const int j = i / H1N, k = i - j * H1N;
+        w1t_g[(j < in ? j : W1K - 1) * W1C + k] = pn;
+    }
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -587,33 +761,32 @@ int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad: bad replay ring / length");
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_prep, dim3(1), dim3(128), 0, st, *d, *ring, ring_len, seed, tick);
+    hipLaunchKernelGGL(k_prep, dim3(5), dim3(256), 0, st, *d, *ring, ring_len, seed, tick);
     const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
     const XSrc x_sa{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr};
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
-    f.job[0] = FwdJob{d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
+    f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
     hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
-    f.job[0] = FwdJob{d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
-    f.job[1] = FwdJob{d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
-    f.job[2] = FwdJob{d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
+    f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
+    f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
+    f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
     hipLaunchKernelGGL(k_fwd, dim3(NT, 3), dim3(256), FWD_LDS, st, f);
-    hipLaunchKernelGGL(k_head_loss, dim3(1), dim3(128), 0, st, *d);
     float *S = slot(ws, SLOT_CRITIC);
-    const BwdArgs b{d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ), dim3(256), BWD_LDS, st, b);
+    const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG), dim3(256), BWD_LDS, st, b);
     hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
                        (const float *)(S + SL_D1P), d->grad_critic);
     return hip_ok(hipGetLastError(), "ddpg critic_grad launches");
 }
 
 static int adam_launch(float *p, const float *g, float *m, float *v, float *target, int n, double eta, double bp1, double bp2,
-                       double gscale, float tau, hipStream_t st)
+                       double gscale, float tau, float *w1t_g, int in, hipStream_t st)
 {
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau);
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -621,7 +794,7 @@ int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double 
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_apply")) return rc;
     return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2,
-                       grad_scale, d->tau, (hipStream_t)stream);
+                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, (hipStream_t)stream);
 }
 
 int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
@@ -636,14 +809,13 @@ int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
     float *C2 = slot(ws, SLOT_CRITIC2);
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
-    f.job[0] = FwdJob{d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
+    f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
     hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
-    const BwdArgs bi{d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0};
+    const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d};
     hipLaunchKernelGGL(k_bwd, dim3(KT * NQ), dim3(256), BWD_LDS, st, bi);
-    hipLaunchKernelGGL(k_head_actor, dim3(1), dim3(256), 0, st, *d);
     float *S = slot(ws, SLOT_ACTOR);
-    const BwdArgs b{d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ), dim3(256), BWD_LDS, st, b);
+    const BwdArgs b{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ, 2, *d};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG), dim3(256), BWD_LDS, st, b);
     hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
                        (const float *)(S + SL_D1P), d->grad_actor);
     return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
@@ -653,7 +825,7 @@ int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double b
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_apply")) return rc;
     return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, grad_scale,
-                       d->tau, (hipStream_t)stream);
+                       d->tau, nullptr, (int)SIN, (hipStream_t)stream);
 }
 
 int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed, float *d_s_min, float *d_s_max,
