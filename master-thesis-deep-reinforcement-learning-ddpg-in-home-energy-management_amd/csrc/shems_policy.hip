@@ -14,16 +14,18 @@
 //     the B operand (B[k][j = m]).  v_mfma_f32_32x32x2_f32: lane l holds A[l&31][l>>5], B[l>>5][l&31].
 //   * layer 2 (97.5 % of the FLOPs): wave w accumulates the 128(n) x BM(m) slab n in [128w, 128w+128)
 //     = 4 x TM tiles of 32x32 (16*4*TM accumulator registers) over K = 250 = 125 MFMA k-steps.
-//     Both operands are streamed through LDS in chunks of KC = 10 k-rows, double-buffered:
-//     W2 rows come from L2 (global -> registers -> LDS, loads issued one chunk ahead), and the layer-1
-//     activations relu(W1 x + b1) of the chunk are (re)computed on the VALU from the 9 normalised
-//     inputs -- K = 9 is too thin for the matrix pipe and recomputing is cheaper than holding the
-//     250 x BM activation tile (125 KB at BM = 128) in LDS.
+//     Both operands are streamed through LDS, double-buffered: W2 in chunks of 16 k-rows by LDS-DMA
+//     (global_load_lds_dwordx4, issued one chunk ahead), and the layer-1 activations relu(W1 x + b1) in
+//     32-row groups that are RECOMPUTED ON THE MATRIX PIPE as well (K = 9 inputs + a bias row, padded to
+//     12 = 6 MFMA k-steps per 32x32 tile, +2.3 % MFMA work) -- cheaper than holding the 250 x BM
+//     activation tile (125 KB at BM = 128) in LDS, and it keeps the VALU out of the main loop (the first
+//     version computed them with FMAs: profiles/r01_train_v1_*).  K is padded 250 -> 256; the pad rows of
+//     layer 1 are exactly zero.
 //   * epilogue: bias + relu on the accumulators, layer 3 (500 -> 2) as per-lane partial dot products
 //     reduced across lane halves (DPP) and the 4 waves (LDS), + b3, tanh, noise, clamp.
 //   * one thread per env then runs scale_action + step! (shems_core.h, exact reference arithmetic)
 //     and pushes the transition into the HBM replay ring.
-// LDS: 2 x 20 KB (W2 chunks) + 2 x KC*BM*4 (H chunks) + x (9*BM*4) + W1/b1 10 KB + b2/W3/b3 6 KB.
+// LDS: 2 x 32 KB (W2 chunks) + 2 x 32*BM*4 (layer-1 groups) + x (12*BM*4) + layer-1 image 12 KB + b2/W3/b3 6 KB.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -36,9 +38,10 @@ namespace shems {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kIn = 9, kH1 = SHEMS_L1, kH2 = SHEMS_L2, kOut = 2;
-constexpr int kKC = 10;                         // k-rows per staged chunk (5 MFMA k-steps)
-constexpr int kChunks = kH1 / kKC;              // 25
-constexpr int kWcFloats = kKC * kH2 + 16;       // + pad: the last n-tile reads 12 floats past a row
+constexpr int kKC = 16;                         // k-rows per staged W2 chunk (8 MFMA k-steps)
+constexpr int kChunks = 16;                     // K = 250 padded to 256: the padded rows of layer 1 are exactly 0
+constexpr int kWcFloats = 8192 + 16;             // 32 whole 1-KiB LDS-DMA pieces (16 rows = 8000 floats, + 192 of the next row) + read pad
+constexpr int kW1K = 12, kW1C = 256;            // layer-1 operand image: rows 0..8 W1[j][k], row 11 b1[k], rest 0
 constexpr int kOffB1 = kIn * kH1, kOffW2 = kOffB1 + kH1, kOffB2 = kOffW2 + kH1 * kH2, kOffW3 = kOffB2 + kH2,
               kOffB3 = kOffW3 + kH2 * kOut;
 static_assert(kOffB3 + kOut == SHEMS_ACTOR_PARAMS, "actor layout");
@@ -64,7 +67,7 @@ struct ActArgs {
 template <int TM>
 constexpr size_t act_lds_bytes()
 {
-    return sizeof(float) * (2 * kWcFloats + 2 * kKC * 32 * TM + kIn * 32 * TM + (kIn * kH1 + kH1) + (kTailFloats + 2) +
+    return sizeof(float) * (2 * kWcFloats + 2 * 32 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
                             4 * 32 * TM * kOut);
 }
 
@@ -87,16 +90,40 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
     return make_float2(r * c, r * s);
 }
 
+// Scheduling pipeline of one chunk (one basic block): [DS reads of k-step 0], then per k-step
+// [2*TM MFMAs] [DS reads of the NEXT k-step] [2*TM MFMAs] [one LDS-DMA piece]: the operand fetch sits in the middle of an
+// MFMA group, half a group (~500 cycles) ahead of its first use.  ds_read2_b32 fetches two operands, so a k-step is
+// 2 + ceil(TM/2) DS instructions.
+template <int TM, bool DMA>
+__device__ __forceinline__ void sched_chunk()
+{
+    constexpr int DS = 2 + (TM + 1) / 2;
+    __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+#pragma unroll
+    for (int ks = 0; ks < kKC / 2; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+        if (ks + 1 < kKC / 2) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+        if (DMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+}
+
+#ifdef ABL_STAMP
+#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define PSTAMP(i)
+#endif
 template <int TM>
 __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
 {
+    PSTAMP(0);
     constexpr int BM = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Wc = reinterpret_cast<float *>(smem);             // [2][kWcFloats]
-    float *Hc = Wc + 2 * kWcFloats;                          // [2][kKC][BM]
-    float *xT = Hc + 2 * kKC * BM;                           // [9][BM]   normalised obs, feature-major
-    float *w1 = xT + kIn * BM;                               // W1 [9][250] then b1 [250]
-    float *tl = w1 + (kIn * kH1 + kH1);                      // b2 [500], W3 [500][2], b3 [2]
+    float *Wc = reinterpret_cast<float *>(smem);             // [2][kWcFloats]   W2 chunks (16 rows x 500)
+    float *Hc = Wc + 2 * kWcFloats;                          // [2][32][BM]      relu(layer 1), 32-row groups
+    float *xT = Hc + 2 * 32 * BM;                            // [12][BM]  normalised obs (rows 0..8), row 11 = 1 (bias), rest 0
+    float *w1 = xT + kW1K * BM;                              // [12][256] layer-1 operand image
+    float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
 
     const int tid = threadIdx.x;
@@ -105,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     const int64_t env0 = (int64_t)blockIdx.x * BM;
     const float *__restrict__ P = A.p.actor;
 
-    // ---- stage 0: x = normalize(s) -> xT[k][m]; W1/b1 and b2/W3/b3 -> LDS; W2 chunk 0 -> LDS -------
+    // ---- stage 0: x = normalize(s) -> xT[k][m]; layer-1 image, b2/W3/b3 -> LDS; W2 chunk 0 -> LDS --------------
     for (int e = tid; e < BM * kIn; e += 256) {
         const int m = e / kIn, k = e - m * kIn;
         const int64_t g = env0 * kIn + e;
@@ -116,88 +143,132 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
         }
         xT[k * BM + m] = x;
     }
-    for (int e = tid; e < (kIn * kH1 + kH1) / 4; e += 256)
-        reinterpret_cast<float4 *>(w1)[e] = reinterpret_cast<const float4 *>(P)[e];
-    for (int e = tid; e < kH2P; e += 256) tl[e] = e < kH2 ? P[kOffB2 + e] : 0.0f;
-    for (int e = tid; e < kH2P * kOut; e += 256) tl[kH2P + e] = e < kH2 * kOut ? P[kOffW3 + e] : 0.0f;
-    if (tid < kOut) tl[kH2P + kH2P * kOut + tid] = P[kOffB3 + tid];
+    for (int e = tid; e < 3 * BM; e += 256) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
+    {   // w1[j][k]: j < 9 -> W1[j][k], j == 11 -> b1[k], else 0; columns 250..255 zero (thread = column k)
+        float v[kW1K];
+        const int kc = min(tid, kH1 - 1);
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) v[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? v[j] : 0.0f;
+    }
+    {   // b2 | W3 | b3 are contiguous in the parameter block (1502 floats): 6 clamped loads in flight per thread
+        float v[6];
+#pragma unroll
+        for (int it = 0; it < 6; ++it) v[it] = P[kOffB2 + min(it * 256 + tid, kH2 + kH2 * kOut + kOut - 1)];
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int e = it * 256 + tid;                      // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
+            if (e < kH2) tl[e] = v[it];
+            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = v[it];
+            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = v[it];
+        }
+        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
+        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
+    }
     if (tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
 
-    // W2 chunk staging, global -> LDS directly (global_load_lds_dwordx4: no staging registers).  A chunk is
-    // kKC*500*4 = 20000 contiguous bytes = 19 full 1-KiB wave pieces + one of 544 B (34 lanes); wave w
-    // issues pieces w, w+4, ...  The LDS image is the linear copy (destination = M0 base + lane*16).
+    // W2 chunk staging, global -> LDS directly (global_load_lds_dwordx4: no staging registers).  A chunk is 16 rows =
+    // 32000 contiguous bytes = 31 full 1-KiB wave pieces + one of 256 B (16 lanes); wave w issues pieces w, w+4, ...
+    // The LDS image is the linear copy (destination = M0 base + lane*16).  The last chunk holds only rows 240..249
+    // (20000 B): its rows 10..15 keep stale (finite) weights, which meet the all-zero rows 250..255 of layer 1.
     const char *W2g = reinterpret_cast<const char *>(P + kOffW2);
     constexpr int kChunkBytes = kKC * kH2 * 4;
-    constexpr int kPieces = (kChunkBytes + 1023) / 1024;            // 20
-    constexpr int kTailLanes = (kChunkBytes - (kPieces - 1) * 1024) / 16;   // 34
-#define W2_ISSUE(chunk, buf)                                                                      \
+    constexpr int kTotalBytes = kH1 * kH2 * 4;
+#define W2_PIECE(chunk, buf, pc)                                                                  \
     do {                                                                                          \
-        const char *src_ = W2g + (size_t)(chunk) * kChunkBytes;                                   \
-        char *dst_ = reinterpret_cast<char *>(Wc + (buf) * kWcFloats);                            \
-        _Pragma("unroll") for (int pc_ = wave; pc_ < kPieces; pc_ += 4) {                         \
-            if (pc_ < kPieces - 1 || lane < kTailLanes)                                           \
-                glds16(src_ + pc_ * 1024 + lane * 16, dst_ + pc_ * 1024);                         \
+        const int off_ = (pc) * 1024 + lane * 16;                                                 \
+        if (off_ < kChunkBytes && (chunk) * kChunkBytes + off_ < kTotalBytes)                     \
+            glds16(W2g + (chunk) * kChunkBytes + off_,                                            \
+                   reinterpret_cast<char *>(Wc + (buf) * kWcFloats) + (pc) * 1024);               \
+    } while (0)
+#define W2_ISSUE(chunk, buf)                                                                      \
+    do { _Pragma("unroll") for (int pc_ = wave; pc_ < 32; pc_ += 4) W2_PIECE(chunk, buf, pc_); } while (0)
+    // Layer 1 on the matrix pipe (K = 12 = 6 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
+    // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
+#define L1_GROUP(g)                                                                               \
+    do {                                                                                          \
+        if (wave < TM) {                                                                          \
+            f32x16 t_;                                                                            \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) t_[r_] = 0.0f;                      \
+            _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
+                const int j_ = 2 * s_ + lh;                                                       \
+                t_ = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j_ * kW1C + 32 * (g) + li],          \
+                                                          xT[j_ * BM + 32 * wave + li], t_, 0, 0, 0); \
+            }                                                                                     \
+            float *dst_ = Hc + ((g) & 1) * (32 * BM) + 32 * wave + li;                            \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
+                dst_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t_[r_], 0.0f);             \
         }                                                                                         \
     } while (0)
-    // layer 1 for the k-rows of one chunk: h1[k][m] = relu(b1[k] + sum_j W1[j][k] x[j][m])
-    auto h1_chunk = [&](int chunk, int buf) {
-        float *dst = Hc + buf * (kKC * BM);
-#pragma unroll 1
-        for (int e = tid; e < kKC * BM; e += 256) {
-            const int kl = e / BM, m = e - kl * BM;
-            const int k = chunk * kKC + kl;
-            float acc = w1[kIn * kH1 + k];
-#pragma unroll
-            for (int j = 0; j < kIn; ++j) acc = fmaf(w1[j * kH1 + k], xT[j * BM + m], acc);
-            dst[e] = fmaxf(acc, 0.0f);
-        }
-    };
 
     W2_ISSUE(0, 0);
     __syncthreads();                     // xT, w1 visible
-    h1_chunk(0, 0);
+    PSTAMP(1);
+    L1_GROUP(0);
     __syncthreads();
+    PSTAMP(2);
 
-    // ---- layer 2: 125 k-steps of 4 x TM MFMA tiles per wave ---------------------------------------
+    // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
     f32x16 acc[4][TM];
+    const int nbase = wave * 128;
+    // the accumulators start at b2[n] (rows >= 500: 0), so the epilogue is relu + two FMAs per element
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b)
+        for (int r = 0; r < 16; ++r) {
+            const float bias = tl[nbase + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int b = 0; b < TM; ++b) acc[a][b][r] = bias;
+        }
 
-    const int nbase = wave * 128;
-    for (int c = 0; c < kChunks; ++c) {
-        const int cur = c & 1, nxt = cur ^ 1;
-        if (c + 1 < kChunks) {
-            W2_ISSUE(c + 1, nxt);        // LDS-DMA in flight under the MFMAs below; __syncthreads drains it
-            h1_chunk(c + 1, nxt);
-        }
-        const float *Wb = Wc + cur * kWcFloats + nbase + li;
-        const float *Hb = Hc + cur * (kKC * BM) + li;
-#pragma unroll
-        for (int ks = 0; ks < kKC / 2; ++ks) {
-            const int krow = 2 * ks + lh;
-            float af[4], bf[TM];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) af[a] = Wb[krow * kH2 + 32 * a];
-#pragma unroll
-            for (int b = 0; b < TM; ++b) bf[b] = Hb[krow * BM + 32 * b];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
-        }
-        __syncthreads();
+    // One chunk = 8 k-steps x (4 x TM) MFMAs.  The operands of k-step ks+1 are fetched from LDS before the MFMAs of
+    // k-step ks issue (register double buffer; sched_group_barrier pins that order -- left alone the compiler sinks each
+    // ds_read to just before its first use and the wave, alone on its SIMD, eats the LDS latency 16 times per chunk).
+    // ISSUE: 0 = the next chunk is a whole 32-piece chunk (branch-free LDS-DMA, one piece per k-step), 1 = the next chunk is
+    // the last one (rows 240..249 only, guarded), 2 = nothing to fetch.  ODD: this chunk also produces the next layer-1 group.
+#define CHUNK_BODY(c, ISSUE, ODD)                                                                               \
+    do {                                                                                                        \
+        const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
+        if (ODD) L1_GROUP(((c) + 1) >> 1);                                                                      \
+        const float *Wb_ = Wc + cur_ * kWcFloats + nbase + li;                                                  \
+        const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + li;                     \
+        float af_[2][4], bf_[2][TM];                                                                            \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[0][a] = Wb_[lh * kH2 + 32 * a];                       \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[0][b] = Hb_[lh * BM + 32 * b];                       \
+        _Pragma("unroll") for (int ks = 0; ks < kKC / 2; ++ks) {                                                \
+            if (ks + 1 < kKC / 2) {                                                                             \
+                const int kr_ = 2 * (ks + 1) + lh;                                                              \
+                _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[(ks + 1) & 1][a] = Wb_[kr_ * kH2 + 32 * a];   \
+                _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[(ks + 1) & 1][b] = Hb_[kr_ * BM + 32 * b];   \
+            }                                                                                                   \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                       \
+                _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                  \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[ks & 1][a], bf_[ks & 1][b], acc[a][b], 0, 0, 0); \
+            if (ISSUE == 0)                                                                                     \
+                glds16(W2g + ((c) + 1) * kChunkBytes + (wave + 4 * ks) * 1024 + lane * 16,                      \
+                       reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + (wave + 4 * ks) * 1024);               \
+            else if (ISSUE == 1)                                                                                \
+                W2_PIECE((c) + 1, nxt_, wave + 4 * ks);                                                         \
+        }                                                                                                       \
+        if (ISSUE != 1) sched_chunk<TM, ISSUE == 0>();                                                          \
+        __syncthreads();                                                                                        \
+    } while (0)
+
+#pragma unroll 1
+    for (int cp = 0; cp < (kChunks - 2) / 2; ++cp) {     // chunks 0..13: the next chunk (1..14) is whole
+        CHUNK_BODY(2 * cp, 0, false);
+        CHUNK_BODY(2 * cp + 1, 0, true);
     }
+    CHUNK_BODY(kChunks - 2, 1, false);                    // chunk 14 fetches the short last chunk
+    CHUNK_BODY(kChunks - 1, 2, false);                    // chunk 15 (rows 240..255; 250..255 are zero in Hc)
+    PSTAMP(10);
 
     // ---- epilogue: relu(acc + b2), layer 3 partial dot products ------------------------------------
     float o0[TM], o1[TM];
 #pragma unroll
     for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
-    const float *b2s = tl, *w3s = tl + kH2P;
+    const float *w3s = tl + kH2P;
     // The accumulators live in AGPRs; read them out one row at a time with v_accvgpr_read (asm volatile keeps
     // program order, which bounds VGPR pressure -- left to itself the compiler copies all 64*TM*4 values first).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA D -> v_accvgpr_read hazard (nothing pads asm)
@@ -205,20 +276,16 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_sched_barrier(0);  // ... and keep the bias / W3 LDS reads with their row
+            if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the W3 LDS reads near their rows (VGPR pressure)
             const int n = nbase + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;     // C/D row of v_mfma_f32_32x32x*
-            const bool valid = n < kH2;
-            const float bias = b2s[n];
-            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);
-            const float wa = w3.x, wb = w3.y;
+            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);   // rows >= 500: zero weights (and finite h)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 float x;
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[a][b][r]));
-                float h = fmaxf(x + bias, 0.0f);
-                h = valid ? h : 0.0f;                                           // rows >= 500 hold garbage
-                o0[b] = fmaf(h, wa, o0[b]);
-                o1[b] = fmaf(h, wb, o1[b]);
+                const float h = fmaxf(x, 0.0f);
+                o0[b] = fmaf(h, w3.x, o0[b]);
+                o1[b] = fmaf(h, w3.y, o1[b]);
             }
         }
     }
@@ -233,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     }
     __syncthreads();
 
+    PSTAMP(11);
     // ---- one thread per env: tanh, noise, clamp, scale_action, step!, remember ---------------------
     double reward = 0.0;
     const int64_t i = env0 + tid;
@@ -281,12 +349,15 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
             }
         }
     }
+    PSTAMP(12);
+#ifndef ABL_STAMP
     if (A.block_reward) {
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Wc);     // Wc is dead by now
         const double s = block_sum(reward, red64);
         if (tid == 0) A.block_reward[blockIdx.x] = s;
     }
+#endif
 }
 
 // BM: as large as keeps >= 2 workgroups per CU's worth of tiles (256 CUs); smaller batches use smaller tiles.
