@@ -147,44 +147,99 @@ class PolicyWorkload(EnvWorkload):
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
 
-def cpu_baseline(n_envs, budget_s=12.0):
-    """The CPU oracle (C restatement of shems_LU1.jl, `kind: port`) on this box's host cores: one
-    thread, the same workload (random targets, 72-step episodes), bounded sample."""
+def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
+    """The CPU oracle (`kind: port`: C restatement of shems_LU1.jl + NumPy restatement of the DDPG learner) on this
+    box's host cores, ONE thread, on a bounded sample of the same workload: the same vector step (act + noise +
+    scale_action + step! + remember [+ `updates` x replay()]) over a 4096-env slice, timed for ~10 s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_c
+    import ddpg_oracle as DO
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                            # pragma: no cover
+        threadpool_limits = None
     S = importlib.import_module(PKG)
     tab = S.tables.synthetic_table("train", 98)
-    n = min(n_envs, 16384)
-    b = oracle_c.Batch(n, EP_LEN, tab, oracle_c.profile(98))
     rng = np.random.default_rng(0)
-    acts = [rng.random((n, 2)).astype(np.float32) for _ in range(4)]
-    idx0 = rng.integers(1, tab.shape[0] - EP_LEN + 1, n)
-    soc0 = (rng.random(n) * 6.75).astype(np.float32)
     L = oracle_c.lib()
+
+    def env_batch(n):
+        b = oracle_c.Batch(n, EP_LEN, tab, oracle_c.profile(98))
+        idx0 = rng.integers(1, tab.shape[0] - EP_LEN + 1, n)
+        soc0 = (rng.random(n) * 6.75).astype(np.float32)
+        return b, idx0, soc0
+
+    # (a) step! only, 1 thread and all cores (OpenMP) -- the env half of the path
+    n = min(n_envs, 16384)
+    b, idx0, soc0 = env_batch(n)
+    acts = [rng.random((n, 2)).astype(np.float32) for _ in range(4)]
     rew = np.empty(n)
-    steps = 0
-    t_step = 0.0
+    obs = np.empty((n, 9), np.float32)
+    steps, t_step = 0, 0.0
     t_all0 = time.perf_counter()
-    while time.perf_counter() - t_all0 < budget_s:
+    while time.perf_counter() - t_all0 < 4.0:
         b.reset(False, idx0, soc0)                  # python-loop reset: not timed
         t0 = time.perf_counter()
         for t in range(EP_LEN):
             L.orc_batch_step(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, None, None)
         t_step += time.perf_counter() - t0
         steps += n * EP_LEN
-    one = steps / t_step
-    # all host cores (OpenMP over envs), short
-    ncore = os.cpu_count() or 1
+    env_one = steps / t_step
     b.reset(False, idx0, soc0)
-    obs = np.empty((n, 9), np.float32)
     t0 = time.perf_counter()
     for t in range(EP_LEN):
         L.orc_batch_step_omp(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, obs.ctypes.data)
-    allc = n * EP_LEN / (time.perf_counter() - t0)
-    return {"value": one, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes, random targets, {steps} env-steps in {t_step:.1f} s (policy/update not included)",
-            "all_cores_value": allc, "all_cores": ncore}
+    env_all = n * EP_LEN / (time.perf_counter() - t0)
+    out = {"env_only_value": env_one, "env_only_all_cores_value": env_all, "all_cores": os.cpu_count() or 1}
+    if mode == "env":
+        out.update({"value": env_one, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                    "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes, {steps} env-steps in {t_step:.1f} s"})
+        return out
+
+    # (b) the full vector step of the train / policy workload on a 4096-env slice, 1 thread
+    n = min(n_envs, 4096)
+    b, idx0, soc0 = env_batch(n)
+    b.reset(False, idx0, soc0)
+    actor, critic = DO.init_params(1231, 9, 2, 0), DO.init_params(1231, 11, 1, 1)
+    st = b.state()
+    s_min, s_max = st.min(0), st.max(0)
+    learner = DO.Learner(actor, critic, s_min, s_max)
+    cap = 24000
+    ring = dict(s=np.zeros((cap, 9), np.float32), a=np.zeros((cap, 2), np.float32), r=np.zeros(cap, np.float32),
+                s2=np.zeros((cap, 9), np.float32), d=np.zeros(cap, bool))
+    ring["s"][:] = st[rng.integers(0, n, cap)]
+    ring["s2"][:] = ring["s"]
+    win = min(n, cap // EP_LEN)
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        nstep, t0, pos = 0, time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s - 5.0 or nstep < 2:
+            s = b.state()
+            a = DO.act(learner.actor, s, s_min, s_max, True, seed=1, tick=nstep)              # actor + Gaussian noise + clamp
+            L.orc_batch_step(b.ptr, n, oracle_c.scale_action(a).ctypes.data, 0, rew.ctypes.data, None, None)
+            s2 = b.state()
+            sl = (pos + np.arange(win)) % cap                                                 # remember(): rotating window
+            ring["s"][sl], ring["a"][sl], ring["r"][sl], ring["s2"][sl] = s[:win], a[:win], rew[:win], s2[:win]
+            pos += win
+            if mode == "train":
+                for u in range(updates):
+                    i = DO.sample_indices(1, nstep * 8 + u, 120, cap)
+                    learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
+            nstep += 1
+            if nstep % (EP_LEN - 1) == 0:
+                b.reset(False, idx0, soc0)
+        dt = time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    out.update({"value": n * nstep / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                "sample": f"CPU oracle (C env + NumPy learner, BLAS limited to 1 thread), the same vector step "
+                          f"(mode={mode}, {updates} update/step) on a {n}-env slice: {nstep} vector steps = {n * nstep} env-steps in {dt:.1f} s",
+                "updates_per_sec": (updates * nstep / dt) if mode == "train" else None})
+    return out
 
 
 def main():
@@ -247,12 +302,18 @@ def main():
     if rank == 0:
         k = wl.kernel_pass(min(args.steps, 500))
         achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes, see profiles/README.md
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(mode, {})
+            if rec.get("envs_per_gpu") == args.envs:
+                traffic = rec.get("hbm_bytes_per_launch")
         roof = {"bound": k["bound"], "achieved": achieved, "peak": k["peak"], "unit": k["unit"],
-                "frac": achieved / k["peak"], "traffic": None, "kernel": k["kernel"],
+                "frac": achieved / k["peak"], "traffic": traffic, "kernel": k["kernel"],
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
                 "algorithmic_per_launch": k["algorithmic"]}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.envs)
+            cpu = cpu_baseline(args.envs, mode, args.updates)
     if dist is not None:
         dist.barrier()
     if rank == 0:
