@@ -215,6 +215,8 @@ int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64
 int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
                        float *d_rewards_f32, double *d_block_reward, double *d_returns_acc,
                        const shems_replay *ring, const shems_ring_window *window, void *stream);
+/* scale_action (DDPG.jl:178-184) on device: d_a [n][2] in [-1,1] -> d_out [n][2] SoC targets in [0,1]. */
+int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stream);
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 

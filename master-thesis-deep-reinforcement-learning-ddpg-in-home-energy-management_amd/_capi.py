@@ -77,6 +77,7 @@ def _declare(L):
         "shems_action_dev": ([PV, vp, C.c_int, vp, vp], C.c_int),
         "shems_reset_dev": ([PV, C.c_int, vp, vp, vp], C.c_int),
         "shems_reset_seeded_dev": ([PV, u64, u32, vp], C.c_int),
+        "shems_scale_action_dev": ([vp, i64, vp, vp], C.c_int),
         "shems_rollout_dev": ([PV, C.c_int, i32, u64, vp, C.POINTER(Replay), i64, i64, vp], C.c_int),
     }
     for name, (args, res) in sigs.items():

@@ -224,6 +224,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(shems_view v, int policy, in
     slab_store(tile, v.obs, base, v.n_envs);
 }
 
+__global__ __launch_bounds__(kBlock) void k_scale_action(const float *__restrict__ a, int64_t n2, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n2) out[i] = scale_action(a[i]);
+}
+
 }  // namespace shems
 
 // =================================================================== C ABI ==
@@ -276,6 +282,13 @@ int shems_reset_seeded_dev(const shems_view *v, uint64_t seed, uint32_t episode,
     hipLaunchKernelGGL(k_reset, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, 0,
                        (const int32_t *)nullptr, (const float *)nullptr, 1, seed, episode);
     return hip_ok(hipGetLastError(), "k_reset launch");
+}
+
+int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stream)
+{
+    if (!d_a || !d_out || n <= 0) return set_error(SHEMS_ERR_ARG, "shems_scale_action_dev: bad arguments");
+    hipLaunchKernelGGL(k_scale_action, dim3(grid_for(2 * n)), dim3(kBlock), 0, (hipStream_t)stream, d_a, 2 * n, d_out);
+    return hip_ok(hipGetLastError(), "k_scale_action launch");
 }
 
 int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t seed, double *d_returns,

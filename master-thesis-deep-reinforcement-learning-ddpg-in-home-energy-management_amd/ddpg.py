@@ -173,11 +173,14 @@ class Agent:
     def act(self, obs, train=True, tick=None, out=None):
         """act(normalize(s); train): obs [M][9] cuda float32 -> a [M][2] in [-1, 1] (unscaled)."""
         t = self.torch
-        m = obs.shape[0]
+        if isinstance(obs, tuple):                       # (device pointer, rows): e.g. the env handle's resident observations
+            ptr, m = int(obs[0]), int(obs[1])
+        else:
+            ptr, m = obs.data_ptr(), obs.shape[0]
         if out is None:
             out = t.empty((m, ACTION), dtype=t.float32, device=self.device)
         p = self._act_params(train, self.tick if tick is None else tick)
-        _capi.check(self.L.shems_actor_forward_dev(C.byref(p), C.c_void_p(obs.data_ptr()), m,
+        _capi.check(self.L.shems_actor_forward_dev(C.byref(p), C.c_void_p(ptr), m,
                                                    C.c_void_p(out.data_ptr()), self._stream()))
         return out
 

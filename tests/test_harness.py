@@ -1,0 +1,71 @@
+"""Results / tracker file formats (CPU) and the tracking inference pass (GPU) -- SURVEY.md 8f rank 2."""
+import csv
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import util as U
+from util import oracle_c
+
+
+def _H():
+    return importlib.import_module(U.PKG_NAME + ".harness")
+
+
+def test_results_and_tracker_file_formats(tmp_path):
+    H = _H()
+    g = np.load(os.path.join(U.ROOT, "tests", "golden", "oracle_golden.npz"))
+    res = g["rule_results"]
+    name = H.results_file_name(11709800, "eval", 72, 1001, 250, 500, "Charger98_rule_based_-0.5", -0.5, -0.5, out_dir=str(tmp_path / "out" / "tracker"))
+    assert name.endswith("11709800_eval_results_Charger98_rule_based_-0.5_rule_-0.5.csv")     # the reference's file name
+    H.write_to_results_file(res, name)
+    rows = list(csv.reader(open(name)))
+    assert rows[0] == ["index", "c_ev", "EV_target", "EV", "Soc_ev", "rewards", "profit", "discomfort", "penalty", "PV_DE", "B_DE",
+                       "GR_DE", "PV_B", "PV_GR", "PV_EV", "B_EV", "GR_EV", "EX_EV", "GR_B", "B_GR", "B", "B_tar", "Soc_b"]
+    back = np.array(rows[1:], dtype=np.float64)
+    assert back.shape == (72, 23) and (back.view(np.uint64) == res.view(np.uint64)).all()        # round-trips exactly
+    assert H.results_file_name(1, "eval", 72, 1001, 250, 500, "c", 1231, 1001).endswith("1_eval_results_charger_v1_72_1001_250_500_c_1231_1001.csv")
+    assert H.results_file_name(1, "eval", 72, 1001, 250, 500, "c", 1231, 301, best=True).endswith("_c_1231_best.csv")
+    trk = str(tmp_path / "out" / "Tracker_Charger.csv")
+    for k in range(2):
+        sums = H.write_to_tracker_file(name, trk, num_ep=1001, job_id=11709800, seed=-0.5, case="Charger98_rule_based_-0.5", idx=-0.5, now=f"t{k}")
+    rows = list(csv.reader(open(trk)))
+    assert rows[0] == ["time", "NUM_EP", "L1", "L2", "BATCH_SIZE", "MEM_SIZE", "MIN_EXP_SIZE", "season", "run", "Job_ID", "seed",
+                       "case", "best", "idx", "rewards", "profit", "discomfort", "penalty", "filename"]
+    assert len(rows) == 3 and rows[1][0] == "t0" and rows[2][0] == "t1" and rows[2][-1] == name
+    assert float(rows[2][14]) == pytest.approx(res[:, 5].sum(), rel=1e-15) and sums["profit"] == pytest.approx(res[:, 6].sum(), rel=1e-15)
+    with pytest.raises(ValueError):
+        H.write_to_results_file(np.zeros((3, 22)), str(tmp_path / "x.csv"))
+
+
+@pytest.mark.gpu
+def test_inference_rule_based_and_drl_tracking():
+    torch = pytest.importorskip("torch")
+    H = _H()
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    import ddpg_oracle as DO
+    ev = S.tables.synthetic_table("eval", 98)
+    env = S.ShemsBatch(3, 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    # rule based, the whole evaluation set (BASELINE config 1 shape at EP_LENGTH["all","eval"] = 1439)
+    total, res = H.inference(env, track=-0.5)
+    ref = oracle_c.Batch(1, 1439, ev, oracle_c.profile(98))
+    tot_ref, res_ref = ref.rule_episode(0, 1439, want_results=True)
+    assert res.shape == (1439, 23) and (U.bits64(res) == U.bits64(res_ref)).all() and (total == tot_ref).all()
+    # DRL tracking: the actor's deterministic actions, results rows consistent with the oracle driven by them
+    ag = D.Agent(seed=4)
+    p = D.init_params(4, 9, 2, 0); p[128000:129000] *= 50
+    ag.set_params(actor=p)
+    st = np.concatenate([ev[:, [1, 1, 0, 2, 3, 4, 5, 6, 7]]]); st[:, 0] = np.linspace(0, 6.75, len(st))
+    ag.set_norm(st.min(0), st.max(0))
+    total, res = H.inference(env, ag, track=1, num_steps=200)
+    ref = oracle_c.Batch(1, 1439, ev, oracle_c.profile(98)); ref.reset(True)
+    for t in range(200):
+        a = DO.act(p, ref.state(), st.min(0), st.max(0), False, dtype=np.float64)
+        tgt = res[t, [21, 2]].astype(np.float32)[None]                 # B_tar, EV_target the kernel used
+        assert np.abs(oracle_c.scale_action(a) - tgt).max() < 1e-5
+        rc, r, o, rr = ref.step(tgt, 1, want_results=True)
+        assert (U.bits64(rr[0]) == U.bits64(res[t])).all()
+    env.close()
