@@ -94,15 +94,15 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
 // [2*TM MFMAs] [DS reads of the NEXT k-step] [2*TM MFMAs] [one LDS-DMA piece]: the operand fetch sits in the middle of an
 // MFMA group, half a group (~500 cycles) ahead of its first use.  ds_read2_b32 fetches two operands, so a k-step is
 // 2 + ceil(TM/2) DS instructions.
-template <int TM, bool DMA>
+template <int TM, bool DMA, int NKS>
 __device__ __forceinline__ void sched_chunk()
 {
     constexpr int DS = 2 + (TM + 1) / 2;
     __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
 #pragma unroll
-    for (int ks = 0; ks < kKC / 2; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
-        if (ks + 1 < kKC / 2) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+        if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
         if (DMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     // ds_read to just before its first use and the wave, alone on its SIMD, eats the LDS latency 16 times per chunk).
     // ISSUE: 0 = the next chunk is a whole 32-piece chunk (branch-free LDS-DMA, one piece per k-step), 1 = the next chunk is
     // the last one (rows 240..249 only, guarded), 2 = nothing to fetch.  ODD: this chunk also produces the next layer-1 group.
-#define CHUNK_BODY(c, ISSUE, ODD)                                                                               \
+#define CHUNK_BODY(c, ISSUE, ODD, NKS)                                                                             \
     do {                                                                                                        \
         const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
         if (ODD) L1_GROUP(((c) + 1) >> 1);                                                                      \
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
         float af_[2][4], bf_[2][TM];                                                                            \
         _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[0][a] = Wb_[lh * kH2 + 32 * a];                       \
         _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[0][b] = Hb_[lh * BM + 32 * b];                       \
-        _Pragma("unroll") for (int ks = 0; ks < kKC / 2; ++ks) {                                                \
-            if (ks + 1 < kKC / 2) {                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < (NKS); ++ks) {                                                  \
+            if (ks + 1 < (NKS)) {                                                                               \
                 const int kr_ = 2 * (ks + 1) + lh;                                                              \
                 _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[(ks + 1) & 1][a] = Wb_[kr_ * kH2 + 32 * a];   \
                 _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[(ks + 1) & 1][b] = Hb_[kr_ * BM + 32 * b];   \
@@ -251,17 +251,17 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
             else if (ISSUE == 1)                                                                                \
                 W2_PIECE((c) + 1, nxt_, wave + 4 * ks);                                                         \
         }                                                                                                       \
-        if (ISSUE != 1) sched_chunk<TM, ISSUE == 0>();                                                          \
+        if (ISSUE != 1) sched_chunk<TM, ISSUE == 0, NKS>();                                                     \
         __syncthreads();                                                                                        \
     } while (0)
 
 #pragma unroll 1
     for (int cp = 0; cp < (kChunks - 2) / 2; ++cp) {     // chunks 0..13: the next chunk (1..14) is whole
-        CHUNK_BODY(2 * cp, 0, false);
-        CHUNK_BODY(2 * cp + 1, 0, true);
+        CHUNK_BODY(2 * cp, 0, false, kKC / 2);
+        CHUNK_BODY(2 * cp + 1, 0, true, kKC / 2);
     }
-    CHUNK_BODY(kChunks - 2, 1, false);                    // chunk 14 fetches the short last chunk
-    CHUNK_BODY(kChunks - 1, 2, false);                    // chunk 15 (rows 240..255; 250..255 are zero in Hc)
+    CHUNK_BODY(kChunks - 2, 1, false, kKC / 2);           // chunk 14 fetches the short last chunk
+    CHUNK_BODY(kChunks - 1, 2, false, (kH1 - (kChunks - 1) * kKC) / 2);   // chunk 15: rows 240..249 only = 5 k-steps
     PSTAMP(10);
 
     // ---- epilogue: relu(acc + b2), layer 3 partial dot products ------------------------------------
