@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void k_step(shems_view v, const float *__re
                                                  double *__restrict__ rewards, float *__restrict__ rewards_f32,
                                                  double *__restrict__ results, double *__restrict__ block_reward)
 {
-    __shared__ float tile[kBlock * SHEMS_NSTATE];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * SHEMS_NSTATE];
     __shared__ double red[4];
     const int64_t base = (int64_t)blockIdx.x * kBlock;
     const int64_t i = base + threadIdx.x;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_step(shems_view v, const float *__re
 __global__ __launch_bounds__(kBlock) void k_action(shems_view v, const float *__restrict__ targets, int rule_based,
                                                    float *__restrict__ out)
 {
-    __shared__ float tile[kBlock * SHEMS_NSTATE];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * SHEMS_NSTATE];
     const int64_t base = (int64_t)blockIdx.x * kBlock;
     const int64_t i = base + threadIdx.x;
     slab_load(tile, v.obs, base, v.n_envs);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(shems_view v, int rng_minus1, 
                                                   const float *__restrict__ soc_b0, int seeded, uint64_t seed,
                                                   uint32_t episode)
 {
-    __shared__ float tile[kBlock * SHEMS_NSTATE];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * SHEMS_NSTATE];
     const int64_t base = (int64_t)blockIdx.x * kBlock;
     const int64_t i = base + threadIdx.x;
     if (i < v.n_envs) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(shems_view v, int policy, in
                                                     double *__restrict__ returns, shems_replay ring,
                                                     int64_t ring_pos, int64_t ring_envs, int64_t first_kept)
 {
-    __shared__ float tile[kBlock * SHEMS_NSTATE];
+    __shared__ __attribute__((aligned(16))) float tile[kBlock * SHEMS_NSTATE];
     const int64_t base = (int64_t)blockIdx.x * kBlock;
     const int64_t i = base + threadIdx.x;
     const bool live = i < v.n_envs;

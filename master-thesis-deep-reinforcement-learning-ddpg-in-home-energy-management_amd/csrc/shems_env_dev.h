@@ -38,10 +38,23 @@ __device__ __forceinline__ void raise(int32_t *err, int code)
     if (err) atomicCAS(err, 0, code);          // sticky: first error wins
 }
 
-// obs slab of this workgroup: global <-> LDS, coalesced (thread t moves dwords t, t+256, ...).
+// obs slab of this workgroup: global <-> LDS.  A full 256-env slab is 9216 contiguous, 16-byte aligned bytes = 576 float4:
+// three 16-B-per-lane passes (the widest coalesced access); the ragged last workgroup falls back to dword passes.
 __device__ __forceinline__ void slab_load(float *lds, const float *g, int64_t base_env, int64_t n)
 {
     const int64_t first = base_env * SHEMS_NSTATE;
+    if (base_env + kBlock <= n) {
+        const float4 *src = reinterpret_cast<const float4 *>(g + first);
+        float4 v[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) v[it] = src[min(it * kBlock + (int)threadIdx.x, kBlock * SHEMS_NSTATE / 4 - 1)];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int e = it * kBlock + threadIdx.x;
+            if (e < kBlock * SHEMS_NSTATE / 4) reinterpret_cast<float4 *>(lds)[e] = v[it];
+        }
+        return;
+    }
     const int64_t total = n * SHEMS_NSTATE;
 #pragma unroll
     for (int k = 0; k < SHEMS_NSTATE; ++k) {
@@ -52,6 +65,15 @@ __device__ __forceinline__ void slab_load(float *lds, const float *g, int64_t ba
 __device__ __forceinline__ void slab_store(const float *lds, float *g, int64_t base_env, int64_t n)
 {
     const int64_t first = base_env * SHEMS_NSTATE;
+    if (base_env + kBlock <= n) {
+        float4 *dst = reinterpret_cast<float4 *>(g + first);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int e = it * kBlock + threadIdx.x;
+            if (e < kBlock * SHEMS_NSTATE / 4) dst[e] = reinterpret_cast<const float4 *>(lds)[e];
+        }
+        return;
+    }
     const int64_t total = n * SHEMS_NSTATE;
 #pragma unroll
     for (int k = 0; k < SHEMS_NSTATE; ++k) {

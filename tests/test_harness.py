@@ -69,3 +69,17 @@ def test_inference_rule_based_and_drl_tracking():
         rc, r, o, rr = ref.step(tgt, 1, want_results=True)
         assert (U.bits64(rr[0]) == U.bits64(res[t])).all()
     env.close()
+
+
+def test_checkpoint_roundtrip_and_reference_file_stems(tmp_path):
+    CK = importlib.import_module(U.PKG_NAME + ".checkpoint")
+    import ddpg_oracle as DO
+    actor = DO.init_params(1231, 9, 2, 0)
+    tr, sm, nm = np.arange(5, dtype=np.float32), np.array([1.5, -2.0]), np.zeros(5, np.float32)
+    st = CK.save(actor, tr, sm, 3, nm, idx=1001, case="Charger98_x", rng=1231, out_dir=str(tmp_path / "out" / "bson"), path="temp")
+    assert st.endswith(os.path.join("out", "bson", "temp", "DDPG_Shems_Charger_v1_72_1001_250_500_Charger98_x_1231"))
+    a, tr2, sm2, best, nm2 = CK.load(idx=1001, case="Charger98_x", rng=1231, out_dir=str(tmp_path / "out" / "bson"), path="temp")
+    assert (a == actor).all() and (tr2 == tr).all() and (sm2 == sm).all() and best == 3 and (nm2 == nm).all()
+    assert len(CK.load(idx=1001, scores_only=True, case="Charger98_x", rng=1231, out_dir=str(tmp_path / "out" / "bson"), path="temp")) == 4
+    with pytest.raises(ValueError):
+        CK.save(actor[:10], tr, sm, 3, nm, idx=1, out_dir=str(tmp_path))
