@@ -188,12 +188,21 @@ typedef struct shems_act_params {
     const float *actor;      /* dev [129002]                                                        */
     const float *s_min;      /* dev [9]  normalize(): (s - s_min) / (s_max - s_min + 1f-8), MPS:55-57 */
     const float *s_max;      /* dev [9]                                                             */
-    float    noise_mu;       /* gn = GNoise(mu, sigma_act, .)  input.jl:198-202, 235                */
+    float    noise_mu;       /* gn = GNoise(mu, sigma_act, .) / ou = OUNoise(mu, sigma, theta, dt, X)  input.jl:190-237 */
     float    noise_sigma;
-    int32_t  train;          /* act(...; train): 1 = add Gaussian noise (DDPG.jl:159-160, 172)      */
+    int32_t  train;          /* act(...; train): 1 = explore (DDPG.jl:151-172)                      */
     uint32_t tick;           /* counter word of the noise stream (the reference's rng_step, DDPG.jl:197) */
     uint64_t seed;           /* Philox key                                                          */
+    int32_t  noise_kind;     /* SHEMS_NOISE_*: which branch of act() (noise_type "gn" / "ou" / "en") */
+    float    ou_theta;       /* OUNoise theta                                                       */
+    float    ou_dt;          /* OUNoise dt (1f-2)                                                   */
+    float    eps;            /* EpsNoise: current xi = max(0.5 - zeta*(episode - MEM/EP), xi_min), DDPG.jl:69-72 */
+    float   *ou_state;       /* dev [n][2]: OUNoise.X per env (persistent, DDPG.jl:49-55); required for SHEMS_NOISE_OU */
 } shems_act_params;
+/* act()'s exploration branches (DDPG.jl:148-176).  GAUSS: clamp(a + N(mu, sigma)); OU: X += theta(mu - X)dt +
+ * sigma sqrt(dt) N(0,1), clamp(a + X); EPS: with probability eps a uniform action in [-1,1]^2, else the
+ * unperturbed a (returned unclamped by the reference -- tanh already bounds it). */
+enum { SHEMS_NOISE_GAUSS = 0, SHEMS_NOISE_OU = 1, SHEMS_NOISE_EPS = 2 };
 
 /* Which transitions of a vector step enter the replay ring: envs i with ((i - offset) mod n) < count
  * are stored at slot (pos + ((i - offset) mod n)) mod capacity.  count = 0 stores nothing. */

@@ -310,13 +310,32 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
         for (int w = 0; w < 4; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
         p0 = tanhf(p0);
         p1 = tanhf(p1);
-        if (A.p.train) {                                   // DDPG.jl:160, 172: act_pred .+ noise
-            const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
-            p0 += A.p.noise_mu + A.p.noise_sigma * z.x;
-            p1 += A.p.noise_mu + A.p.noise_sigma * z.y;
+        float a0, a1;
+        if (A.p.train && A.p.noise_kind == SHEMS_NOISE_EPS) {          // DDPG.jl:161-170
+            const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.p.tick, kStreamNoise, (uint32_t)A.p.seed,
+                                          (uint32_t)(A.p.seed >> 32));
+            const bool explore = !(u01_24(x.z) > A.p.eps);             // rng > eps: greedy; rng <= eps: uniform action
+            a0 = explore ? (float)((double)x.x * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
+            a1 = explore ? (float)((double)x.y * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
+        } else {
+            if (A.p.train) {
+                const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
+                if (A.p.noise_kind == SHEMS_NOISE_OU) {                // DDPG.jl:49-55, 157-158
+                    float2 X = reinterpret_cast<float2 *>(A.p.ou_state)[i];
+                    const float sdt = A.p.noise_sigma * sqrtf(A.p.ou_dt);
+                    X.x += A.p.ou_theta * (A.p.noise_mu - X.x) * A.p.ou_dt + sdt * z.x;
+                    X.y += A.p.ou_theta * (A.p.noise_mu - X.y) * A.p.ou_dt + sdt * z.y;
+                    reinterpret_cast<float2 *>(A.p.ou_state)[i] = X;
+                    p0 += X.x;
+                    p1 += X.y;
+                } else {                                               // DDPG.jl:57-61, 159-160: Normal(mu, sigma_act)
+                    p0 += A.p.noise_mu + A.p.noise_sigma * z.x;
+                    p1 += A.p.noise_mu + A.p.noise_sigma * z.y;
+                }
+            }
+            a0 = fminf(fmaxf(p0, -1.0f), 1.0f);                        // clamp.(act_pred .+ noise, -1f0, 1f0)
+            a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
         }
-        const float a0 = fminf(fmaxf(p0, -1.0f), 1.0f);    // clamp.(., -1f0, 1f0)
-        const float a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
         if (A.a_out) reinterpret_cast<float2 *>(A.a_out)[i] = make_float2(a0, a1);
         if (A.do_step) {
             const shems_view &v = A.v;
@@ -412,6 +431,8 @@ int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks)
 static int check_act(const shems_act_params *p, const char *fn)
 {
     if (!p || !p->actor || !p->s_min || !p->s_max) return set_error(SHEMS_ERR_ARG, "%s: actor / s_min / s_max required", fn);
+    if (p->noise_kind < SHEMS_NOISE_GAUSS || p->noise_kind > SHEMS_NOISE_EPS) return set_error(SHEMS_ERR_ARG, "%s: unknown noise_kind %d", fn, p->noise_kind);
+    if (p->train && p->noise_kind == SHEMS_NOISE_OU && !p->ou_state) return set_error(SHEMS_ERR_ARG, "%s: OU noise needs ou_state", fn);
     if (((uintptr_t)p->actor & 15) != 0) return set_error(SHEMS_ERR_ARG, "%s: actor parameter block must be 16-byte aligned", fn);
     return SHEMS_OK;
 }

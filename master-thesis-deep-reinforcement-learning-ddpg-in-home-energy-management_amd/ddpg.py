@@ -33,7 +33,11 @@ BATCH_SIZE, MEM_SIZE, NOISE_SIGMA, EP_LENGTH_TRAIN = 120, 24000, 0.1, 72
 class ActParams(C.Structure):          # shems_act_params
     _fields_ = [("actor", C.c_void_p), ("s_min", C.c_void_p), ("s_max", C.c_void_p),
                 ("noise_mu", C.c_float), ("noise_sigma", C.c_float), ("train", C.c_int32),
-                ("tick", C.c_uint32), ("seed", C.c_uint64)]
+                ("tick", C.c_uint32), ("seed", C.c_uint64), ("noise_kind", C.c_int32), ("ou_theta", C.c_float),
+                ("ou_dt", C.c_float), ("eps", C.c_float), ("ou_state", C.c_void_p)]
+
+
+NOISE_KINDS = {"gn": 0, "ou": 1, "en": 2}       # noise_type strings of the reference (DDPG.jl:152-161)
 
 
 class DdpgArgs(C.Structure):           # shems_ddpg
@@ -111,7 +115,8 @@ def init_params(seed, in_dim, out_dim, which):
 class Agent:
     """The DDPG learner state on one GPU (one replica under data parallelism)."""
 
-    def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None):
+    def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None, noise_type="gn", theta=0.15,
+                 dt=1e-2, eps=0.5):
         import torch
         self.torch = torch
         self.L = _declare()
@@ -119,6 +124,8 @@ class Agent:
         self.seed = int(seed)                      # network initialisation (identical on every replica)
         self.rng_seed = self.seed if rng_seed is None else int(rng_seed)   # noise / minibatch streams (per replica)
         self.sigma, self.mu = float(sigma), float(mu)
+        self.noise_type, self.theta, self.dt, self.eps = noise_type, float(theta), float(dt), float(eps)
+        self.ou_state = None                      # OUNoise.X per env, allocated on first use
         a = init_params(self.seed, STATE, ACTION, 0)
         c = init_params(self.seed, STATE + ACTION, 1, 1)
         assert a.size == N_ACTOR and c.size == N_CRITIC
@@ -168,7 +175,12 @@ class Agent:
     def _act_params(self, train, tick, actor=None):
         a = self.actor if actor is None else actor
         return ActParams(a.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(), self.mu, self.sigma,
-                         1 if train else 0, int(tick) & 0xFFFFFFFF, self.rng_seed)
+                         1 if train else 0, int(tick) & 0xFFFFFFFF, self.rng_seed, NOISE_KINDS[self.noise_type], self.theta,
+                         self.dt, self.eps, self.ou_state.data_ptr() if self.ou_state is not None else None)
+
+    def _ensure_ou(self, n):
+        if self.noise_type == "ou" and (self.ou_state is None or self.ou_state.shape[0] != n):
+            self.ou_state = self.torch.zeros((n, ACTION), dtype=self.torch.float32, device=self.device)   # X = zeros(Float32, 2)
 
     def act(self, obs, train=True, tick=None, out=None):
         """act(normalize(s); train): obs [M][9] cuda float32 -> a [M][2] in [-1, 1] (unscaled)."""
@@ -179,6 +191,7 @@ class Agent:
             ptr, m = obs.data_ptr(), obs.shape[0]
         if out is None:
             out = t.empty((m, ACTION), dtype=t.float32, device=self.device)
+        self._ensure_ou(m)
         p = self._act_params(train, self.tick if tick is None else tick)
         _capi.check(self.L.shems_actor_forward_dev(C.byref(p), C.c_void_p(ptr), m,
                                                    C.c_void_p(out.data_ptr()), self._stream()))
@@ -188,6 +201,7 @@ class Agent:
                  returns_acc=None, ring=None, window=None):
         """One fused vector step: s = env.state; a = act(s); step!(env, s, scale_action(a)); remember(...)."""
         v = env.view()
+        self._ensure_ou(env.n)
         p = self._act_params(train, self.tick if tick is None else tick)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         rs = ring.struct() if ring is not None else None

@@ -173,11 +173,25 @@ def init_params(seed, in_dim, out_dim, which):
 
 
 # ------------------------------------------------------------ act / replay --
-def act(actor, s, s_min, s_max, train, seed=0, tick=0, mu=0.0, sigma=0.1, dtype=np.float32):
-    """act(): clamp(actor(normalize(s)) + noise, -1, 1)  (DDPG.jl:148-176, gn noise)."""
+def act(actor, s, s_min, s_max, train, seed=0, tick=0, mu=0.0, sigma=0.1, dtype=np.float32, noise="gn", ou_state=None,
+        theta=0.15, dt=1e-2, eps=0.5):
+    """act(): the exploration branches of DDPG.jl:148-176 (gn / ou / en).  `ou_state` [n][2] is updated in place."""
     a = actor_forward(actor, normalize(s, s_min, s_max), dtype=dtype).astype(f32)
+    n = len(a)
+    if train and noise == "en":
+        i = np.arange(n, dtype=np.uint64)
+        x, y, z, _ = philox(i & 0xFFFFFFFF, i >> np.uint64(32), tick, STREAM_NOISE, seed & 0xFFFFFFFF, seed >> 32)
+        explore = ~(((z >> np.uint32(8)).astype(f32) * f32(1.0 / 16777216.0)) > f32(eps))
+        uni = np.stack([(x.astype(np.float64) / 4294967296.0 * 2 - 1), (y.astype(np.float64) / 4294967296.0 * 2 - 1)], 1).astype(f32)
+        return np.where(explore[:, None], uni, a).astype(f32)
     if train:
-        a = a + (f32(mu) + f32(sigma) * gauss_noise(seed, tick, len(a)))
+        zn = gauss_noise(seed, tick, n)
+        if noise == "ou":
+            sdt = f32(sigma) * np.sqrt(f32(dt))
+            ou_state += (f32(theta) * (f32(mu) - ou_state) * f32(dt) + sdt * zn).astype(f32)
+            a = a + ou_state
+        else:
+            a = a + (f32(mu) + f32(sigma) * zn)
     return np.clip(a, f32(-1), f32(1)).astype(f32)
 
 

@@ -123,3 +123,31 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
         pos += 333
     assert (env.idx == ref.idx()).all() and (env.step == 6).all()
     env.close()
+
+
+def test_ou_and_epsilon_noise_branches():
+    """noise_type "ou" (persistent per-env OUNoise.X) and "en" (epsilon-greedy uniform actions), DDPG.jl:49-72, 157-170."""
+    torch, S, D = _mods()
+    rng = np.random.default_rng(5)
+    m = 5000
+    obs = _rand_obs(rng, m)
+    p = D.init_params(9, 9, 2, 0); p[128000:129000] *= 30
+    s_min, s_max = obs.min(0), obs.max(0) + 0.1
+    ag = D.Agent(seed=9, noise_type="ou", sigma=0.3, theta=0.15, dt=1e-2)
+    ag.set_params(actor=p); ag.set_norm(s_min, s_max)
+    X = np.zeros((m, 2), np.float32)
+    dev = torch.from_numpy(obs).cuda()
+    for t in range(4):
+        out = ag.act(dev, train=True, tick=t).cpu().numpy()
+        ref = DO.act(p, obs, s_min, s_max, True, seed=9, tick=t, sigma=0.3, noise="ou", ou_state=X, dtype=np.float64)
+        assert np.abs(out - ref).max() < 2e-5
+    assert np.abs(ag.ou_state.cpu().numpy() - X).max() < 1e-5 and np.abs(X).std() > 0.03      # the state accumulated
+    clean = ag.act(dev, train=False).cpu().numpy()
+    assert np.abs(clean - DO.act(p, obs, s_min, s_max, False, dtype=np.float64)).max() < ATOL
+    ag2 = D.Agent(seed=9, noise_type="en", eps=0.3)
+    ag2.set_params(actor=p); ag2.set_norm(s_min, s_max)
+    out = ag2.act(dev, train=True, tick=7).cpu().numpy()
+    ref = DO.act(p, obs, s_min, s_max, True, seed=9, tick=7, noise="en", eps=0.3, dtype=np.float64)
+    assert np.abs(out - ref).max() < ATOL
+    frac = (np.abs(out - clean).max(1) > 1e-4).mean()
+    assert 0.25 < frac < 0.35
