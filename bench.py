@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env"])
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
+    ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -273,7 +274,7 @@ def main():
     if mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
-        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist)
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap)
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
 

@@ -259,11 +259,21 @@ typedef struct shems_ddpg {
 int shems_ddpg_workspace_floats(int64_t *out);
 int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len,
                            uint64_t seed, uint32_t tick, void *stream);
+/* Pipelined variant for running replay() on a second stream WHILE the fused act/step kernel of the same vector step
+ * inserts into the ring: slots [excl_pos, excl_pos + excl_count) (mod capacity) -- the window being written -- are
+ * excluded from sampling, i.e. the minibatch is drawn from the buffer as it stood before this step's inserts.
+ * excl_count = 0 is shems_ddpg_critic_grad. */
+int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len,
+                              uint64_t seed, uint32_t tick, int64_t excl_pos, int64_t excl_count, void *stream);
 int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
                             void *stream);
 int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream);
 int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
                            void *stream);
+/* Same, and also writes the updated actor into d_publish [129002] (a second copy the policy kernel of the NEXT
+ * vector step reads while this stream already works on the next update). */
+int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
+                               float *d_publish, void *stream);
 /* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
 int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
 /* min_max_buffer (MPS:50-53): minimum/maximum of s over a bootstrap sample of `count` ring entries. */

@@ -162,7 +162,8 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int
 }
 
 // ---- kernel A: sample + gather + normalize -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick)
+__global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                                              int64_t excl_pos, int64_t excl_count)
 {
     float *ws = d.ws;
     if (blockIdx.x > 0) {          // workgroups 1..4: packed layer-1 images of actor_t, critic_t, critic, actor
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, i
         // StatsBase.sample(rng, memory, BATCH) -- with replacement (MPS:33)
         const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
         const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
-        j = (int64_t)(w % (uint32_t)ring_len);
+        j = (int64_t)(w % (uint32_t)(ring_len - excl_count));
+        if (excl_count > 0) j = (excl_pos + excl_count + j) % ring.capacity;     // skip the window another stream is writing
 #pragma unroll
         for (int k = 0; k < SIN; ++k) { s[k] = ring.s[j * SIN + k]; s2[k] = ring.s2[j * SIN + k]; }
         a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
@@ -651,7 +653,8 @@ __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, c
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
 __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mt,
                                                    float *__restrict__ vt, float *__restrict__ target, int n, double eta,
-                                                   double bp1, double bp2, double gscale, float tau, float *__restrict__ w1t_g, int in)
+                                                   double bp1, double bp2, double gscale, float tau, float *__restrict__ w1t_g, int in,
+                                                   float *__restrict__ publish)
 {
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,6 +665,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const 
     const float delta = (float)((double)m1 / (1.0 - bp1) / (sqrt((double)v1 / (1.0 - bp2)) + eps) * eta);
     const float pn = p[i] - delta;
     mt[i] = m1; vt[i] = v1; p[i] = pn;
+    if (publish) publish[i] = pn;
     const float one_m_tau = 1.0f - tau;
     target[i] = one_m_tau * target[i] + tau * pn;
     if (w1t_g && i < in * H1N + H1N) {       // keep the packed layer-1 image of the updated network current
@@ -756,12 +760,20 @@ int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64
 int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
                            void *stream)
 {
+    return shems_ddpg_critic_grad_ex(d, ring, ring_len, seed, tick, 0, 0, stream);
+}
+
+int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                              int64_t excl_pos, int64_t excl_count, void *stream)
+{
     if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
     if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad: bad replay ring / length");
+    if (excl_count < 0 || excl_pos < 0 || (excl_count > 0 && (ring_len != ring->capacity || excl_count >= ring_len)))
+        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad_ex: an exclusion window needs a full ring and 0 <= count < capacity");
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_prep, dim3(5), dim3(256), 0, st, *d, *ring, ring_len, seed, tick);
+    hipLaunchKernelGGL(k_prep, dim3(5), dim3(256), 0, st, *d, *ring, ring_len, seed, tick, excl_pos, excl_count);
     const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
@@ -783,10 +795,10 @@ int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_
 }
 
 static int adam_launch(float *p, const float *g, float *m, float *v, float *target, int n, double eta, double bp1, double bp2,
-                       double gscale, float tau, float *w1t_g, int in, hipStream_t st)
+                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st)
 {
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in);
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in, publish);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -794,7 +806,7 @@ int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double 
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_apply")) return rc;
     return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2,
-                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, (hipStream_t)stream);
+                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream);
 }
 
 int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
@@ -821,11 +833,17 @@ int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
     return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
 }
 
-int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)
+int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, float *d_publish,
+                               void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_apply")) return rc;
     return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, grad_scale,
-                       d->tau, nullptr, (int)SIN, (hipStream_t)stream);
+                       d->tau, nullptr, (int)SIN, d_publish, (hipStream_t)stream);
+}
+
+int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)
+{
+    return shems_ddpg_actor_apply_pub(d, eta, bp1, bp2, grad_scale, nullptr, stream);
 }
 
 int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed, float *d_s_min, float *d_s_max,

@@ -65,6 +65,10 @@ def _declare():
     PD = C.POINTER(DdpgArgs)
     L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
     L.shems_ddpg_critic_grad.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, vp]
+    L.shems_ddpg_critic_grad_ex.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, vp]
+    L.shems_ddpg_critic_grad_ex.restype = C.c_int
+    L.shems_ddpg_actor_apply_pub.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
+    L.shems_ddpg_actor_apply_pub.restype = C.c_int
     L.shems_ddpg_critic_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_actor_grad.argtypes = [PD, vp]
     L.shems_ddpg_actor_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
@@ -224,20 +228,24 @@ class Agent:
     def _allreduce(self, g):
         self.sync.sum_(g)                          # sum over replicas; the 1/world is folded into ADAM's grad_scale
 
-    def replay(self, ring, tick=None):
-        """replay(; rng_rpl) (DDPG.jl:121-145): one DDPG update from `ring`."""
+    def replay(self, ring, tick=None, exclude=None, publish=None):
+        """replay(; rng_rpl) (DDPG.jl:121-145): one DDPG update from `ring`.  exclude = (pos, count): ring slots another
+        stream is writing right now (pipelined mode); publish = tensor that also receives the updated actor."""
         d = self._ddpg_args()
         st = self._stream()
         rs = ring.struct()
         tick = self.updates if tick is None else tick
-        _capi.check(self.L.shems_ddpg_critic_grad(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF, st))
+        ex_pos, ex_cnt = (0, 0) if exclude is None else (int(exclude[0]) % ring.capacity, int(exclude[1]))
+        _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF,
+                                                     ex_pos, ex_cnt, st))
         self._allreduce(self.grad_critic)
         gs = self.sync.grad_scale
         _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
         self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
         _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
         self._allreduce(self.grad_actor)
-        _capi.check(self.L.shems_ddpg_actor_apply(C.byref(d), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs, st))
+        _capi.check(self.L.shems_ddpg_actor_apply_pub(C.byref(d), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs,
+                                                      C.c_void_p(publish.data_ptr()) if publish is not None else None, st))
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
@@ -340,8 +348,9 @@ class TrainWorkload:
     dtype = "f32"
     EP_LEN = EP_LENGTH_TRAIN
 
-    def __init__(self, S, torch, n, seed, updates=1, dist=None):
+    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False):
         self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
+        self.overlap = bool(overlap)
         self.tab = S.tables.synthetic_table("train", 98)
         self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
                                 device=torch.cuda.current_device()).use_torch_stream()
@@ -357,23 +366,59 @@ class TrainWorkload:
         self.t = 0
         self.episode = 1
         self.env.reset_(self.env_seed, episode=self.episode)
+        if self.overlap:
+            # Pipelined mode: replay(t) runs on a second stream while the fused act/step kernel of step t runs on the main
+            # one.  act(t) still uses the actor produced by replay(t-1), exactly as in the sequential loop; the one deviation
+            # is that replay(t) cannot sample the transitions step t is inserting (333 of 24 000 slots are excluded).
+            self.upd_stream = torch.cuda.Stream()
+            self.actor_pub = [self.agent.actor.clone(), self.agent.actor.clone()]
+            self.ev_act = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_upd = [torch.cuda.Event(), torch.cuda.Event()]
+            for e in self.ev_act + self.ev_upd:
+                e.record()
 
-    def _act(self, tick):
+    def _act(self, tick, actor=None):
         w = RingWindow(self.ring.pos, self.win, (tick * self.win) % self.n)
-        self.agent.act_step(self.env, train=True, tick=tick, rewards_f32=self.rew32, ring=self.ring, window=w)
+        if actor is None:
+            self.agent.act_step(self.env, train=True, tick=tick, rewards_f32=self.rew32, ring=self.ring, window=w)
+        else:
+            v = self.env.view()
+            p = self.agent._act_params(True, tick, actor=actor)
+            rs = self.ring.struct()
+            _capi.check(self.agent.L.shems_act_step_dev(C.byref(v), C.byref(p), None, None, C.c_void_p(self.rew32.data_ptr()), None,
+                                                        None, C.byref(rs), C.byref(w), self.agent._stream()))
         self.ring.pushed += self.win
 
     def step(self):
+        torch = self.torch
         if self.t and self.t % self.EP_LEN == 0:
             self.episode += 1
             v = self.env.view()
             _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, self.episode, self.env._stream()))
-        self._act(self.t)
-        for _ in range(self.updates):
-            self.agent.replay(self.ring)
+        if not self.overlap:
+            self._act(self.t)
+            for _ in range(self.updates):
+                self.agent.replay(self.ring)
+            self.t += 1
+            return
+        t = self.t
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ev_upd[(t - 1) & 1])                  # actor_pub[t & 1] was published by replay(t - 1)
+        win_pos = self.ring.pos
+        self._act(t, actor=self.actor_pub[t & 1])
+        self.ev_act[t & 1].record(main)
+        self.upd_stream.wait_event(self.ev_act[(t - 1) & 1])       # ring complete through step t-1; actor_pub[(t+1)&1] no longer read
+        with torch.cuda.stream(self.upd_stream):
+            for u in range(self.updates):
+                self.agent.replay(self.ring, exclude=(win_pos, self.win),
+                                  publish=self.actor_pub[(t + 1) & 1] if u == self.updates - 1 else None)
+            self.ev_upd[t & 1].record(self.upd_stream)
         self.t += 1
 
     def finish(self):
+        if self.overlap:
+            self.torch.cuda.current_stream().wait_stream(self.upd_stream)
+            self.torch.cuda.synchronize()
         self.env.check_error()
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
             raise RuntimeError("non-finite network parameters after the timed steps")
@@ -409,7 +454,7 @@ class TrainWorkload:
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
 
     def extra(self):
-        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE,
+        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "overlap": self.overlap,
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8}
 

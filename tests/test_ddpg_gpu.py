@@ -155,3 +155,21 @@ def test_min_max_buffer_bootstrap():
     assert (ag.s_min.cpu().numpy() == h["s"][idx].min(0)).all()
     assert (ag.s_max.cpu().numpy() == h["s"][idx].max(0)).all()
     assert len(np.unique(idx)) < 5000           # with replacement
+
+
+def test_pipelined_replay_excludes_the_window_being_written_and_publishes_the_actor():
+    torch, S, D, ag, ring, h = _setup(seed=21)
+    pub = torch.zeros_like(ag.actor)
+    pos, cnt = 23900, 333                         # wraps around the end of the ring
+    seen = set()
+    for t in range(40):
+        ag.replay(ring, tick=t, exclude=(pos, cnt), publish=pub)
+        idx = ag.ws[30 * 128:31 * 128].cpu().numpy().view(np.int32)[:120]      # WS_IDX
+        assert ((idx >= 0) & (idx < 24000)).all()
+        rel = (idx - pos) % 24000
+        assert (rel >= cnt).all(), "sampled a slot inside the excluded window"
+        seen.update(idx.tolist())
+        assert torch.equal(pub, ag.actor)
+    assert len(seen) > 3000
+    with pytest.raises(S.ShemsError):
+        ag.replay(ring, tick=0, exclude=(0, 24000))
