@@ -439,15 +439,20 @@ class TrainWorkload:
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in ev)
         avg = sum(ms) / len(ms)
-        # one replay() alone, for the updates/sec breakdown
+        # one replay() alone, for the updates/sec breakdown.  This pass runs on rank 0 only: no collective may be issued
+        # here (the other ranks are not in this code), so the gradient exchange is switched off for its duration.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         nup = 50
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(nup):
-            self.agent.replay(self.ring)
-        e1.record()
-        torch.cuda.synchronize()
+        saved_sync, self.agent.sync = self.agent.sync, GradSync(None)
+        try:
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(nup):
+                self.agent.replay(self.ring)
+            e1.record()
+            torch.cuda.synchronize()
+        finally:
+            self.agent.sync = saved_sync
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
         return dict(kernel="shems::k_act<TM>", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
