@@ -1,0 +1,41 @@
+"""bench.py contract on the GPU box: the JSON line, and a 2-rank rehearsal of the data-parallel flow (both ranks on the one
+GPU, gloo instead of RCCL) so that a rank-0-only collective or a mismatched collective count shows up as a hang here and not
+on the 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, env=None, timeout=420):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=U.ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_json_contract_small():
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["warmup"] == 4 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["mode"] == "train" and d["config"]["envs_per_gpu"] == 8192 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 1e6 and d["updates_per_sec"] > 100
+
+
+def test_two_rank_data_parallel_rehearsal():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "4096"],
+             env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["value"] > 0
