@@ -213,8 +213,11 @@ struct FwdJob {
 };
 struct FwdArgs { FwdJob job[3]; };
 
-constexpr int FWD_KC = 126;                                   // k rows per phase (63 MFMA pairs), 2 phases
-constexpr int FWD_LDS = (128 * BP + 128 * 32 + W1K * BP + W1K * W1C + 96) * 4;
+// Workgroup = one 32-wide n-tile x one 64-column half of the batch; its 4 waves split the work as (m-tile, K-half):
+// wave w computes columns [64*mh + 32*(w&1), +32) over hidden units [128*(w>>1), +128) (125 real rows + zero pad), so the two
+// K halves run concurrently on different SIMDs; the upper pair's accumulators are added through LDS at the end.
+constexpr int FWD_KH = 128;                                   // k rows per K-half (64 MFMA pairs; rows 250..255 are zero)
+constexpr int FWD_LDS = (4 * FWD_KH * 32 + 2 * FWD_KH * 32 + W1K * BP + W1K * W1C + 96) * 4;
 
 #ifdef ABL_STAMP
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { stamps[2*(i)] = __builtin_amdgcn_s_memtime(); stamps[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
@@ -228,13 +231,14 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(const_cast<float *>(J.P3) + 100000);   // unused part of the slot
 #endif
     STAMP(0);
-    float *Hc = smem;                          // [128][BP]  relu(layer 1) rows of the current phase
-    float *Wc = Hc + 128 * BP;                 // [128][32]  W2 panel of the current phase
-    float *xs = Wc + 128 * 32;                 // [12][BP]
+    float *Hc = smem;                          // [4 waves][128][32]  relu(layer 1): this wave's K-half x its 32 columns
+    float *Wc = Hc + 4 * FWD_KH * 32;          // [2 K-halves][128][32]  W2 panel (rows >= 250: zero)
+    float *xs = Wc + 2 * FWD_KH * 32;          // [12][BP]
     float *w1 = xs + W1K * BP;                 // w1m [12][256]
     float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.x * 32;
+    const int n0 = (blockIdx.x >> 1) * 32, mh = blockIdx.x & 1;
+    const int kh = wave >> 1, mbase = 64 * mh + 32 * (wave & 1);
     const float *__restrict__ P = J.P;
 
     float epv = 0.0f;
@@ -243,67 +247,84 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
         epv = c == 0 ? P[off_b2(IN) + nc] : P[off_w3(IN) + nc * J.out + min(c - 1, J.out - 1)];
         if (n0 + nl >= H2N || c - 1 >= J.out) epv = 0.0f;
     }
+    // W2[0..255][n0..n0+31] (rows of 128 B, 8 float4 each): 2048 float4, 8 per thread, all issued before the first store.
+    // Columns >= 500 of the last tile read the next row / b2 (in bounds) and only feed output rows that are discarded.
+    const float *__restrict__ W2 = P + off_w2(IN);
+    float4 wv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid, k = e >> 3, c = e & 7;
+        const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c);
+        wv[it] = k < H1N ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     build_x<IN>(J.x, xs, blockIdx.x == 0);
     stage_w1m(J.w1t, w1);
     if (tid < 96) ep[tid] = epv;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) reinterpret_cast<float4 *>(Wc)[it * 256 + tid] = wv[it];
     __syncthreads();
     STAMP(1);
 
+    // layer 1 on the matrix pipe: 4 tiles (128 rows of this K-half) x this wave's 32 columns; the four accumulator chains
+    // are independent, so their MFMAs interleave
+    float *Hw = Hc + wave * (FWD_KH * 32);
+    {
+        f32x16 t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[q][r] = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < W1K / 2; ++sidx) {
+            const int j = 2 * sidx + lh;
+            const float xb = xs[j * BP + mbase + li];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j * W1C + FWD_KH * kh + 32 * q + li], xb, t[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Hw[(32 * q + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = fmaxf(t[q][r], 0.0f);
+    }
+    STAMP(2);
+    // this wave reads only its own Hw columns: no barrier needed between the layer-1 writes and the main loop
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const float *__restrict__ W2 = P + off_w2(IN);
-    const int mbase = wave * 32;
-#pragma unroll 1
-    for (int ph = 0; ph < 2; ++ph) {
-        const int k0 = ph * FWD_KC, kn = ph == 0 ? FWD_KC : H1N - FWD_KC;      // 126 + 124 rows
-        // W2[k0..][n0..n0+31] (rows of 128 B, 8 float4 each): all loads issued before the first store.  Columns >= 500 of the
-        // last tile read the next row / b2 (in bounds) and only feed output rows that are discarded.
-        float4 wv[4];
+    {
+        // 64 MFMA pairs over this K-half, operand fetch software-pipelined one group (8 pairs) ahead
+        const float *pa = Wc + kh * (FWD_KH * 32) + li, *pb = Hw + li;
+        float ac[8], bc[8], an[8], bn[8];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = it * 256 + tid, kl = e >> 3, c = e & 7;
-            const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)(k0 + min(kl, kn - 1)) * H2N + n0 + 4 * c);
-            wv[it] = kl < kn ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        STAMP(2 + 5 * ph);
-        // layer 1 on the matrix pipe: this wave's 32 columns x 128 rows (rows past 249 come out as relu(0) = 0)
+        for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 32]; bc[u] = pb[(2 * u + lh) * 32]; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x16 t = l1_tile(w1, xs, k0 + 32 * q, mbase, li, lh);
+        for (int g = 0; g < 8; ++g) {
+            if (g < 7) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Hc[(32 * q + (r & 3) + 8 * (r >> 2) + 4 * lh) * BP + mbase + li] = fmaxf(t[r], 0.0f);
-        }
-        STAMP(3 + 5 * ph);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) reinterpret_cast<float4 *>(Wc)[it * 256 + tid] = wv[it];
-        __syncthreads();
-        STAMP(4 + 5 * ph);
-        // 63 MFMA pairs, operand fetch software-pipelined one group (9 pairs) ahead.  In the second phase the last pair
-        // multiplies the zero rows 124/125 of Wc.
-        const float *pa = Wc + li, *pb = Hc + mbase + li;
-        float ac[9], bc[9], an[9], bn[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) { ac[u] = pa[(2 * u + lh) * 32]; bc[u] = pb[(2 * u + lh) * BP]; }
-#pragma unroll
-        for (int g = 0; g < 7; ++g) {
-            if (g < 6) {
-#pragma unroll
-                for (int u = 0; u < 9; ++u) {
-                    const int kk = 2 * ((g + 1) * 9 + u) + lh;
-                    an[u] = pa[kk * 32]; bn[u] = pb[kk * BP];
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = 2 * ((g + 1) * 8 + u) + lh;
+                    an[u] = pa[kk * 32]; bn[u] = pb[kk * 32];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 9; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 9; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+            for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
         }
-        STAMP(5 + 5 * ph);
-        __syncthreads();
-        STAMP(6 + 5 * ph);
     }
+    STAMP(3);
+    // add the two K halves: waves 2,3 hand their accumulators to waves 0,1 through LDS (Hc is free once everybody is here)
+    __syncthreads();
+    float *xch = Hc + (wave & 1) * (16 * 64);
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += xch[r * 64 + lane];
     // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
     const int m = mbase + li;
     float p0 = 0.0f, p1 = 0.0f;
@@ -318,8 +339,8 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
     p0 += __shfl_xor(p0, 32, 64);
     p1 += __shfl_xor(p1, 32, 64);
     if (lh == 0) {
-        J.P3[(blockIdx.x * 2 + 0) * BP + m] = p0;
-        J.P3[(blockIdx.x * 2 + 1) * BP + m] = p1;
+        J.P3[((blockIdx.x >> 1) * 2 + 0) * BP + m] = p0;
+        J.P3[((blockIdx.x >> 1) * 2 + 1) * BP + m] = p1;
     }
     STAMP(12);
 }
@@ -474,15 +495,14 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 
     if (is_w) {
         const int nbase = nq * 128;
-        // D2^T panel Bt[m][nl], nl = 2*it + half: 64 rows per thread, H2 loads issued 32 at a time (W3 comes from LDS)
-#pragma unroll 1
-        for (int blk = 0; blk < 2; ++blk) {
-            float hv[32];
+        // D2^T panel Bt[m][nl], nl = 2*it + half: 64 rows per thread, all 64 H2 loads in flight at once (W3 comes from LDS)
+        {
+            float hv[64];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) hv[u] = A.H2[min(nbase + 2 * (blk * 32 + u) + half, H2N - 1) * BP + mcol];
+            for (int u = 0; u < 64; ++u) hv[u] = A.H2[min(nbase + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int nl = 2 * (blk * 32 + u) + half, n = nbase + nl;       // rows >= 500: W3 image is zero there
+            for (int u = 0; u < 64; ++u) {
+                const int nl = 2 * u + half, n = nbase + nl;                    // rows >= 500: W3 image is zero there
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
                 Bt[mcol * 129 + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
             }
@@ -495,10 +515,24 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         }
         __syncthreads();
         const float *pa = At + li, *pb = Bt + wave * 32 + li;
-#pragma unroll 8
-        for (int s = 0; s < BP / 2; ++s) {
-            const int mm = 2 * s + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[mm * 33], pb[mm * 129], acc, 0, 0, 0);
+        {   // 64 MFMA pairs, operand fetch software-pipelined one group (8 pairs) ahead
+            float ac[8], bc[8], an[8], bn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * 129]; }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < 7) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int mm = 2 * ((g + 1) * 8 + u) + lh;
+                        an[u] = pa[mm * 33]; bn[u] = pb[mm * 129];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+            }
         }
         float *gW2 = A.grad + off_w2(IN);
         const int n = nbase + wave * 32 + li;
@@ -536,17 +570,16 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         }
     } else {
         const int nb = nq * NQW;                // 125 n, padded with one zero row to 63 MFMA pairs
-        // D2 panel Bt[nl][m], nl = 2*it + half, it < 63 (row 125 = 0)
-#pragma unroll 1
-        for (int blk = 0; blk < 2; ++blk) {
-            float hv[32];
+        // D2 panel Bt[nl][m], nl = 2*it + half, it < 63 (row 125 = 0): all H2 loads of the thread in flight at once
+        {
+            float hv[63];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) hv[u] = A.H2[(nb + min(2 * (blk * 32 + u) + half, NQW - 1)) * BP + mcol];
+            for (int u = 0; u < 63; ++u) hv[u] = A.H2[(nb + min(2 * u + half, NQW - 1)) * BP + mcol];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int nl = 2 * (blk * 32 + u) + half;
+            for (int u = 0; u < 63; ++u) {
+                const int nl = 2 * u + half;
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * (nb + min(nl, NQW - 1)));
-                if (nl < 126) Bt[nl * BP + mcol] = nl < NQW ? d2_val(hv[u], 2, w.x, w.y, d3a, d3b) : 0.0f;
+                Bt[nl * BP + mcol] = nl < NQW ? d2_val(hv[u], 2, w.x, w.y, d3a, d3b) : 0.0f;
             }
         }
         // W2 panel At[kl][nl] (row stride 127): 32 x 126 elements, 16 loads in flight per thread
@@ -567,10 +600,24 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         }
         __syncthreads();
         const float *pa = At + li * 127, *pb = Bt + wave * 32 + li;
-#pragma unroll 9
-        for (int s = 0; s < 63; ++s) {
-            const int nn = 2 * s + lh;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[nn], pb[nn * BP], acc, 0, 0, 0);
+        {   // 63 MFMA pairs (7 groups of 9), operand fetch one group ahead
+            float ac[9], bc[9], an[9], bn[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { ac[u] = pa[2 * u + lh]; bc[u] = pb[(2 * u + lh) * BP]; }
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                if (g < 6) {
+#pragma unroll
+                    for (int u = 0; u < 9; ++u) {
+                        const int nn = 2 * ((g + 1) * 9 + u) + lh;
+                        an[u] = pa[nn]; bn[u] = pb[nn * BP];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 9; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 9; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+            }
         }
         const int m = wave * 32 + li;
         float *D1 = A.D1P + (int64_t)nq * H1N * BP;
@@ -781,11 +828,11 @@ int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
     f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1), dim3(256), FWD_LDS, st, f);
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
     f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
     f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(NT, 3), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 3), dim3(256), FWD_LDS, st, f);
     float *S = slot(ws, SLOT_CRITIC);
     const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d};
     hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG), dim3(256), BWD_LDS, st, b);
@@ -822,7 +869,7 @@ int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(NT, 1), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1), dim3(256), FWD_LDS, st, f);
     const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d};
     hipLaunchKernelGGL(k_bwd, dim3(KT * NQ), dim3(256), BWD_LDS, st, bi);
     float *S = slot(ws, SLOT_ACTOR);
