@@ -83,7 +83,7 @@ __device__ __forceinline__ void slab_store(const float *lds, float *g, int64_t b
 }
 
 // Sum of `x` over the workgroup (wavefront butterfly, then 4 partials through LDS).
-__device__ __forceinline__ double block_sum(double x, double *lds4)
+__device__ __forceinline__ double block_sum(double x, double *lds4, int nwaves = 4)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -91,7 +91,10 @@ __device__ __forceinline__ double block_sum(double x, double *lds4)
     if (lane == 0) lds4[w] = x;
     __syncthreads();
     double s = 0.0;
-    if (threadIdx.x == 0) s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+    if (threadIdx.x == 0) {
+        s = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+        for (int w = 4; w < nwaves; ++w) s += lds4[w];
+    }
     return s;
 }
 

@@ -28,6 +28,7 @@
 // LDS: 2 x 32 KB (W2 chunks) + 2 x 32*BM*4 (layer-1 groups) + x (12*BM*4) + layer-1 image 12 KB + b2/W3/b3 6 KB.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "shems_env_dev.h"
@@ -64,11 +65,11 @@ struct ActArgs {
     int use_ring;
 };
 
-template <int TM>
+template <int TM, int NW>
 constexpr size_t act_lds_bytes()
 {
     return sizeof(float) * (2 * kWcFloats + 2 * 32 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
-                            4 * 32 * TM * kOut);
+                            NW * 32 * TM * kOut);
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -94,17 +95,17 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
 // [2*TM MFMAs] [DS reads of the NEXT k-step] [2*TM MFMAs] [one LDS-DMA piece]: the operand fetch sits in the middle of an
 // MFMA group, half a group (~500 cycles) ahead of its first use.  ds_read2_b32 fetches two operands, so a k-step is
 // 2 + ceil(TM/2) DS instructions.
-template <int TM, bool DMA, int NKS>
+template <int TM, int NA, bool DMA, int NKS>
 __device__ __forceinline__ void sched_chunk()
 {
-    constexpr int DS = 2 + (TM + 1) / 2;
+    constexpr int DS = (NA + 1) / 2 + (TM + 1) / 2;
     __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 2, 0);
         if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
-        if (DMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NA * TM - NA * TM / 2, 0);
+        if (DMA && (NA == 4 || (ks & 1) == 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 }
 
@@ -113,9 +114,11 @@ __device__ __forceinline__ void sched_chunk()
 #else
 #define PSTAMP(i)
 #endif
-template <int TM>
-__global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
+template <int TM, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 {
+    constexpr int NT_ = 64 * NW;            // threads per workgroup
+    constexpr int NA = 16 / NW;             // 32-wide n-tiles per wave (4 waves: 4, 8 waves: 2)
     PSTAMP(0);
     constexpr int BM = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     const float *__restrict__ P = A.p.actor;
 
     // ---- stage 0: x = normalize(s) -> xT[k][m]; layer-1 image, b2/W3/b3 -> LDS; W2 chunk 0 -> LDS --------------
-    for (int e = tid; e < BM * kIn; e += 256) {
+    for (int e = tid; e < BM * kIn; e += NT_) {
         const int m = e / kIn, k = e - m * kIn;
         const int64_t g = env0 * kIn + e;
         float x = 0.0f;
@@ -143,22 +146,24 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
         }
         xT[k * BM + m] = x;
     }
-    for (int e = tid; e < 3 * BM; e += 256) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
+    for (int e = tid; e < 3 * BM; e += NT_) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
     {   // w1[j][k]: j < 9 -> W1[j][k], j == 11 -> b1[k], else 0; columns 250..255 zero (thread = column k)
         float v[kW1K];
         const int kc = min(tid, kH1 - 1);
 #pragma unroll
         for (int j = 0; j < kW1K; ++j) v[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
+        if (tid < kW1C) {
 #pragma unroll
-        for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? v[j] : 0.0f;
+            for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? v[j] : 0.0f;
+        }
     }
     {   // b2 | W3 | b3 are contiguous in the parameter block (1502 floats): 6 clamped loads in flight per thread
         float v[6];
 #pragma unroll
-        for (int it = 0; it < 6; ++it) v[it] = P[kOffB2 + min(it * 256 + tid, kH2 + kH2 * kOut + kOut - 1)];
+        for (int it = 0; it < 6; ++it) v[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
-            const int e = it * 256 + tid;                      // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
+            const int e = tid < 256 ? it * 256 + tid : 1 << 20;   // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
             if (e < kH2) tl[e] = v[it];
             else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = v[it];
             else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = v[it];
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
                    reinterpret_cast<char *>(Wc + (buf) * kWcFloats) + (pc) * 1024);               \
     } while (0)
 #define W2_ISSUE(chunk, buf)                                                                      \
-    do { _Pragma("unroll") for (int pc_ = wave; pc_ < 32; pc_ += 4) W2_PIECE(chunk, buf, pc_); } while (0)
+    do { _Pragma("unroll") for (int pc_ = wave; pc_ < 32; pc_ += NW) W2_PIECE(chunk, buf, pc_); } while (0)
     // Layer 1 on the matrix pipe (K = 12 = 6 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
     // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
 #define L1_GROUP(g)                                                                               \
@@ -210,11 +215,11 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     PSTAMP(2);
 
     // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
-    f32x16 acc[4][TM];
-    const int nbase = wave * 128;
+    f32x16 acc[NA][TM];
+    const int nbase = wave * (32 * NA);
     // the accumulators start at b2[n] (rows >= 500: 0), so the epilogue is relu + two FMAs per element
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bias = tl[nbase + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh];
@@ -233,25 +238,28 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
         if (ODD) L1_GROUP(((c) + 1) >> 1);                                                                      \
         const float *Wb_ = Wc + cur_ * kWcFloats + nbase + li;                                                  \
         const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + li;                     \
-        float af_[2][4], bf_[2][TM];                                                                            \
-        _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[0][a] = Wb_[lh * kH2 + 32 * a];                       \
+        float af_[2][NA], bf_[2][TM];                                                                            \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a) af_[0][a] = Wb_[lh * kH2 + 32 * a];                       \
         _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[0][b] = Hb_[lh * BM + 32 * b];                       \
         _Pragma("unroll") for (int ks = 0; ks < (NKS); ++ks) {                                                  \
             if (ks + 1 < (NKS)) {                                                                               \
                 const int kr_ = 2 * (ks + 1) + lh;                                                              \
-                _Pragma("unroll") for (int a = 0; a < 4; ++a) af_[(ks + 1) & 1][a] = Wb_[kr_ * kH2 + 32 * a];   \
+                _Pragma("unroll") for (int a = 0; a < NA; ++a) af_[(ks + 1) & 1][a] = Wb_[kr_ * kH2 + 32 * a];   \
                 _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[(ks + 1) & 1][b] = Hb_[kr_ * BM + 32 * b];   \
             }                                                                                                   \
-            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                       \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                      \
                 _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                  \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[ks & 1][a], bf_[ks & 1][b], acc[a][b], 0, 0, 0); \
-            if (ISSUE == 0)                                                                                     \
-                glds16(W2g + ((c) + 1) * kChunkBytes + (wave + 4 * ks) * 1024 + lane * 16,                      \
-                       reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + (wave + 4 * ks) * 1024);               \
-            else if (ISSUE == 1)                                                                                \
-                W2_PIECE((c) + 1, nxt_, wave + 4 * ks);                                                         \
+            if (NA == 4 || (ks & 1) == 0) {                                                                     \
+                const int pc_ = NA == 4 ? wave + 4 * ks : wave + 8 * (ks >> 1);                                 \
+                if (ISSUE == 0)                                                                                 \
+                    glds16(W2g + ((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16,                              \
+                           reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                       \
+                else if (ISSUE == 1)                                                                            \
+                    W2_PIECE((c) + 1, nxt_, pc_);                                                               \
+            }                                                                                                   \
         }                                                                                                       \
-        if (ISSUE != 1) sched_chunk<TM, ISSUE == 0, NKS>();                                                     \
+        if (ISSUE != 1) sched_chunk<TM, NA, ISSUE == 0, NKS>();                                                     \
         __syncthreads();                                                                                        \
     } while (0)
 
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     // program order, which bounds VGPR pressure -- left to itself the compiler copies all 64*TM*4 values first).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA D -> v_accvgpr_read hazard (nothing pads asm)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the W3 LDS reads near their rows (VGPR pressure)
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     if (tid < BM && i < A.m) {
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
+        for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
         p0 = tanhf(p0);
         p1 = tanhf(p1);
         float a0, a1;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void k_act(ActArgs A)
     if (A.block_reward) {
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Wc);     // Wc is dead by now
-        const double s = block_sum(reward, red64);
+        const double s = block_sum(reward, red64, NW);
         if (tid == 0) A.block_reward[blockIdx.x] = s;
     }
 #endif
@@ -387,30 +395,31 @@ static int pick_tm(int64_t m)
     return 1;
 }
 
-template <int TM>
+template <int TM, int NW>
 static int launch_act(const ActArgs &a, hipStream_t st)
 {
     constexpr int BM = 32 * TM;
-    const size_t lds = act_lds_bytes<TM>();
+    const size_t lds = act_lds_bytes<TM, NW>();
     static bool attr_done = false;
     if (!attr_done) {
-        if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_act<TM>),
+        if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_act<TM, NW>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                             "hipFuncSetAttribute(k_act)"))
             return rc;
         attr_done = true;
     }
     const unsigned grid = (unsigned)((a.m + BM - 1) / BM);
-    hipLaunchKernelGGL(k_act<TM>, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_act<TM, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hip_ok(hipGetLastError(), "k_act launch");
 }
 
 static int dispatch_act(const ActArgs &a, hipStream_t st)
 {
+    static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     switch (pick_tm(a.m)) {
-    case 4: return launch_act<4>(a, st);
-    case 2: return launch_act<2>(a, st);
-    default: return launch_act<1>(a, st);
+    case 4: return nw == 8 ? launch_act<4, 8>(a, st) : launch_act<4, 4>(a, st);
+    case 2: return launch_act<2, 4>(a, st);
+    default: return launch_act<1, 4>(a, st);
     }
 }
 
