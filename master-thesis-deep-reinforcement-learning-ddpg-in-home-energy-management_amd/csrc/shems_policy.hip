@@ -268,7 +268,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         CHUNK_BODY(2 * cp, 0, false, kKC / 2);
         CHUNK_BODY(2 * cp + 1, 0, true, kKC / 2);
     }
+    PSTAMP(3);
     CHUNK_BODY(kChunks - 2, 1, false, kKC / 2);           // chunk 14 fetches the short last chunk
+    PSTAMP(4);
     CHUNK_BODY(kChunks - 1, 2, false, (kH1 - (kChunks - 1) * kKC) / 2);   // chunk 15: rows 240..249 only = 5 k-steps
     PSTAMP(10);
 

@@ -204,6 +204,7 @@ class Agent:
     def act_step(self, env, train=True, tick=None, a_out=None, rewards=None, rewards_f32=None, block_reward=None,
                  returns_acc=None, ring=None, window=None):
         """One fused vector step: s = env.state; a = act(s); step!(env, s, scale_action(a)); remember(...)."""
+        env.use_torch_stream()
         v = env.view()
         self._ensure_ou(env.n)
         p = self._act_params(train, self.tick if tick is None else tick)

@@ -172,20 +172,26 @@ class ShemsBatch:
 
     # -- device chaining --------------------------------------------------
     def view(self):
+        """Device pointers of this handle (shems_view) for the zero-copy entry points."""
         v = _capi.View()
         _capi.check(self._L.shems_get_view(self._h, C.byref(v)))
         return v
 
     def use_torch_stream(self):
-        """Run the handle's kernels on PyTorch's current HIP stream so they order with tensor ops."""
+        """Run the handle's kernels on PyTorch's current HIP stream so they order with tensor ops and with the policy /
+        DDPG kernels.  Idempotent; every device-chaining method calls it, so mixing the host-array API and the device API
+        on one handle is safe."""
         import torch
-        self.torch_device = torch.device("cuda", torch.cuda.current_device())
-        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        ptr = torch.cuda.current_stream().cuda_stream
+        if getattr(self, "_bound_stream", None) != ptr:
+            self.torch_device = torch.device("cuda", torch.cuda.current_device())
+            self.set_stream(ptr)                      # synchronises the stream used so far, then switches
+            self._bound_stream = ptr
         return self
 
     def _stream(self):
-        import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.use_torch_stream()
+        return C.c_void_p(self._bound_stream)
 
     def rollout(self, policy, nsteps, seed=0, ring=None, ring_envs=0):
         """`nsteps` x { a = policy(env); step! } in one launch (shems_rollout_dev).  policy: "rule"
