@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env"])
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
+    ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -281,7 +282,7 @@ def main():
     if mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
-        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap)
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed)
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
 
@@ -341,7 +342,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.envs} parallel shems_LU1 envs per GPU, Charger98 synthetic train table "
                                    f"(4320 rows), {EP_LEN}-step episodes, mode={mode}",
-                       "envs_per_gpu": args.envs, "episode_len": EP_LEN, "mode": mode},
+                       "envs_per_gpu": args.envs, "episode_len": EP_LEN, "mode": mode, "mixed_profiles": bool(args.mixed)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

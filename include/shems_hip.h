@@ -276,6 +276,17 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
                                float *d_publish, void *stream);
 /* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
 int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
+/* Parameter noise, noise_type "pn" (struct ParamNoise input.jl:210-215; add_perturb! DDPG.jl:89-96;
+ * adapt_param_noise! DDPG.jl:74-87).  The reference adds ONE scalar draw N(mu, sigma_current) to every parameter
+ * array of a copy of the actor (sample_noise(pn, rng) re-seeds before each draw); act() then evaluates the copy
+ * without action noise (pass it as shems_act_params.actor with train = 0), and replay() adapts sigma_current from
+ * the distance between the two actors' outputs on the sampled minibatch.
+ *   perturb:    d_perturbed[i] = d_params[i] + shift, i < n
+ *   batch_obs:  the s rows of the minibatch the last shems_ddpg_critic_grad(_ex) sampled -> d_obs [batch][9]
+ *   distance:   d_out[0] = sqrt(mean((d_a - d_b)^2)) over `count` floats */
+int shems_ddpg_perturb_dev(const float *d_params, float *d_perturbed, int64_t n, float shift, void *stream);
+int shems_ddpg_batch_obs_dev(const shems_ddpg *d, const shems_replay *ring, float *d_obs, void *stream);
+int shems_action_distance_dev(const float *d_a, const float *d_b, int64_t count, float *d_out, void *stream);
 /* min_max_buffer (MPS:50-53): minimum/maximum of s over a bootstrap sample of `count` ring entries. */
 int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed,
                      float *d_s_min, float *d_s_max, void *stream);

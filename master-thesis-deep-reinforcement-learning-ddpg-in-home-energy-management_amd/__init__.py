@@ -8,7 +8,7 @@ or `importlib.import_module("master-thesis-deep-reinforcement-learning-ddpg-in-h
 """
 from . import _capi, tables                     # noqa: F401
 from ._capi import BoundsError, ShemsError      # noqa: F401
-from .env import Shems, ShemsBatch, action, finished, make_config, reset_, step_   # noqa: F401
+from .env import Shems, ShemsBatch, action, finished, make_config, mixed_profile_setup, reset_, step_   # noqa: F401
 
 __all__ = ["Shems", "ShemsBatch", "reset_", "step_", "action", "finished", "make_config", "tables",
            "ShemsError", "BoundsError"]

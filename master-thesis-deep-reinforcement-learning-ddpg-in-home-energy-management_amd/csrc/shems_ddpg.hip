@@ -759,6 +759,37 @@ __global__ __launch_bounds__(1024) void k_minmax(shems_replay ring, int64_t ring
     }
 }
 
+// ---- parameter noise (input.jl:210-215 ParamNoise; DDPG.jl:74-96) -----------------------------------------------
+// add_perturb!: every parameter array of the copy gets the SAME scalar (sample_noise(pn, rng) re-seeds before each draw).
+__global__ __launch_bounds__(256) void k_perturb(const float *__restrict__ src, float *__restrict__ dst, int64_t n, float shift)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] + shift;
+}
+
+// s of the minibatch the last shems_ddpg_critic_grad sampled (ring slots kept in the workspace) -> obs [batch][9]
+__global__ __launch_bounds__(256) void k_batch_obs(shems_replay ring, const float *__restrict__ ws, int batch, float *__restrict__ obs)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch * SIN) return;
+    const int m = t / SIN, k = t - m * SIN;
+    const int64_t j = reinterpret_cast<const int32_t *>(ws + WS_IDX)[m];
+    obs[t] = ring.s[j * SIN + k];
+}
+
+// distance = sqrt(Flux.mse(a, a_perturb)) (DDPG.jl:79): one workgroup, fixed summation order
+__global__ __launch_bounds__(256) void k_action_distance(const float *__restrict__ a, const float *__restrict__ b, int64_t count, float *out)
+{
+    __shared__ float part[4];
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < count; i += 256) { const float d = a[i] - b[i]; acc += d * d; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sqrtf(((part[0] + part[1]) + (part[2] + part[3])) / (float)count);
+}
+
 static int set_lds_attrs()
 {
     static bool done = false;
@@ -891,6 +922,28 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
 int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)
 {
     return shems_ddpg_actor_apply_pub(d, eta, bp1, bp2, grad_scale, nullptr, stream);
+}
+
+int shems_ddpg_perturb_dev(const float *d_params, float *d_perturbed, int64_t n, float shift, void *stream)
+{
+    if (!d_params || !d_perturbed || n < 1) return set_error(SHEMS_ERR_ARG, "shems_ddpg_perturb_dev: bad arguments");
+    hipLaunchKernelGGL(k_perturb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_params, d_perturbed, n, shift);
+    return hip_ok(hipGetLastError(), "k_perturb launch");
+}
+
+int shems_ddpg_batch_obs_dev(const shems_ddpg *d, const shems_replay *ring, float *d_obs, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_batch_obs_dev")) return rc;
+    if (!ring || !ring->s || !d_obs) return set_error(SHEMS_ERR_ARG, "shems_ddpg_batch_obs_dev: bad arguments");
+    hipLaunchKernelGGL(k_batch_obs, dim3((d->batch * SIN + 255) / 256), dim3(256), 0, (hipStream_t)stream, *ring, d->ws, d->batch, d_obs);
+    return hip_ok(hipGetLastError(), "k_batch_obs launch");
+}
+
+int shems_action_distance_dev(const float *d_a, const float *d_b, int64_t count, float *d_out, void *stream)
+{
+    if (!d_a || !d_b || !d_out || count < 1) return set_error(SHEMS_ERR_ARG, "shems_action_distance_dev: bad arguments");
+    hipLaunchKernelGGL(k_action_distance, dim3(1), dim3(256), 0, (hipStream_t)stream, d_a, d_b, count, d_out);
+    return hip_ok(hipGetLastError(), "k_action_distance launch");
 }
 
 int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed, float *d_s_min, float *d_s_max,

@@ -95,6 +95,8 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
 // [2*TM MFMAs] [DS reads of the NEXT k-step] [2*TM MFMAs] [one LDS-DMA piece]: the operand fetch sits in the middle of an
 // MFMA group, half a group (~500 cycles) ahead of its first use.  ds_read2_b32 fetches two operands, so a k-step is
 // 2 + ceil(TM/2) DS instructions.
+constexpr int kDmaKs = 4;   // 4 waves: the 8 LDS-DMA pieces a wave issues per chunk go out in k-steps 0..3 (two each), so the
+                            // last one has half a chunk (~4000 cycles) to land before the barrier that publishes it
 template <int TM, int NA, bool DMA, int NKS>
 __device__ __forceinline__ void sched_chunk()
 {
@@ -104,11 +106,24 @@ __device__ __forceinline__ void sched_chunk()
     for (int ks = 0; ks < NKS; ++ks) {
         __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 2, 0);
         if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
+        if (DMA && NA == 4 && ks < kDmaKs) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NA * TM - NA * TM / 2, 0);
-        if (DMA && (NA == 4 || (ks & 1) == 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (DMA && ((NA == 4 && ks < kDmaKs) || (NA != 4 && (ks & 1) == 0))) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 }
 
+#ifndef ABL_NOL1
+#define ABL_NOL1 0
+#endif
+#ifndef ABL_NODMA
+#define ABL_NODMA 0
+#endif
+#ifndef ABL_NOBAR
+#define ABL_NOBAR 0
+#endif
+#ifndef ABL_NOSCHED
+#define ABL_NOSCHED 0
+#endif
 #ifdef ABL_STAMP
 #define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: LDS-DMA bases (M0) stay on the SALU
     const int li = lane & 31, lh = lane >> 5;
     const int64_t env0 = (int64_t)blockIdx.x * BM;
     const float *__restrict__ P = A.p.actor;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // W2 chunk staging, global -> LDS directly (global_load_lds_dwordx4: no staging registers).  A chunk is 16 rows =
     // 32000 contiguous bytes = 31 full 1-KiB wave pieces + one of 256 B (16 lanes); wave w issues pieces w, w+4, ...
     // The LDS image is the linear copy (destination = M0 base + lane*16).  The last chunk holds only rows 240..249
-    // (20000 B): its rows 10..15 keep stale (finite) weights, which meet the all-zero rows 250..255 of layer 1.
+    // (20000 B): its rows 10..15 receive clamped-source filler that is never read (the last chunk runs 5 k-steps).
     const char *W2g = reinterpret_cast<const char *>(P + kOffW2);
     constexpr int kChunkBytes = kKC * kH2 * 4;
     constexpr int kTotalBytes = kH1 * kH2 * 4;
@@ -231,11 +246,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // k-step ks issue (register double buffer; sched_group_barrier pins that order -- left alone the compiler sinks each
     // ds_read to just before its first use and the wave, alone on its SIMD, eats the LDS latency 16 times per chunk).
     // ISSUE: 0 = the next chunk is a whole 32-piece chunk (branch-free LDS-DMA, one piece per k-step), 1 = the next chunk is
-    // the last one (rows 240..249 only, guarded), 2 = nothing to fetch.  ODD: this chunk also produces the next layer-1 group.
+    // the last one (rows 240..249 only: source addresses clamped to the end of W2, still branch-free), 2 = nothing to fetch.  ODD: this chunk also produces the next layer-1 group.
 #define CHUNK_BODY(c, ISSUE, ODD, NKS)                                                                             \
     do {                                                                                                        \
         const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
-        if (ODD) L1_GROUP(((c) + 1) >> 1);                                                                      \
+        if (ODD && !ABL_NOL1) L1_GROUP(((c) + 1) >> 1);                                                         \
         const float *Wb_ = Wc + cur_ * kWcFloats + nbase + li;                                                  \
         const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + li;                     \
         float af_[2][NA], bf_[2][TM];                                                                            \
@@ -250,17 +265,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                      \
                 _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                  \
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[ks & 1][a], bf_[ks & 1][b], acc[a][b], 0, 0, 0); \
-            if (NA == 4 || (ks & 1) == 0) {                                                                     \
-                const int pc_ = NA == 4 ? wave + 4 * ks : wave + 8 * (ks >> 1);                                 \
-                if (ISSUE == 0)                                                                                 \
-                    glds16(W2g + ((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16,                              \
-                           reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                       \
-                else if (ISSUE == 1)                                                                            \
-                    W2_PIECE((c) + 1, nxt_, pc_);                                                               \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                  \
+                if (NA == 4 ? ks < kDmaKs : ((ks & 1) == 0 && h_ == 0)) {                                       \
+                    const int pc_ = NA == 4 ? wave + 4 * (2 * ks + h_) : wave + 8 * (ks >> 1);                  \
+                    if (ISSUE == 0 && !ABL_NODMA)                                                               \
+                        glds16(W2g + ((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16,                          \
+                               reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                   \
+                    else if (ISSUE == 1 && !ABL_NODMA)   /* short last chunk: source clamped to the end of W2 */ \
+                        glds16(W2g + min(((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16, kTotalBytes - 16),   \
+                               reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                   \
+                }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
-        if (ISSUE != 1) sched_chunk<TM, NA, ISSUE == 0, NKS>();                                                     \
-        __syncthreads();                                                                                        \
+        if (!ABL_NOSCHED) sched_chunk<TM, NA, ISSUE != 2 && !ABL_NODMA, NKS>();                   \
+        if (!ABL_NOBAR) __syncthreads();                                                                        \
     } while (0)
 
 #pragma unroll 1

@@ -37,7 +37,8 @@ class ActParams(C.Structure):          # shems_act_params
                 ("ou_dt", C.c_float), ("eps", C.c_float), ("ou_state", C.c_void_p)]
 
 
-NOISE_KINDS = {"gn": 0, "ou": 1, "en": 2}       # noise_type strings of the reference (DDPG.jl:152-161)
+NOISE_KINDS = {"gn": 0, "ou": 1, "en": 2, "pn": 0}   # noise_type strings of the reference (DDPG.jl:152-161); "pn" runs the perturbed actor with train = 0
+NOISE_ACT = 0.1                                  # noise_act, input.jl:231 (ParamNoise.sigma_target)
 
 
 class DdpgArgs(C.Structure):           # shems_ddpg
@@ -74,6 +75,11 @@ def _declare():
     L.shems_ddpg_actor_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_sample_indices.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, i64, vp]
     L.shems_minmax_dev.argtypes = [C.POINTER(_capi.Replay), i64, i64, C.c_uint64, vp, vp, vp]
+    L.shems_ddpg_perturb_dev.argtypes = [vp, vp, i64, C.c_float, vp]
+    L.shems_ddpg_batch_obs_dev.argtypes = [PD, C.POINTER(_capi.Replay), vp, vp]
+    L.shems_action_distance_dev.argtypes = [vp, vp, i64, vp, vp]
+    for fn in ("shems_ddpg_perturb_dev", "shems_ddpg_batch_obs_dev", "shems_action_distance_dev"):
+        getattr(L, fn).restype = C.c_int
     for fn in ("shems_ddpg_workspace_floats", "shems_ddpg_critic_grad", "shems_ddpg_critic_apply", "shems_ddpg_actor_grad",
                "shems_ddpg_actor_apply", "shems_ddpg_sample_indices", "shems_minmax_dev"):
         getattr(L, fn).restype = C.c_int
@@ -96,6 +102,17 @@ def _philox(c0, c1, c2, c3, k0, k1):
 
 
 _STREAM_INIT = 0x494E4954
+_STREAM_PERTURB = 0x50455254
+
+
+def perturb_shift(seed, tick, mu, sigma):
+    """sample_noise(pn, rng) (DDPG.jl:63-67): one scalar Normal(mu, sigma_current) draw per (seed, tick), Float32.
+    Box-Muller on two Philox words (stream PERT); the reference's Random.seed!(rng) stream is Julia-only."""
+    x = _philox(int(tick) & 0xFFFFFFFF, 0, 0, _STREAM_PERTURB, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = (float(x[0] >> np.uint32(8)) + 0.5) / 16777216.0
+    u2 = (float(x[1] >> np.uint32(8)) + 0.5) / 16777216.0
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return float(f32(mu + sigma * z))
 
 
 def init_params(seed, in_dim, out_dim, which):
@@ -130,6 +147,9 @@ class Agent:
         self.sigma, self.mu = float(sigma), float(mu)
         self.noise_type, self.theta, self.dt, self.eps = noise_type, float(theta), float(dt), float(eps)
         self.ou_state = None                      # OUNoise.X per env, allocated on first use
+        # pn = ParamNoise(mu, sigma, noise_act, 1.01), input.jl:237
+        self.pn_sigma, self.pn_target, self.pn_adoption, self.pn_shift = float(f32(sigma)), NOISE_ACT, 1.01, 0.0
+        self.actor_perturb = None                  # actor_perturb = deepcopy(actor), DDPG.jl:39
         a = init_params(self.seed, STATE, ACTION, 0)
         c = init_params(self.seed, STATE + ACTION, 1, 1)
         assert a.size == N_ACTOR and c.size == N_CRITIC
@@ -186,7 +206,45 @@ class Agent:
         if self.noise_type == "ou" and (self.ou_state is None or self.ou_state.shape[0] != n):
             self.ou_state = self.torch.zeros((n, ACTION), dtype=self.torch.float32, device=self.device)   # X = zeros(Float32, 2)
 
-    def act(self, obs, train=True, tick=None, out=None):
+    def add_perturb_(self, rng):
+        """add_perturb!(rng) (DDPG.jl:89-96): actor_perturb = actor .+ one scalar N(mu, sigma_current) draw."""
+        if self.actor_perturb is None:
+            self.actor_perturb = self.torch.empty_like(self.actor)
+        self.pn_shift = perturb_shift(self.rng_seed, rng, self.mu, self.pn_sigma)
+        _capi.check(self.L.shems_ddpg_perturb_dev(C.c_void_p(self.actor.data_ptr()), C.c_void_p(self.actor_perturb.data_ptr()),
+                                                  N_ACTOR, self.pn_shift, self._stream()))
+        return self.actor_perturb
+
+    def adapt_param_noise_(self, ring, rng):
+        """adapt_param_noise!(s_norm, rng_rpl) (DDPG.jl:74-87) on the minibatch the running replay() sampled: sigma_current
+        shrinks / grows by `adoption` when the perturbed actor's actions are farther / nearer than sigma_target."""
+        t = self.torch
+        d = self._ddpg_args()
+        rs = ring.struct()
+        st = self._stream()
+        obs = t.empty((self.batch, STATE), dtype=t.float32, device=self.device)
+        _capi.check(self.L.shems_ddpg_batch_obs_dev(C.byref(d), C.byref(rs), C.c_void_p(obs.data_ptr()), st))
+        a = self.act(obs, train=False)
+        self.add_perturb_(rng)
+        a_p = self.act(obs, train=False, actor=self.actor_perturb)
+        dist = t.empty(1, dtype=t.float32, device=self.device)
+        _capi.check(self.L.shems_action_distance_dev(C.c_void_p(a.data_ptr()), C.c_void_p(a_p.data_ptr()), a.numel(),
+                                                     C.c_void_p(dist.data_ptr()), st))
+        distance = float(dist.item())
+        if distance > self.pn_target:
+            self.pn_sigma /= self.pn_adoption
+        else:
+            self.pn_sigma *= self.pn_adoption
+        return distance
+
+    def _explore(self, train, tick):
+        """(train flag, actor block) the policy kernel runs with: "pn" evaluates the freshly perturbed copy without action
+        noise (DDPG.jl:152-156), every other noise type the actor itself."""
+        if train and self.noise_type == "pn":
+            return False, self.add_perturb_(tick)
+        return train, None
+
+    def act(self, obs, train=True, tick=None, out=None, actor=None):
         """act(normalize(s); train): obs [M][9] cuda float32 -> a [M][2] in [-1, 1] (unscaled)."""
         t = self.torch
         if isinstance(obs, tuple):                       # (device pointer, rows): e.g. the env handle's resident observations
@@ -196,7 +254,10 @@ class Agent:
         if out is None:
             out = t.empty((m, ACTION), dtype=t.float32, device=self.device)
         self._ensure_ou(m)
-        p = self._act_params(train, self.tick if tick is None else tick)
+        tick = self.tick if tick is None else tick
+        if actor is None:
+            train, actor = self._explore(train, tick)
+        p = self._act_params(train, tick, actor)
         _capi.check(self.L.shems_actor_forward_dev(C.byref(p), C.c_void_p(ptr), m,
                                                    C.c_void_p(out.data_ptr()), self._stream()))
         return out
@@ -207,7 +268,9 @@ class Agent:
         env.use_torch_stream()
         v = env.view()
         self._ensure_ou(env.n)
-        p = self._act_params(train, self.tick if tick is None else tick)
+        tick = self.tick if tick is None else tick
+        train, actor = self._explore(train, tick)
+        p = self._act_params(train, tick, actor)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         rs = ring.struct() if ring is not None else None
         _capi.check(self.L.shems_act_step_dev(C.byref(v), C.byref(p), ptr(a_out), ptr(rewards), ptr(rewards_f32),
@@ -239,6 +302,8 @@ class Agent:
         ex_pos, ex_cnt = (0, 0) if exclude is None else (int(exclude[0]) % ring.capacity, int(exclude[1]))
         _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF,
                                                      ex_pos, ex_cnt, st))
+        if self.noise_type == "pn":                # DDPG.jl:126-128 (the actor is still the pre-update one here)
+            self.adapt_param_noise_(ring, tick)
         self._allreduce(self.grad_critic)
         gs = self.sync.grad_scale
         _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
@@ -349,12 +414,16 @@ class TrainWorkload:
     dtype = "f32"
     EP_LEN = EP_LENGTH_TRAIN
 
-    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False):
+    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False):
         self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
         self.overlap = bool(overlap)
-        self.tab = S.tables.synthetic_table("train", 98)
-        self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
-                                device=torch.cuda.current_device()).use_torch_stream()
+        if mixed:                                            # BASELINE config 5: 10 profiles x discomfort-weight sweep
+            tabs, cfgs, co = S.mixed_profile_setup(self.n)
+            self.env = S.ShemsBatch(self.n, self.EP_LEN, tabs, cfgs, co, device=torch.cuda.current_device()).use_torch_stream()
+        else:
+            self.tab = S.tables.synthetic_table("train", 98)
+            self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
+                                    device=torch.cuda.current_device()).use_torch_stream()
         self.env_seed = int(seed)
         self.agent = Agent(seed=1231, rng_seed=self.env_seed)   # same initial weights on every rank (config: seed 1231)
         if dist is not None:

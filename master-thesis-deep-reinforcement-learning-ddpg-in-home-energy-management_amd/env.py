@@ -38,6 +38,17 @@ def make_config(charger_id=98, table_row0=0, nrow=0, disc_weight=0.01, disc_pot=
                   float(f32(penalty_weight)), int(table_row0), int(nrow), 0)
 
 
+def mixed_profile_setup(n_envs, charger_ids=(1, 2, 3, 4, 5, 6, 7, 8, 9, 98), sweep=((0.01, 2.0), (0.04, 2.0), (0.1, 2.0), (0.01, 1.0), (0.04, 1.0), (0.1, 1.0)),
+                        split="train"):
+    """BASELINE config 5: one synthetic table per charger profile and one config per (profile, discomfort weight, power)
+    point of the sweep (values of shems_LU1.jl:20-41 / shems_LU1_input0607.jl); env i uses config i mod n_cfg.
+    Returns (tables, configs, cfg_of_env)."""
+    tabs = [_tables.synthetic_table(split, c) for c in charger_ids]
+    row0 = np.cumsum([0] + [t.shape[0] for t in tabs])
+    cfgs = [make_config(c, row0[p], tabs[p].shape[0], w, pot) for p, c in enumerate(charger_ids) for (w, pot) in sweep]
+    return tabs, cfgs, (np.arange(n_envs) % len(cfgs)).astype(np.uint16)
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

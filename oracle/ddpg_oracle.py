@@ -195,6 +195,38 @@ def act(actor, s, s_min, s_max, train, seed=0, tick=0, mu=0.0, sigma=0.1, dtype=
     return np.clip(a, f32(-1), f32(1)).astype(f32)
 
 
+STREAM_PERTURB = 0x50455254
+
+
+def perturb_shift(seed, tick, mu, sigma):
+    """sample_noise(pn::ParamNoise, rng) (DDPG.jl:63-67): ONE scalar Normal(mu, sigma_current) draw, Float32."""
+    x = philox(int(tick) & 0xFFFFFFFF, 0, 0, STREAM_PERTURB, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = (float(x[0] >> np.uint32(8)) + 0.5) / 16777216.0
+    u2 = (float(x[1] >> np.uint32(8)) + 0.5) / 16777216.0
+    return float(f32(mu + sigma * np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)))
+
+
+def add_perturb(actor, shift):
+    """add_perturb! (DDPG.jl:89-96): `p_t .= p_t .+ sample_noise(pn, rng)` re-seeds before each draw, so all six parameter
+    arrays of the copy receive the same scalar."""
+    return (actor.astype(f32) + f32(shift)).astype(f32)
+
+
+def act_param_noise(actor, s, s_min, s_max, shift, dtype=np.float32):
+    """act(...; train=true) with noise_type == "pn" (DDPG.jl:152-156): clamp(actor_perturb(s_norm), -1, 1)."""
+    a = actor_forward(add_perturb(actor, shift), normalize(s, s_min, s_max), dtype=dtype).astype(f32)
+    return np.clip(a, f32(-1), f32(1)).astype(f32)
+
+
+def adapt_param_noise(actor, s, s_min, s_max, shift, sigma_current, sigma_target=0.1, adoption=1.01, dtype=np.float32):
+    """adapt_param_noise! (DDPG.jl:74-87) -> (distance, new sigma_current)."""
+    sn = normalize(s, s_min, s_max)
+    a = actor_forward(actor, sn, dtype=dtype).astype(np.float64)
+    ap = actor_forward(add_perturb(actor, shift), sn, dtype=dtype).astype(np.float64)
+    distance = float(np.sqrt(np.mean((a - ap) ** 2)))
+    return distance, (sigma_current / adoption if distance > sigma_target else sigma_current * adoption)
+
+
 class Learner:
     """actor/critic/targets + two ADAMs; replay() = one DDPG update (DDPG.jl:121-145)."""
 

@@ -34,6 +34,12 @@ def test_bench_json_contract_small():
     assert d["value"] > 1e6 and d["updates_per_sec"] > 100
 
 
+def test_bench_mixed_profiles():
+    """BASELINE config 5: 10 charger profiles x 6 (discomfort weight, power) points, per-env configs."""
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline", "--mixed"])
+    assert d["config"]["mixed_profiles"] is True and d["value"] > 1e6
+
+
 def test_two_rank_data_parallel_rehearsal():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "4096"],

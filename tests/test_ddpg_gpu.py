@@ -173,3 +173,39 @@ def test_pipelined_replay_excludes_the_window_being_written_and_publishes_the_ac
     assert len(seen) > 3000
     with pytest.raises(S.ShemsError):
         ag.replay(ring, tick=0, exclude=(0, 24000))
+
+
+def test_parameter_noise_act_and_adaptation():
+    """noise_type "pn" (input.jl:210-215, DDPG.jl:63-96, 126-128, 152-156): act() evaluates actor .+ one scalar draw with no action
+    noise; replay() adapts sigma_current from the distance of the two actors on the sampled minibatch."""
+    torch, S, D, ag0, ring, h = _setup(seed=13)
+    ag = D.Agent(seed=13, noise_type="pn", sigma=0.02)
+    ag.set_params(actor=h["pa"], critic=h["pc"]); ag.set_norm(h["s_min"], h["s_max"])
+    obs = h["s"][:3000]
+    dev = torch.from_numpy(obs).cuda()
+    out = ag.act(dev, train=True, tick=5).cpu().numpy()
+    shift = ag.pn_shift
+    assert shift == DO.perturb_shift(13, 5, 0.0, ag.pn_sigma) and shift != 0.0
+    assert np.abs(ag.actor_perturb.cpu().numpy() - DO.add_perturb(h["pa"], shift)).max() == 0.0
+    ref = DO.act_param_noise(h["pa"], obs, h["s_min"], h["s_max"], shift, dtype=np.float64)
+    assert np.abs(out - ref).max() < 2e-5
+    clean = ag.act(dev, train=False).cpu().numpy()
+    assert np.abs(clean - DO.act(h["pa"], obs, h["s_min"], h["s_max"], False, dtype=np.float64)).max() < 1e-5
+    assert np.abs(out - clean).max() > 1e-3                       # the perturbation reaches the actions
+    # the fused vector step takes the same branch: its actions equal act()'s on the env's observations
+    tab = S.tables.synthetic_table("train", 98)
+    env = S.ShemsBatch(2048, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    env.reset_(3, episode=1)
+    s_before = np.array(env.state, np.float32, copy=True)
+    a_out = torch.empty((2048, 2), dtype=torch.float32, device="cuda")
+    ag.act_step(env, train=True, tick=9, a_out=a_out)
+    ref = DO.act_param_noise(h["pa"], s_before, h["s_min"], h["s_max"], DO.perturb_shift(13, 9, 0.0, ag.pn_sigma), dtype=np.float64)
+    assert np.abs(a_out.cpu().numpy() - ref).max() < 2e-5
+    # adaptation inside replay(): sigma moves by the adoption factor in the direction the oracle's distance says
+    sig = ag.pn_sigma
+    idx = DO.sample_indices(13, 0, 120, len(ring))
+    dist, sig_ref = DO.adapt_param_noise(h["pa"], h["s"][idx], h["s_min"], h["s_max"], DO.perturb_shift(13, 0, 0.0, sig), sig, dtype=np.float64)
+    assert abs(dist - 0.1) > 1e-3                                  # not a knife-edge case
+    ag.replay(ring)
+    assert abs(ag.pn_sigma - sig_ref) < 1e-12 and ag.pn_sigma != sig
+    torch.cuda.synchronize()

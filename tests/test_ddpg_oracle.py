@@ -107,3 +107,24 @@ def test_replay_update_reduces_critic_loss_and_moves_targets_slowly():
     assert losses[-1] < 0.5 * losses[0]
     assert 0 < np.abs(L.actor_t - actor).max() < np.abs(L.actor - actor).max()
     assert np.abs(L.critic_t - critic).max() < 0.1 * np.abs(L.critic - critic).max()
+
+
+def test_param_noise_restatement():
+    """ParamNoise (input.jl:210-215, DDPG.jl:63-96): scalar shift on every array, adaptation by the adoption factor; the product's
+    host draw (ddpg.perturb_shift) and the oracle's agree bit for bit."""
+    import importlib
+    import util as U
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    for seed, tick in ((1, 0), (13, 5), (2 ** 40 + 7, 123456)):
+        assert D.perturb_shift(seed, tick, 0.0, 0.1) == DO.perturb_shift(seed, tick, 0.0, 0.1)
+    z = np.array([DO.perturb_shift(3, t, 0.0, 1.0) for t in range(4000)])
+    assert abs(z.mean()) < 0.06 and abs(z.std() - 1.0) < 0.05
+    p = DO.init_params(5, 9, 2, 0)
+    q = DO.add_perturb(p, 0.25)
+    assert q.dtype == np.float32 and np.all(q == (p + np.float32(0.25)).astype(np.float32))
+    rng = np.random.default_rng(0)
+    s = rng.random((120, 9)).astype(np.float32)
+    d0, s0 = DO.adapt_param_noise(p, s, np.zeros(9, np.float32), np.ones(9, np.float32), 0.0, 0.1)
+    assert d0 == 0.0 and abs(s0 - 0.1 * 1.01) < 1e-15                  # identical actors: distance 0 -> sigma grows
+    d1, s1 = DO.adapt_param_noise(p, s, np.zeros(9, np.float32), np.ones(9, np.float32), 0.5, 0.1)
+    assert d1 > 0.1 and abs(s1 - 0.1 / 1.01) < 1e-15                   # far apart -> sigma shrinks
