@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=720)
     ap.add_argument("--warmup", type=int, default=72)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env", "group"])
+    ap.add_argument("--learners", type=int, default=32, help="group mode: independent learners per GPU (the thesis protocol of many seeds x chargers, SURVEY 8(f) rank 4); --envs must be learners x a multiple of 128")
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
     ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
@@ -279,7 +280,9 @@ def main():
         if train_mod is None and mode == "train":
             raise SystemExit("train mode requested but the DDPG path is not built")
         mode = "train" if train_mod is not None else "env"
-    if mode == "policy":
+    if mode == "group":
+        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank)
+    elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
         wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed)
@@ -322,7 +325,7 @@ def main():
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
                 "algorithmic_per_launch": k["algorithmic"]}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.envs, mode, args.updates)
+            cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -349,6 +352,8 @@ def main():
         out.update(wl.extra())
         if mode == "train":
             out["updates_per_sec"] = args.updates * args.steps / dt      # complete replay() equivalents (B = 120)
+        if mode == "group":
+            out["updates_per_sec"] = args.learners * world * args.steps / dt   # one replay() per learner per vector step
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -276,6 +276,40 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
                                float *d_publish, void *stream);
 /* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
 int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
+/* ------------------------------------------------- learner groups -- */
+/* The thesis protocol trains many INDEPENDENT learners (40 seeds x 10 charger profiles, one OS process and one
+ * batch-1 GPU stream each: run scripts + DDPG_reinforce_charger_v1.jl:10-47).  A learner
+ * group advances `count` independent learners with the same launches: every device buffer of learner l -- all
+ * pointers of shems_ddpg, shems_replay and the actor / s_min / s_max of shems_act_params -- is learner 0's pointer
+ * plus l * stride_bytes (one slab per learner, carved identically), and learner l owns the envs
+ * [l * envs_per_learner, (l + 1) * envs_per_learner) of the view.  Learners never exchange anything: per learner the
+ * result is bit-identical to the single-learner entry points run on that learner's buffers with seed + l.
+ *   act/step:  env i is driven by learner i / envs_per_learner's actor and normalisation; the ring window applies
+ *              inside each learner's env block (n = envs_per_learner) and pushes into that learner's ring.
+ *              envs_per_learner must be a multiple of 128.
+ *   update:    grid z = learner; minibatch l is sampled with Philox key seed + l; ADAM scalars are shared (the
+ *              learners advance in lockstep). */
+typedef struct shems_group {
+    int32_t count;             /* learners (>= 1)                                         */
+    int32_t reserved;
+    int64_t stride_bytes;      /* byte distance between consecutive learners' slabs (multiple of 16) */
+    int64_t envs_per_learner;  /* act/step only                                           */
+} shems_group;
+
+int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,
+                             double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window,
+                             void *stream);
+int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g,
+                                 int64_t ring_len, uint64_t seed, uint32_t tick, void *stream);
+int shems_ddpg_group_critic_apply(const shems_ddpg *d0, const shems_group *g, double eta, double bp1, double bp2,
+                                  void *stream);
+int shems_ddpg_group_actor_grad(const shems_ddpg *d0, const shems_group *g, void *stream);
+int shems_ddpg_group_actor_apply(const shems_ddpg *d0, const shems_group *g, double eta, double bp1, double bp2,
+                                 void *stream);
+/* min_max_buffer for every learner of the group (learner l: Philox key seed + l). */
+int shems_minmax_group_dev(const shems_replay *ring0, const shems_group *g, int64_t ring_len, int64_t count,
+                           uint64_t seed, float *d_s_min0, float *d_s_max0, void *stream);
+
 /* Parameter noise, noise_type "pn" (struct ParamNoise input.jl:210-215; add_perturb! DDPG.jl:89-96;
  * adapt_param_noise! DDPG.jl:74-87).  The reference adds ONE scalar draw N(mu, sigma_current) to every parameter
  * array of a copy of the actor (sample_noise(pn, rng) re-seeds before each draw); act() then evaluates the copy

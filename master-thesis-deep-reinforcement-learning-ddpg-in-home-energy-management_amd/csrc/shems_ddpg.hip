@@ -88,6 +88,25 @@ struct XSrc {
     float *publish;        // optional [2][BP]: where workgroup 0 stores the computed action
 };
 
+// Learner groups (shems_group): learner l's copy of every device buffer is learner 0's pointer + l * stride bytes.
+template <class T>
+__device__ __forceinline__ T *gsh(T *p, int64_t off) { return p ? reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off) : p; }
+__device__ __forceinline__ void gshift(XSrc &x, int64_t off)
+{
+    x.X = gsh(x.X, off); x.A = gsh(x.A, off); x.P3 = gsh(x.P3, off); x.b3 = gsh(x.b3, off); x.publish = gsh(x.publish, off);
+}
+__device__ __forceinline__ void gshift(shems_ddpg &d, int64_t off)
+{
+    d.actor = gsh(d.actor, off); d.critic = gsh(d.critic, off); d.actor_t = gsh(d.actor_t, off); d.critic_t = gsh(d.critic_t, off);
+    d.m_actor = gsh(d.m_actor, off); d.v_actor = gsh(d.v_actor, off); d.m_critic = gsh(d.m_critic, off); d.v_critic = gsh(d.v_critic, off);
+    d.grad_actor = gsh(d.grad_actor, off); d.grad_critic = gsh(d.grad_critic, off);
+    d.s_min = gsh(d.s_min, off); d.s_max = gsh(d.s_max, off); d.ws = gsh(d.ws, off); d.losses = gsh(d.losses, off);
+}
+__device__ __forceinline__ void gshift(shems_replay &r, int64_t off)
+{
+    r.s = gsh(r.s, off); r.a = gsh(r.a, off); r.r = gsh(r.r, off); r.s2 = gsh(r.s2, off); r.done = gsh(r.done, off);
+}
+
 template <int IN>
 __device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
 {
@@ -163,8 +182,9 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int
 
 // ---- kernel A: sample + gather + normalize -----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                                              int64_t excl_pos, int64_t excl_count)
+                                              int64_t excl_pos, int64_t excl_count, int64_t gstride)
 {
+    if (gstride) { gshift(d, blockIdx.z * gstride); gshift(ring, blockIdx.z * gstride); seed += blockIdx.z; }   // learner blockIdx.z
     float *ws = d.ws;
     if (blockIdx.x > 0) {          // workgroups 1..4: packed layer-1 images of actor_t, critic_t, critic, actor
         const int net = blockIdx.x - 1;
@@ -211,7 +231,11 @@ struct FwdJob {
     float *H2;             // [500][BP] or null (target nets: nothing downstream needs it)
     float *P3;             // [NT][2][BP] layer-3 partials of this n-tile
 };
-struct FwdArgs { FwdJob job[3]; };
+struct FwdArgs { FwdJob job[3]; int64_t gstride; };
+__device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
+{
+    J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
+}
 
 // Workgroup = one 32-wide n-tile x one 64-column half of the batch; its 4 waves split the work as (m-tile, K-half):
 // wave w computes columns [64*mh + 32*(w&1), +32) over hidden units [128*(w>>1), +128) (125 real rows + zero pad), so the two
@@ -348,7 +372,8 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const FwdJob &J = A.job[blockIdx.y];
+    FwdJob J = A.job[blockIdx.y];
+    if (A.gstride) gshift(J, blockIdx.z * A.gstride);
     if (J.in == SIN) fwd_body<SIN>(J, smem); else fwd_body<CIN>(J, smem);
 }
 
@@ -437,7 +462,13 @@ struct BwdArgs {
     int n_w;               // number of W workgroups (32 or 0); when > 0, 8 more "G" workgroups emit gb2 and gW3
     int head;              // how d3 is obtained: 0 = read A.d3, 1 = critic loss head, 2 = actor head
     shems_ddpg dd;         // for the heads
+    int64_t gstride;       // learner groups: byte stride between learners (0 = single learner)
 };
+__device__ __forceinline__ void gshift(BwdArgs &B, int64_t off)
+{
+    B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.d3 = gsh(B.d3, off);
+    B.grad = gsh(B.grad, off); B.D1P = gsh(B.D1P, off); B.DAP = gsh(B.DAP, off); gshift(B.dd, off);
+}
 enum { BWD_NG = 8 };
 
 constexpr int BWD_LDS = (BP * 129 + 33 * 128 + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8) * 4;
@@ -650,6 +681,12 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_bwd(BwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (A.gstride) {
+        BwdArgs B = A;
+        gshift(B, blockIdx.z * A.gstride);
+        if (B.in == SIN) bwd_body<SIN>(B, smem); else bwd_body<CIN>(B, smem);
+        return;
+    }
     if (A.in == SIN) bwd_body<SIN>(A, smem); else bwd_body<CIN>(A, smem);
 }
 
@@ -688,9 +725,10 @@ __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XS
     }
 }
 
-__global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad)
+__global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad, int64_t gstride)
 {
     __shared__ float xs[W1K * BP];
+    if (gstride) { const int64_t off = blockIdx.z * gstride; P = gsh(P, off); gshift(x, off); D1P = gsh(D1P, off); grad = gsh(grad, off); }
     if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad, xs); else l1bwd_body<CIN>(P, x, D1P, grad, xs);
 }
 
@@ -698,11 +736,14 @@ __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, c
 //   mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2 ; delta = mt/(1-bp1) / (sqrt(vt/(1-bp2)) + eps) * eta ; p -= delta
 //   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32)
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
-__global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ mt,
-                                                   float *__restrict__ vt, float *__restrict__ target, int n, double eta,
-                                                   double bp1, double bp2, double gscale, float tau, float *__restrict__ w1t_g, int in,
-                                                   float *__restrict__ publish)
+__global__ __launch_bounds__(256) void k_adam_soft(float *p, const float *g, float *mt, float *vt, float *target, int n, double eta,
+                                                   double bp1, double bp2, double gscale, float tau, float *w1t_g, int in,
+                                                   float *__restrict__ publish, int64_t gstride)
 {
+    if (gstride) {
+        const int64_t off = blockIdx.z * gstride;
+        p = gsh(p, off); g = gsh(g, off); mt = gsh(mt, off); vt = gsh(vt, off); target = gsh(target, off); w1t_g = gsh(w1t_g, off);
+    }
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -723,8 +764,9 @@ __global__ __launch_bounds__(256) void k_adam_soft(float *__restrict__ p, const 
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_minmax(shems_replay ring, int64_t ring_len, int64_t count, uint64_t seed,
-                                                 float *s_min, float *s_max)
+                                                 float *s_min, float *s_max, int64_t gstride)
 {
+    if (gstride) { const int64_t off = blockIdx.x * gstride; gshift(ring, off); s_min = gsh(s_min, off); s_max = gsh(s_max, off); seed += blockIdx.x; }
     __shared__ float lmin[16 * SIN], lmax[16 * SIN];
     float mn[SIN], mx[SIN];
 #pragma unroll
@@ -835,14 +877,15 @@ int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64
     return SHEMS_OK;
 }
 
-int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                           void *stream)
+static int check_group(const shems_group *g, const char *fn)
 {
-    return shems_ddpg_critic_grad_ex(d, ring, ring_len, seed, tick, 0, 0, stream);
+    if (!g || g->count < 1 || g->count > 65535 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
+        return set_error(SHEMS_ERR_ARG, "%s: shems_group needs 1 <= count <= 65535 and a 16-byte-multiple stride", fn);
+    return SHEMS_OK;
 }
 
-int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                              int64_t excl_pos, int64_t excl_count, void *stream)
+static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                            int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
     if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
@@ -851,32 +894,52 @@ int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad_ex: an exclusion window needs a full ring and 0 <= count < capacity");
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_prep, dim3(5), dim3(256), 0, st, *d, *ring, ring_len, seed, tick, excl_pos, excl_count);
+    hipLaunchKernelGGL(k_prep, dim3(5, 1, L), dim3(256), 0, st, *d, *ring, ring_len, seed, tick, excl_pos, excl_count, gs);
     const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
     const XSrc x_sa{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr};
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
+    f.gstride = gs;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1, L), dim3(256), FWD_LDS, st, f);
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
     f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
     f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 3), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 3, L), dim3(256), FWD_LDS, st, f);
     float *S = slot(ws, SLOT_CRITIC);
-    const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG), dim3(256), BWD_LDS, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
-                       (const float *)(S + SL_D1P), d->grad_critic);
+    const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d, gs};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
+    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
+                       (const float *)(S + SL_D1P), d->grad_critic, gs);
     return hip_ok(hipGetLastError(), "ddpg critic_grad launches");
 }
 
+int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                           void *stream)
+{
+    return critic_grad_impl(d, ring, ring_len, seed, tick, 0, 0, 1, 0, stream);
+}
+
+int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                              int64_t excl_pos, int64_t excl_count, void *stream)
+{
+    return critic_grad_impl(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, stream);
+}
+
+int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
+                                 uint64_t seed, uint32_t tick, void *stream)
+{
+    if (int rc = check_group(g, "shems_ddpg_group_critic_grad")) return rc;
+    return critic_grad_impl(d0, ring0, ring_len, seed, tick, 0, 0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, stream);
+}
+
 static int adam_launch(float *p, const float *g, float *m, float *v, float *target, int n, double eta, double bp1, double bp2,
-                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st)
+                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st, unsigned L = 1, int64_t gs = 0)
 {
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in, publish);
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256, 1, L), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in, publish, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -887,7 +950,16 @@ int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double 
                        grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream);
 }
 
-int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
+int shems_ddpg_group_critic_apply(const shems_ddpg *d, const shems_group *g, double eta, double bp1, double bp2, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_group_critic_apply")) return rc;
+    if (int rc = check_group(g, "shems_ddpg_group_critic_apply")) return rc;
+    return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2, 1.0,
+                       d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream, (unsigned)g->count,
+                       g->count > 1 ? g->stride_bytes : 0);
+}
+
+static int actor_grad_impl(const shems_ddpg *d, unsigned L, int64_t gs, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -899,16 +971,33 @@ int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream)
     float *C2 = slot(ws, SLOT_CRITIC2);
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
+    f.gstride = gs;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1), dim3(256), FWD_LDS, st, f);
-    const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d};
-    hipLaunchKernelGGL(k_bwd, dim3(KT * NQ), dim3(256), BWD_LDS, st, bi);
+    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1, L), dim3(256), FWD_LDS, st, f);
+    const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d, gs};
+    hipLaunchKernelGGL(k_bwd, dim3(KT * NQ, 1, L), dim3(256), BWD_LDS, st, bi);
     float *S = slot(ws, SLOT_ACTOR);
-    const BwdArgs b{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ, 2, *d};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG), dim3(256), BWD_LDS, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
-                       (const float *)(S + SL_D1P), d->grad_actor);
+    const BwdArgs b{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ, 2, *d, gs};
+    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
+    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
+                       (const float *)(S + SL_D1P), d->grad_actor, gs);
     return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
+}
+
+int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream) { return actor_grad_impl(d, 1, 0, stream); }
+
+int shems_ddpg_group_actor_grad(const shems_ddpg *d0, const shems_group *g, void *stream)
+{
+    if (int rc = check_group(g, "shems_ddpg_group_actor_grad")) return rc;
+    return actor_grad_impl(d0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, stream);
+}
+
+int shems_ddpg_group_actor_apply(const shems_ddpg *d, const shems_group *g, double eta, double bp1, double bp2, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_group_actor_apply")) return rc;
+    if (int rc = check_group(g, "shems_ddpg_group_actor_apply")) return rc;
+    return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, 1.0,
+                       d->tau, nullptr, (int)SIN, nullptr, (hipStream_t)stream, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0);
 }
 
 int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, float *d_publish,
@@ -951,7 +1040,18 @@ int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, 
 {
     if (!ring || !ring->s || ring_len < 1 || ring_len > ring->capacity || count < 1 || !d_s_min || !d_s_max)
         return set_error(SHEMS_ERR_ARG, "shems_minmax_dev: bad arguments");
-    hipLaunchKernelGGL(k_minmax, dim3(1), dim3(1024), 0, (hipStream_t)stream, *ring, ring_len, count, seed, d_s_min, d_s_max);
+    hipLaunchKernelGGL(k_minmax, dim3(1), dim3(1024), 0, (hipStream_t)stream, *ring, ring_len, count, seed, d_s_min, d_s_max, (int64_t)0);
+    return hip_ok(hipGetLastError(), "k_minmax launch");
+}
+
+int shems_minmax_group_dev(const shems_replay *ring, const shems_group *g, int64_t ring_len, int64_t count, uint64_t seed,
+                           float *d_s_min, float *d_s_max, void *stream)
+{
+    if (int rc = check_group(g, "shems_minmax_group_dev")) return rc;
+    if (!ring || !ring->s || ring_len < 1 || ring_len > ring->capacity || count < 1 || !d_s_min || !d_s_max)
+        return set_error(SHEMS_ERR_ARG, "shems_minmax_group_dev: bad arguments");
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)g->count), dim3(1024), 0, (hipStream_t)stream, *ring, ring_len, count, seed, d_s_min,
+                       d_s_max, g->count > 1 ? g->stride_bytes : (int64_t)0);
     return hip_ok(hipGetLastError(), "k_minmax launch");
 }
 

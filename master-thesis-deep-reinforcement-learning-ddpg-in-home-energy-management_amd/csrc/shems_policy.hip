@@ -63,7 +63,15 @@ struct ActArgs {
     shems_ring_window win;
     int do_step;
     int use_ring;
+    // learner groups (shems_group): env i belongs to learner i / genvs, whose actor / s_min / s_max / ring are the
+    // learner-0 pointers + learner * gstride bytes.  gcount <= 1: one learner.
+    int gcount;
+    int64_t gstride;
+    int64_t genvs;
 };
+
+template <class T>
+__device__ __forceinline__ T *gsh(T *p, int64_t off) { return p ? reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off) : p; }
 
 template <int TM, int NW>
 constexpr size_t act_lds_bytes()
@@ -147,8 +155,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: LDS-DMA bases (M0) stay on the SALU
     const int li = lane & 31, lh = lane >> 5;
-    const int64_t env0 = (int64_t)blockIdx.x * BM;
-    const float *__restrict__ P = A.p.actor;
+    // Learner groups: the workgroups of one learner stream the same 500 KB W2, so they should share an L2.  Workgroup ids
+    // go round-robin over the 8 XCDs; remapping id -> (id % 8) * (grid / 8) + id / 8 gives each XCD a contiguous range of
+    // tiles (= a few whole learners) instead of a slice of every learner.
+    int64_t bid = blockIdx.x;
+    if (A.gcount > 1 && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t env0 = bid * BM;
+    const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
+    const int64_t goff = learner * A.gstride;
+    const float *__restrict__ P = gsh(A.p.actor, goff);
+    const float *__restrict__ s_min = gsh(A.p.s_min, goff), *__restrict__ s_max = gsh(A.p.s_max, goff);
 
     // ---- stage 0: x = normalize(s) -> xT[k][m]; layer-1 image, b2/W3/b3 -> LDS; W2 chunk 0 -> LDS --------------
     for (int e = tid; e < BM * kIn; e += NT_) {
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float x = 0.0f;
         if (g < A.m * kIn) {
             const float s = A.obs[g];
-            x = (s - A.p.s_min[k]) / ((A.p.s_max[k] - A.p.s_min[k]) + 1e-8f);      // MPS:56
+            x = (s - s_min[k]) / ((s_max[k] - s_min[k]) + 1e-8f);      // MPS:56
         }
         xT[k * BM + m] = x;
     }
@@ -384,11 +400,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
                 if (A.rewards_f32) A.rewards_f32[i] = (float)reward;
                 if (A.returns_acc) A.returns_acc[i] += reward;
                 if (A.use_ring) {
-                    int64_t rel = i - A.win.offset;
-                    rel %= v.n_envs;
-                    if (rel < 0) rel += v.n_envs;
-                    if (rel < A.win.count)
-                        ring_push(A.ring, (A.win.pos + rel) % A.ring.capacity, pre, a0, a1, (float)reward, obs);
+                    const int64_t nl = A.gcount > 1 ? A.genvs : v.n_envs;          // the window rotates inside a learner's env block
+                    int64_t rel = (i - learner * nl) - A.win.offset;
+                    rel %= nl;
+                    if (rel < 0) rel += nl;
+                    if (rel < A.win.count) {
+                        shems_replay ring = A.ring;
+                        if (A.gcount > 1) {
+                            ring.s = gsh(ring.s, goff); ring.a = gsh(ring.a, goff); ring.r = gsh(ring.r, goff);
+                            ring.s2 = gsh(ring.s2, goff); ring.done = gsh(ring.done, goff);
+                        }
+                        ring_push(ring, (A.win.pos + rel) % ring.capacity, pre, a0, a1, (float)reward, obs);
+                    }
                 }
             } else {
                 reward = 0.0;
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Wc);     // Wc is dead by now
         const double s = block_sum(reward, red64, NW);
-        if (tid == 0) A.block_reward[blockIdx.x] = s;
+        if (tid == 0) A.block_reward[bid] = s;
     }
 #endif
 }
@@ -495,6 +518,33 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
         if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0)
             return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: ring window larger than the ring or the batch");
         a.ring = *ring; a.win = *window; a.use_ring = 1;
+    }
+    return dispatch_act(a, (hipStream_t)stream);
+}
+
+int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,
+                             double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
+{
+    if (int rc = check_act(p0, "shems_act_step_group_dev")) return rc;
+    if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1)
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: invalid view");
+    if (!g || g->count < 1 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: shems_group needs count >= 1 and a 16-byte-multiple stride");
+    if (g->envs_per_learner < 128 || g->envs_per_learner % 128 != 0 || g->envs_per_learner * g->count != v->n_envs)
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: envs_per_learner must be a multiple of 128 and count * envs_per_learner == n_envs "
+                         "(got %lld x %d for %lld envs)", (long long)g->envs_per_learner, g->count, (long long)v->n_envs);
+    ActArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.v = *v; a.p = *p0; a.obs = v->obs; a.m = v->n_envs; a.a_out = d_a;
+    a.returns_acc = d_returns_acc;
+    a.do_step = 1;
+    a.gcount = g->count; a.gstride = g->count > 1 ? g->stride_bytes : 0; a.genvs = g->envs_per_learner;
+    if (ring0 && window && window->count > 0) {
+        if (ring0->capacity <= 0 || !ring0->s || !ring0->a || !ring0->r || !ring0->s2 || !ring0->done)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: incomplete replay ring");
+        if (window->count > ring0->capacity || window->count > g->envs_per_learner || window->pos < 0)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: ring window larger than the ring or a learner's env block");
+        a.ring = *ring0; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);
 }

@@ -137,7 +137,10 @@ class Agent:
     """The DDPG learner state on one GPU (one replica under data parallelism)."""
 
     def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None, noise_type="gn", theta=0.15,
-                 dt=1e-2, eps=0.5):
+                 dt=1e-2, eps=0.5, tensors=None):
+        """tensors: dict of float32 device views (actor, critic, actor_t, critic_t, m_actor, v_actor, m_critic, v_critic,
+        grad_actor, grad_critic, s_min, s_max, ws, losses) in memory the caller owns -- a learner group's slab -- instead
+        of buffers allocated here."""
         import torch
         self.torch = torch
         self.L = _declare()
@@ -153,21 +156,30 @@ class Agent:
         a = init_params(self.seed, STATE, ACTION, 0)
         c = init_params(self.seed, STATE + ACTION, 1, 1)
         assert a.size == N_ACTOR and c.size == N_CRITIC
-        self.actor = torch.from_numpy(a).to(self.device)
-        self.critic = torch.from_numpy(c).to(self.device)
-        self.actor_t = self.actor.clone()          # deepcopy(actor), DDPG.jl:38
-        self.critic_t = self.critic.clone()
-        self.s_min = torch.zeros(STATE, dtype=torch.float32, device=self.device)
-        self.s_max = torch.ones(STATE, dtype=torch.float32, device=self.device)
-        self.tick = 0
-        # learner state: ADAM moments (opt_act = ADAM(eta_act), opt_crit = ADAM(eta_crit), input.jl:126-127)
-        z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.m_actor, self.v_actor, self.m_critic, self.v_critic = z(N_ACTOR), z(N_ACTOR), z(N_CRITIC), z(N_CRITIC)
-        self.grad_actor, self.grad_critic = z(N_ACTOR), z(N_CRITIC)
         nws = C.c_int64(0)
         _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
-        self.ws = z(nws.value)
-        self.losses = z(2)
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+        if tensors is None:
+            tensors = dict(actor=z(N_ACTOR), critic=z(N_CRITIC), actor_t=z(N_ACTOR), critic_t=z(N_CRITIC),
+                           m_actor=z(N_ACTOR), v_actor=z(N_ACTOR), m_critic=z(N_CRITIC), v_critic=z(N_CRITIC),
+                           grad_actor=z(N_ACTOR), grad_critic=z(N_CRITIC), s_min=z(STATE), s_max=z(STATE), ws=z(nws.value), losses=z(2))
+        for k, n in (("actor", N_ACTOR), ("critic", N_CRITIC), ("actor_t", N_ACTOR), ("critic_t", N_CRITIC), ("m_actor", N_ACTOR),
+                     ("v_actor", N_ACTOR), ("m_critic", N_CRITIC), ("v_critic", N_CRITIC), ("grad_actor", N_ACTOR),
+                     ("grad_critic", N_CRITIC), ("s_min", STATE), ("s_max", STATE), ("ws", nws.value), ("losses", 2)):
+            t = tensors[k]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, k
+            setattr(self, k, t)
+        self.device = self.actor.device
+        self.actor.copy_(torch.from_numpy(a))
+        self.critic.copy_(torch.from_numpy(c))
+        self.actor_t.copy_(self.actor)             # deepcopy(actor), DDPG.jl:38
+        self.critic_t.copy_(self.critic)
+        self.s_min.zero_()
+        self.s_max.fill_(1.0)
+        self.tick = 0
+        # learner state: ADAM moments (opt_act = ADAM(eta_act), opt_crit = ADAM(eta_crit), input.jl:126-127)
+        for k in ("m_actor", "v_actor", "m_critic", "v_critic", "grad_actor", "grad_critic", "ws", "losses"):
+            getattr(self, k).zero_()
         self.gamma, self.tau = GAMMA, TAU
         self.eta_act, self.eta_crit = float(f32(ETA_ACT)), float(f32(ETA_CRIT))
         self.batch = BATCH_SIZE

@@ -38,6 +38,42 @@ def make_config(charger_id=98, table_row0=0, nrow=0, disc_weight=0.01, disc_pot=
                   float(f32(penalty_weight)), int(table_row0), int(nrow), 0)
 
 
+class EnvSlice:
+    """Envs [start, start + count) of a ShemsBatch through the device-chaining entry points only (view, seeded reset,
+    rollout): what one learner of a learner group needs for populate_memory and what the parity tests drive.  Inside the
+    slice env indices -- and with them the Philox counters of reset / random actions / noise -- start at 0."""
+
+    def __init__(self, parent, start, count):
+        start, count = int(start), int(count)
+        if start < 0 or count < 1 or start + count > parent.n:
+            raise ValueError("slice outside the batch")
+        self.parent, self.start, self.n, self.maxsteps = parent, start, count, parent.maxsteps
+        self._L = parent._L
+
+    def view(self):
+        v = self.parent.view()
+        v.n_envs = self.n
+        v.obs += self.start * _capi.NSTATE * 4
+        v.idx += self.start * 4
+        v.step += self.start * 4
+        if v.cfg_of_env:
+            v.cfg_of_env += self.start * 2
+        return v
+
+    def use_torch_stream(self):
+        self.parent.use_torch_stream()
+        return self
+
+    def _stream(self):
+        return self.parent._stream()
+
+    def reset_(self, rng=0, episode=0):
+        v = self.view()
+        _capi.check(self._L.shems_reset_seeded_dev(C.byref(v), int(rng) & ((1 << 64) - 1), int(episode), self._stream()))
+        return self
+
+
+
 def mixed_profile_setup(n_envs, charger_ids=(1, 2, 3, 4, 5, 6, 7, 8, 9, 98), sweep=((0.01, 2.0), (0.04, 2.0), (0.1, 2.0), (0.01, 1.0), (0.04, 1.0), (0.1, 1.0)),
                         split="train"):
     """BASELINE config 5: one synthetic table per charger profile and one config per (profile, discomfort weight, power)
@@ -231,8 +267,15 @@ class ShemsBatch:
     def set_stream(self, stream_ptr):
         _capi.check(self._L.shems_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def slice(self, start, count):
+        """Envs [start, start + count) as a device view of their own (see EnvSlice)."""
+        return EnvSlice(self, start, count)
+
     def check_error(self):
         _capi.check(self._L.shems_check_error(self._h))
+
+
+EnvSlice.rollout = ShemsBatch.rollout          # same launch, on the slice's view
 
 
 class Shems:

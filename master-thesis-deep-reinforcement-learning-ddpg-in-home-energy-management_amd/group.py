@@ -1,0 +1,245 @@
+"""Learner groups: many INDEPENDENT DDPG learners advanced by the same launches.
+
+The thesis protocol is 40 seeds x 10 charger profiles, each an OS process of its own running the batch-1 loop of
+DDPG_reinforce_charger_v1.jl:10-47 (run scripts `RL-SHEMS/*.sh`).  Here learner l owns one slab of device memory
+(networks, targets, ADAM moments, gradients, workspace, normalisation, replay ring -- all carved identically) and the
+env block [l * E, (l + 1) * E) of one ShemsBatch; `shems_act_step_group_dev` / `shems_ddpg_group_*` take learner 0's
+pointers plus the slab stride and run every learner in the same grid (grid z = learner for the update kernels).
+Learners never exchange anything, so a group shards over GPUs as plain replicas (no collective).
+
+Per learner the results are bit-identical to the single-learner `Agent` driven on that learner's views
+(tests/test_group_gpu.py); `LearnerGroup.learners[l]` / `.rings[l]` ARE such single-learner objects on the slab.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .ddpg import (ACTION, BATCH_SIZE, MEM_SIZE, N_ACTOR, N_CRITIC, NOISE_SIGMA, STATE, Agent, RingWindow, _declare)
+from .replay import ReplayRing
+
+
+class Group(C.Structure):              # shems_group
+    _fields_ = [("count", C.c_int32), ("reserved", C.c_int32), ("stride_bytes", C.c_int64), ("envs_per_learner", C.c_int64)]
+
+
+def _declare_group():
+    L = _declare()
+    if getattr(L, "_group_declared", False):
+        return L
+    vp, i64 = C.c_void_p, C.c_int64
+    from .ddpg import ActParams, DdpgArgs
+    PD, PG, PR = C.POINTER(DdpgArgs), C.POINTER(Group), C.POINTER(_capi.Replay)
+    L.shems_act_step_group_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), PG, vp, vp, PR, C.POINTER(RingWindow), vp]
+    L.shems_ddpg_group_critic_grad.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, vp]
+    L.shems_ddpg_group_critic_apply.argtypes = [PD, PG, C.c_double, C.c_double, C.c_double, vp]
+    L.shems_ddpg_group_actor_grad.argtypes = [PD, PG, vp]
+    L.shems_ddpg_group_actor_apply.argtypes = [PD, PG, C.c_double, C.c_double, C.c_double, vp]
+    L.shems_minmax_group_dev.argtypes = [PR, PG, i64, i64, C.c_uint64, vp, vp, vp]
+    for fn in ("shems_act_step_group_dev", "shems_ddpg_group_critic_grad", "shems_ddpg_group_critic_apply",
+               "shems_ddpg_group_actor_grad", "shems_ddpg_group_actor_apply", "shems_minmax_group_dev"):
+        getattr(L, fn).restype = C.c_int
+    L._group_declared = True
+    return L
+
+
+def _pad4(n):
+    return (int(n) + 3) & ~3
+
+
+class LearnerGroup:
+    """`count` independent learners, learner l seeded with (seed + l) for its network initialisation and (rng_seed + l)
+    for its minibatch stream; exploration noise is keyed per env, so it differs between learners by construction."""
+
+    def __init__(self, count, envs_per_learner, seed=1231, rng_seed=None, capacity=MEM_SIZE, sigma=NOISE_SIGMA, device=None):
+        import torch
+        self.torch = torch
+        self.L = _declare_group()
+        self.count, self.envs_per_learner, self.capacity = int(count), int(envs_per_learner), int(capacity)
+        if self.count < 1 or self.envs_per_learner % 128 != 0:
+            raise ValueError("a learner group needs count >= 1 and envs_per_learner a multiple of 128")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.seed = int(seed)
+        self.rng_seed = self.seed if rng_seed is None else int(rng_seed)
+        nws = C.c_int64(0)
+        _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
+        # one slab per learner; every block starts on a 16-byte boundary (float offsets are multiples of 4)
+        layout, off = {}, 0
+        for name, n in (("actor", N_ACTOR), ("critic", N_CRITIC), ("actor_t", N_ACTOR), ("critic_t", N_CRITIC),
+                        ("m_actor", N_ACTOR), ("v_actor", N_ACTOR), ("m_critic", N_CRITIC), ("v_critic", N_CRITIC),
+                        ("grad_actor", N_ACTOR), ("grad_critic", N_CRITIC), ("s_min", STATE), ("s_max", STATE), ("losses", 2),
+                        ("ws", nws.value), ("ring_s", self.capacity * STATE), ("ring_a", self.capacity * ACTION),
+                        ("ring_r", self.capacity), ("ring_s2", self.capacity * STATE), ("ring_done", (self.capacity + 3) // 4)):
+            layout[name] = (off, int(n))
+            off = _pad4(off + n)
+        self.layout, self.slab_floats = layout, off
+        self.slab = torch.zeros((self.count, self.slab_floats), dtype=torch.float32, device=self.device)
+        self.learners, self.rings = [], []
+        for l in range(self.count):
+            v = lambda name: self.slab[l, layout[name][0]:layout[name][0] + layout[name][1]]
+            tens = {k: v(k) for k in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic",
+                                      "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")}
+            self.learners.append(Agent(seed=self.seed + l, rng_seed=self.rng_seed + l, sigma=sigma, device=self.device, tensors=tens))
+            done = v("ring_done").view(torch.uint8)[:self.capacity]
+            self.rings.append(ReplayRing(self.capacity, tensors=(v("ring_s").view(self.capacity, STATE), v("ring_a").view(self.capacity, ACTION),
+                                                                 v("ring_r"), v("ring_s2").view(self.capacity, STATE), done)))
+        self.updates = 0
+        self.tick = 0
+
+    # ------------------------------------------------------------------
+    def struct(self):
+        return Group(self.count, 0, self.slab_floats * 4, self.envs_per_learner)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    @property
+    def n_envs(self):
+        return self.count * self.envs_per_learner
+
+    def populate_memory(self, env, seed=None):
+        """populate_memory (MPS:9-29) per learner on its own env block (learner l: seed + l)."""
+        seed = self.rng_seed if seed is None else int(seed)
+        E = self.envs_per_learner
+        for l, (ag, ring) in enumerate(zip(self.learners, self.rings)):
+            ag.populate_memory(env.slice(l * E, E), ring, seed=seed + l)
+        return self
+
+    def min_max_buffer(self, count=None, seed=None):
+        """min_max_buffer (MPS:50-53) for every learner in one launch (learner l: Philox key seed + l)."""
+        g, r0 = self.struct(), self.rings[0].struct()
+        n = len(self.rings[0])
+        a0 = self.learners[0]
+        _capi.check(self.L.shems_minmax_group_dev(C.byref(r0), C.byref(g), n, n if count is None else int(count),
+                                                  self.rng_seed if seed is None else int(seed), C.c_void_p(a0.s_min.data_ptr()),
+                                                  C.c_void_p(a0.s_max.data_ptr()), self._stream()))
+        return self
+
+    def act_step(self, env, train=True, tick=None, a_out=None, returns_acc=None, window=None):
+        """One fused vector step for all learners: env i acts with learner i // E's actor; with `window` = (pos, count, offset)
+        each learner stores `count` transitions of its own env block into its own ring."""
+        if env.n != self.n_envs:
+            raise ValueError("the env batch must hold count * envs_per_learner envs")
+        env.use_torch_stream()
+        v, g = env.view(), self.struct()
+        a0 = self.learners[0]
+        p = a0._act_params(train, self.tick if tick is None else tick)
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        r0 = self.rings[0].struct()
+        w = RingWindow(*window) if window is not None else None
+        _capi.check(self.L.shems_act_step_group_dev(C.byref(v), C.byref(p), C.byref(g), ptr(a_out), ptr(returns_acc),
+                                                    C.byref(r0) if w is not None else None, C.byref(w) if w is not None else None,
+                                                    self._stream()))
+        if w is not None:
+            for ring in self.rings:
+                ring.pushed += int(window[1])
+
+    def replay(self, tick=None):
+        """replay() (DDPG.jl:121-145) for every learner: 11 launches in total, grid z = learner."""
+        a0, g, r0 = self.learners[0], self.struct(), self.rings[0].struct()
+        d = a0._ddpg_args()
+        st = self._stream()
+        tick = self.updates if tick is None else tick
+        _capi.check(self.L.shems_ddpg_group_critic_grad(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed,
+                                                        int(tick) & 0xFFFFFFFF, st))
+        _capi.check(self.L.shems_ddpg_group_critic_apply(C.byref(d), C.byref(g), a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], st))
+        _capi.check(self.L.shems_ddpg_group_actor_grad(C.byref(d), C.byref(g), st))
+        _capi.check(self.L.shems_ddpg_group_actor_apply(C.byref(d), C.byref(g), a0.eta_act, a0.bp_actor[0], a0.bp_actor[1], st))
+        for ag in self.learners:                   # the learners advance in lockstep: shared beta powers / update count
+            ag.bp_critic = [ag.bp_critic[0] * 0.9, ag.bp_critic[1] * 0.999]
+            ag.bp_actor = [ag.bp_actor[0] * 0.9, ag.bp_actor[1] * 0.999]
+            ag.updates += 1
+        self.updates += 1
+
+    def episode_(self, env, train=True, num_steps=None, rng_ep=0, episode=0, window_count=None):
+        """episode! for all learners at once (cf. Agent.episode_).  Returns the per-env episode returns [count * E]."""
+        t = self.torch
+        num_steps = env.maxsteps if num_steps is None else int(num_steps)
+        env.reset_(rng_ep, episode=episode) if rng_ep != -1 else env.reset_(-1)
+        returns = t.zeros(env.n, dtype=t.float64, device=self.device)
+        E = self.envs_per_learner
+        wc = min(E, max(1, self.capacity // num_steps)) if window_count is None else int(window_count)
+        for step in range(num_steps):
+            tick = (int(episode) * 4096 + step) & 0xFFFFFFFF
+            win = (self.rings[0].pos, wc, (self.tick * wc) % E) if train else None
+            self.act_step(env, train=train, tick=tick, returns_acc=returns, window=win)
+            if train:
+                self.replay()
+            self.tick += 1
+        return returns
+
+
+class GroupWorkload:
+    """bench.py's "group" step: one fused vector step of all learners' envs + one replay() of every learner."""
+
+    name = "group"
+    dtype = "f32"
+    EP_LEN = 72
+
+    def __init__(self, S, torch, n, learners, seed):
+        self.S, self.torch, self.n, self.count = S, torch, int(n), int(learners)
+        if self.n % self.count or (self.n // self.count) % 128:
+            raise ValueError("--envs must be learners x a multiple of 128")
+        E = self.n // self.count
+        self.tab = S.tables.synthetic_table("train", 98)
+        self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
+                                device=torch.cuda.current_device()).use_torch_stream()
+        self.env_seed = int(seed)
+        self.group = LearnerGroup(self.count, E, seed=1231, rng_seed=self.env_seed)
+        self.group.populate_memory(self.env, seed=self.env_seed)
+        self.group.min_max_buffer()
+        self.win = min(E, MEM_SIZE // self.EP_LEN)
+        self.t, self.episode = 0, 1
+        self.env.reset_(self.env_seed, episode=self.episode)
+
+    def step(self):
+        if self.t and self.t % self.EP_LEN == 0:
+            self.episode += 1
+            v = self.env.view()
+            _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, self.episode, self.env._stream()))
+        g = self.group
+        g.act_step(self.env, train=True, tick=self.t, window=(g.rings[0].pos, self.win, (self.t * self.win) % g.envs_per_learner))
+        g.replay()
+        self.t += 1
+
+    def finish(self):
+        self.torch.cuda.synchronize()
+        self.env.check_error()
+        end = self.group.layout["ws"][0]               # networks, targets, moments, gradients, normalisation, losses (the workspace
+        if not bool(self.torch.isfinite(self.group.slab[:, :end]).all()):      # keeps int32 slots whose -1 pad reads as NaN)
+            raise RuntimeError("non-finite learner state after the timed steps")
+
+    def kernel_pass(self, reps):
+        """HIP-event timing of the fused act/step launch (all learners' envs) and of one grouped replay()."""
+        torch = self.torch
+        reps = min(reps, 100)
+        g = self.group
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        self.env.reset_(self.env_seed, episode=100000)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            if i and i % (self.EP_LEN - 1) == 0:
+                self.env.reset_(self.env_seed, episode=100000 + i)
+            a.record()
+            g.act_step(self.env, train=True, tick=i, window=(g.rings[0].pos, self.win, (i * self.win) % g.envs_per_learner))
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nup = 20
+        e0.record()
+        for _ in range(nup):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        self.update_us = e0.elapsed_time(e1) * 1e3 / nup
+        flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
+        return dict(kernel="shems::k_act<TM>", avg_us=sum(ms) / len(ms) * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
+
+    def extra(self):
+        return {"learners": self.count, "envs_per_learner": self.n // self.count, "updates_per_step": self.count,
+                "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "replay_window_envs_per_step": self.win,
+                "group_update_us": getattr(self, "update_us", None), "update_mflop": 307.8}

@@ -11,15 +11,21 @@ from . import _capi
 
 
 class ReplayRing:
-    def __init__(self, capacity, device="cuda:0"):
+    def __init__(self, capacity, device="cuda:0", tensors=None):
+        """tensors = (s, a, r, s2, done): views into memory the caller owns (a learner group's slab) instead of new buffers."""
         import torch
         self.capacity = int(capacity)
-        self.device = torch.device(device)
-        self.s = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
-        self.a = torch.zeros((self.capacity, _capi.NACTION), dtype=torch.float32, device=self.device)
-        self.r = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)
-        self.s2 = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
-        self.done = torch.zeros((self.capacity,), dtype=torch.uint8, device=self.device)
+        if tensors is not None:
+            self.s, self.a, self.r, self.s2, self.done = tensors
+            self.device = self.s.device
+            assert self.s.shape == (self.capacity, _capi.NSTATE) and self.done.dtype == torch.uint8 and self.done.shape == (self.capacity,)
+        else:
+            self.device = torch.device(device)
+            self.s = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
+            self.a = torch.zeros((self.capacity, _capi.NACTION), dtype=torch.float32, device=self.device)
+            self.r = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)
+            self.s2 = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((self.capacity,), dtype=torch.uint8, device=self.device)
         self.pushed = 0                      # total transitions ever pushed (host state)
 
     def __len__(self):                       # length(memory)
