@@ -281,7 +281,7 @@ def main():
             raise SystemExit("train mode requested but the DDPG path is not built")
         mode = "train" if train_mod is not None else "env"
     if mode == "group":
-        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank)
+        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank, mixed=args.mixed)
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":

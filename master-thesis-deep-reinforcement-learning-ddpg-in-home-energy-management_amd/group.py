@@ -178,14 +178,22 @@ class GroupWorkload:
     dtype = "f32"
     EP_LEN = 72
 
-    def __init__(self, S, torch, n, learners, seed):
+    def __init__(self, S, torch, n, learners, seed, mixed=False):
         self.S, self.torch, self.n, self.count = S, torch, int(n), int(learners)
         if self.n % self.count or (self.n // self.count) % 128:
             raise ValueError("--envs must be learners x a multiple of 128")
         E = self.n // self.count
-        self.tab = S.tables.synthetic_table("train", 98)
-        self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
-                                device=torch.cuda.current_device()).use_torch_stream()
+        if mixed:                       # the thesis grid: learner l trains on charger profile l mod 10 (ids 1-9, 98; LU1:47-58)
+            ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
+            tabs = [S.tables.synthetic_table("train", c) for c in ids]
+            row0 = np.cumsum([0] + [t.shape[0] for t in tabs])
+            cfgs = [S.make_config(c, row0[k], tabs[k].shape[0]) for k, c in enumerate(ids)]
+            co = ((np.arange(self.n) // E) % len(ids)).astype(np.uint16)
+            self.env = S.ShemsBatch(self.n, self.EP_LEN, tabs, cfgs, co, device=torch.cuda.current_device()).use_torch_stream()
+        else:
+            self.tab = S.tables.synthetic_table("train", 98)
+            self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
+                                    device=torch.cuda.current_device()).use_torch_stream()
         self.env_seed = int(seed)
         self.group = LearnerGroup(self.count, E, seed=1231, rng_seed=self.env_seed)
         self.group.populate_memory(self.env, seed=self.env_seed)

@@ -40,6 +40,14 @@ def test_bench_mixed_profiles():
     assert d["config"]["mixed_profiles"] is True and d["value"] > 1e6
 
 
+def test_bench_group_mode_with_charger_grid():
+    """--mode group: independent learners, learner l on charger profile l mod 10."""
+    d = _run([sys.executable, "bench.py", "--mode", "group", "--learners", "16", "--envs", "8192", "--mixed", "--steps", "12", "--warmup", "2",
+              "--no-cpu-baseline"])
+    assert d["config"]["mode"] == "group" and d["learners"] == 16 and d["envs_per_learner"] == 512
+    assert d["updates_per_sec"] > 16 * 100 and d["value"] > 1e6
+
+
 def test_two_rank_data_parallel_rehearsal():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "4096"],
