@@ -238,6 +238,23 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)
+    if mode == "train":
+        # replay() alone, one thread (BLAS capped) and BLAS on all host cores -- informational
+        def upd_rate(nrep):
+            t1 = time.perf_counter()
+            for u in range(nrep):
+                i = DO.sample_indices(2, u, 120, cap)
+                learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
+            return nrep / (time.perf_counter() - t1)
+        ctx = threadpool_limits(limits=1) if threadpool_limits else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            out["update_only_per_sec"] = upd_rate(40)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        out["update_only_all_cores_per_sec"] = upd_rate(40)
     out.update({"value": n * nstep / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
                 "sample": f"CPU oracle (C env + NumPy learner, BLAS limited to 1 thread), the same vector step "
                           f"(mode={mode}, {updates} update/step) on a {n}-env slice: {nstep} vector steps = {n * nstep} env-steps in {dt:.1f} s",
