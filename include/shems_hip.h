@@ -253,7 +253,10 @@ typedef struct shems_ddpg {
     float *losses;                                  /* [2] out: critic mse, actor loss (-mean q)   */
     float gamma, tau;
     int32_t batch;                                  /* BATCH_SIZE (<= 128)                         */
-    int32_t reserved;
+    int32_t fuse_l1;                                /* single replica only (no all-reduce between *_grad and *_apply): 1 = the
+                                                     * layer-1 rows gW1/gb1 are produced inside the ADAM launch of *_apply instead of
+                                                     * by a launch of *_grad; grad_* is complete only after the matching *_apply.
+                                                     * Same bits either way.  Must be 0 when gradients are exchanged.              */
 } shems_ddpg;
 
 int shems_ddpg_workspace_floats(int64_t *out);

@@ -692,14 +692,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 // ---- kernel E: layer-1 gradients, one wave per hidden unit k --------------------------------------------------
 //   D1[k][m] = (h1[k][m] > 0) * sum_q D1part[q][k][m];  gb1[k] = sum_m D1;  gW1[j][k] = sum_m x[j][m] D1[k][m]
+// One wave, xs = the network input [12][BP] in LDS.  gout[j] = gW1[j][k] (j < IN), gout[IN] = gb1[k], valid in every lane.
 template <int IN>
-__device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
-                                           float *__restrict__ grad, float *xs)
+__device__ __forceinline__ void l1bwd_wave(const float *__restrict__ P, const float *xs, const float *__restrict__ D1P, int k, int lane,
+                                           float (&gout)[IN + 1])
 {
-    build_x<IN>(x, xs, false);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= H1N) return;
     float w[IN];
 #pragma unroll
     for (int j = 0; j < IN; ++j) w[j] = P[j * H1N + k];
@@ -716,12 +713,25 @@ __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XS
         for (int q = 0; q < NQ; ++q) s += D1P[((int64_t)q * H1N + k) * BP + m];
         dv[h] = pre > 0.0f ? s : 0.0f;
     }
-    const float sb = wave_sum(dv[0] + dv[1]);
-    if (lane == 0) grad[off_b1(IN) + k] = sb;
+    gout[IN] = __shfl(wave_sum(dv[0] + dv[1]), 0, 64);
 #pragma unroll
-    for (int j = 0; j < IN; ++j) {
-        const float s = wave_sum(xs[j * BP + lane] * dv[0] + xs[j * BP + 64 + lane] * dv[1]);
-        if (lane == 0) grad[j * H1N + k] = s;
+    for (int j = 0; j < IN; ++j) gout[j] = __shfl(wave_sum(xs[j * BP + lane] * dv[0] + xs[j * BP + 64 + lane] * dv[1]), 0, 64);
+}
+
+template <int IN>
+__device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
+                                           float *__restrict__ grad, float *xs)
+{
+    build_x<IN>(x, xs, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= H1N) return;
+    float gout[IN + 1];
+    l1bwd_wave<IN>(P, xs, D1P, k, lane, gout);
+    if (lane == 0) {
+        grad[off_b1(IN) + k] = gout[IN];
+#pragma unroll
+        for (int j = 0; j < IN; ++j) grad[j * H1N + k] = gout[j];
     }
 }
 
@@ -736,30 +746,74 @@ __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, c
 //   mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2 ; delta = mt/(1-bp1) / (sqrt(vt/(1-bp2)) + eps) * eta ; p -= delta
 //   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32)
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
-__global__ __launch_bounds__(256) void k_adam_soft(float *p, const float *g, float *mt, float *vt, float *target, int n, double eta,
-                                                   double bp1, double bp2, double gscale, float tau, float *w1t_g, int in,
-                                                   float *__restrict__ publish, int64_t gstride)
+// Single-replica form (shems_ddpg.fuse_l1): no gradient exchange sits between backward and ADAM, so the layer-1 gradient rows are
+// produced HERE instead of by a k_l1bwd launch of their own: workgroup b < 63 computes the rows of hidden units 4b..4b+3 (one wave
+// each, same arithmetic as k_l1bwd), stores them to the gradient block and applies ADAM to exactly those (in + 1) * 4 elements; all
+// workgroups then sweep the elements from b1's end onwards.  No element is read by one workgroup and written by another.
+struct AdamCtx {
+    float *p; const float *g; float *mt, *vt, *target; float *w1t_g; float *publish;
+    int n, in; double eta, bp1, bp2, gscale; float tau;
+};
+struct L1Src { const float *P; XSrc x; const float *D1P; float *grad; int on; };
+
+__device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
 {
+    // Julia evaluates the broadcast expressions without fusing multiplies into adds; keeping the compiler from contracting also
+    // makes the two inlined copies of this function (layer-1 rows / sweep) round identically.
+#pragma clang fp contract(off)
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    const float gf = (float)((double)graw * c.gscale);          // averaged gradient, as every replica holds it
+    const float m1 = (float)(b1 * (double)c.mt[i] + (1.0 - b1) * (double)gf);
+    const float v1 = (float)(b2 * (double)c.vt[i] + (1.0 - b2) * ((double)gf * (double)gf));
+    const float delta = (float)((double)m1 / (1.0 - c.bp1) / (sqrt((double)v1 / (1.0 - c.bp2)) + eps) * c.eta);
+    const float pn = c.p[i] - delta;
+    c.mt[i] = m1; c.vt[i] = v1; c.p[i] = pn;
+    if (c.publish) c.publish[i] = pn;
+    const float one_m_tau = 1.0f - c.tau;
+    c.target[i] = one_m_tau * c.target[i] + c.tau * pn;
+    if (c.w1t_g && i < c.in * H1N + H1N) {   // keep the packed layer-1 image of the updated network current
+        const int j = i / H1N, k = i - j * H1N;
+        c.w1t_g[(j < c.in ? j : W1K - 1) * W1C + k] = pn;
+    }
+}
+
+template <int IN>
+__device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1, float *xs)
+{
+    build_x<IN>(l1.x, xs, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= H1N) return;
+    float gout[IN + 1];
+    l1bwd_wave<IN>(l1.P, xs, l1.D1P, k, lane, gout);
+    float mine = 0.0f;
+#pragma unroll
+    for (int j = 0; j <= IN; ++j) mine = lane == j ? gout[j] : mine;
+    if (lane <= IN) {
+        const int e = lane < IN ? lane * H1N + k : off_b1(IN) + k;
+        l1.grad[e] = mine;                   // the gradient block stays complete for callers that read it after the update
+        adam_elem(c, e, mine);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t gstride)
+{
+    __shared__ float xs[W1K * BP];
     if (gstride) {
         const int64_t off = blockIdx.z * gstride;
-        p = gsh(p, off); g = gsh(g, off); mt = gsh(mt, off); vt = gsh(vt, off); target = gsh(target, off); w1t_g = gsh(w1t_g, off);
+        c.p = gsh(c.p, off); c.g = gsh(c.g, off); c.mt = gsh(c.mt, off); c.vt = gsh(c.vt, off); c.target = gsh(c.target, off);
+        c.w1t_g = gsh(c.w1t_g, off);
+        l1.P = gsh(l1.P, off); gshift(l1.x, off); l1.D1P = gsh(l1.D1P, off); l1.grad = gsh(l1.grad, off);
     }
-    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gf = (float)((double)g[i] * gscale);            // averaged gradient, as every replica holds it
-    const float m1 = (float)(b1 * (double)mt[i] + (1.0 - b1) * (double)gf);
-    const float v1 = (float)(b2 * (double)vt[i] + (1.0 - b2) * ((double)gf * (double)gf));
-    const float delta = (float)((double)m1 / (1.0 - bp1) / (sqrt((double)v1 / (1.0 - bp2)) + eps) * eta);
-    const float pn = p[i] - delta;
-    mt[i] = m1; vt[i] = v1; p[i] = pn;
-    if (publish) publish[i] = pn;
-    const float one_m_tau = 1.0f - tau;
-    target[i] = one_m_tau * target[i] + tau * pn;
-    if (w1t_g && i < in * H1N + H1N) {       // keep the packed layer-1 image of the updated network current
-        const int j = i / H1N, k = i - j * H1N;
-        w1t_g[(j < in ? j : W1K - 1) * W1C + k] = pn;
+    int first = 0;
+    if (l1.on) {
+        first = (c.in + 1) * H1N;
+        if ((int)blockIdx.x < (H1N + 3) / 4) {
+            if (c.in == SIN) adam_l1_rows<SIN>(c, l1, xs); else adam_l1_rows<CIN>(c, l1, xs);
+        }
     }
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c.n) adam_elem(c, i, c.g[i]);
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -911,8 +965,9 @@ static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64
     float *S = slot(ws, SLOT_CRITIC);
     const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d, gs};
     hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
-                       (const float *)(S + SL_D1P), d->grad_critic, gs);
+    if (!d->fuse_l1)
+        hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
+                           (const float *)(S + SL_D1P), d->grad_critic, gs);
     return hip_ok(hipGetLastError(), "ddpg critic_grad launches");
 }
 
@@ -936,18 +991,34 @@ int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0
 }
 
 static int adam_launch(float *p, const float *g, float *m, float *v, float *target, int n, double eta, double bp1, double bp2,
-                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st, unsigned L = 1, int64_t gs = 0)
+                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st, unsigned L, int64_t gs, const L1Src &l1)
 {
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    hipLaunchKernelGGL(k_adam_soft, dim3((n + 255) / 256, 1, L), dim3(256), 0, st, p, g, m, v, target, n, eta, bp1, bp2, gscale, tau, w1t_g, in, publish, gs);
+    const AdamCtx c{p, g, m, v, target, w1t_g, publish, n, in, eta, bp1, bp2, gscale, tau};
+    const int sweep = l1.on ? n - (in + 1) * H1N : n;             // elements the plain sweep covers
+    hipLaunchKernelGGL(k_adam_soft, dim3((sweep + 255) / 256, 1, L), dim3(256), 0, st, c, l1, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
+}
+
+// the layer-1 sources of the two differentiated networks (must match what *_grad_impl hands to k_bwd / k_l1bwd)
+static L1Src l1_critic(const shems_ddpg *d, bool on)
+{
+    float *ws = d->ws;
+    return L1Src{d->critic, XSrc{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr}, slot(ws, SLOT_CRITIC) + SL_D1P, d->grad_critic, on ? 1 : 0};
+}
+static L1Src l1_actor(const shems_ddpg *d, bool on)
+{
+    float *ws = d->ws;
+    return L1Src{d->actor, XSrc{ws + WS_XT, nullptr, nullptr, nullptr, nullptr}, slot(ws, SLOT_ACTOR) + SL_D1P, d->grad_actor, on ? 1 : 0};
 }
 
 int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_apply")) return rc;
+    if (d->fuse_l1 && grad_scale != 1.0)
+        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_apply: fuse_l1 is the single-replica form (grad_scale must be 1)");
     return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2,
-                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream);
+                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream, 1, 0, l1_critic(d, d->fuse_l1 != 0));
 }
 
 int shems_ddpg_group_critic_apply(const shems_ddpg *d, const shems_group *g, double eta, double bp1, double bp2, void *stream)
@@ -956,7 +1027,7 @@ int shems_ddpg_group_critic_apply(const shems_ddpg *d, const shems_group *g, dou
     if (int rc = check_group(g, "shems_ddpg_group_critic_apply")) return rc;
     return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2, 1.0,
                        d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream, (unsigned)g->count,
-                       g->count > 1 ? g->stride_bytes : 0);
+                       g->count > 1 ? g->stride_bytes : 0, l1_critic(d, d->fuse_l1 != 0));
 }
 
 static int actor_grad_impl(const shems_ddpg *d, unsigned L, int64_t gs, void *stream)
@@ -979,8 +1050,9 @@ static int actor_grad_impl(const shems_ddpg *d, unsigned L, int64_t gs, void *st
     float *S = slot(ws, SLOT_ACTOR);
     const BwdArgs b{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ, 2, *d, gs};
     hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
-    hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
-                       (const float *)(S + SL_D1P), d->grad_actor, gs);
+    if (!d->fuse_l1)
+        hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
+                           (const float *)(S + SL_D1P), d->grad_actor, gs);
     return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
 }
 
@@ -997,15 +1069,20 @@ int shems_ddpg_group_actor_apply(const shems_ddpg *d, const shems_group *g, doub
     if (int rc = check_ddpg(d, "shems_ddpg_group_actor_apply")) return rc;
     if (int rc = check_group(g, "shems_ddpg_group_actor_apply")) return rc;
     return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, 1.0,
-                       d->tau, nullptr, (int)SIN, nullptr, (hipStream_t)stream, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0);
+                       d->tau, nullptr, (int)SIN, nullptr, (hipStream_t)stream, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0,
+                       l1_actor(d, d->fuse_l1 != 0));
 }
 
 int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, float *d_publish,
                                void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_apply")) return rc;
+    if (d->fuse_l1 && grad_scale != 1.0)
+        return set_error(SHEMS_ERR_ARG, "shems_ddpg_actor_apply: fuse_l1 is the single-replica form (grad_scale must be 1)");
+    static_assert((SHEMS_CRITIC_PARAMS - (CIN + 1) * H1N + 255) / 256 >= (H1N + 3) / 4 && (SHEMS_ACTOR_PARAMS - (SIN + 1) * H1N + 255) / 256 >= (H1N + 3) / 4,
+                  "the fused ADAM launch needs at least 63 workgroups");
     return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, grad_scale,
-                       d->tau, nullptr, (int)SIN, d_publish, (hipStream_t)stream);
+                       d->tau, nullptr, (int)SIN, d_publish, (hipStream_t)stream, 1, 0, l1_actor(d, d->fuse_l1 != 0));
 }
 
 int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)

@@ -44,7 +44,7 @@ NOISE_ACT = 0.1                                  # noise_act, input.jl:231 (Para
 class DdpgArgs(C.Structure):           # shems_ddpg
     _fields_ = [(n, C.c_void_p) for n in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic",
                                           "v_critic", "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")] + \
-               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("reserved", C.c_int32)]
+               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("fuse_l1", C.c_int32)]
 
 
 class RingWindow(C.Structure):         # shems_ring_window
@@ -187,6 +187,7 @@ class Agent:
         self.bp_critic = [0.9, 0.999]
         self.updates = 0
         self.sync = GradSync(None)                 # replicas exchange gradients through this (RCCL)
+        self.fuse_l1 = True                        # used only while world == 1 (see shems_ddpg.fuse_l1)
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -294,7 +295,8 @@ class Agent:
         return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
                         self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
                         self.grad_actor.data_ptr(), self.grad_critic.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
-                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch, 0)
+                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch,
+                        1 if (self.fuse_l1 and self.sync.world == 1) else 0)     # single replica: gW1/gb1 inside the ADAM launch
 
     def enable_data_parallel(self, dist):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""

@@ -209,3 +209,21 @@ def test_parameter_noise_act_and_adaptation():
     ag.replay(ring)
     assert abs(ag.pn_sigma - sig_ref) < 1e-12 and ag.pn_sigma != sig
     torch.cuda.synchronize()
+
+
+def test_fused_layer1_gradient_is_bit_identical_to_the_separate_launch():
+    """shems_ddpg.fuse_l1 (single replica): gW1/gb1 produced inside the ADAM launch.  Same bytes as the k_l1bwd launch that the
+    data-parallel path keeps (the all-reduce needs the complete gradient before ADAM)."""
+    out = []
+    for fuse in (True, False):
+        torch, S, D, ag, ring, h = _setup(seed=17)
+        ag.fuse_l1 = fuse
+        assert ag._ddpg_args().fuse_l1 == (1 if fuse else 0)
+        for t in range(3):
+            ag.replay(ring, tick=t)
+        torch.cuda.synchronize()
+        out.append({k: getattr(ag, k).clone() for k in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic",
+                                                        "grad_actor", "grad_critic", "losses")})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+    assert float(out[0]["grad_critic"][:3000].abs().max()) > 0 and float(out[0]["grad_actor"][:2500].abs().max()) > 0
