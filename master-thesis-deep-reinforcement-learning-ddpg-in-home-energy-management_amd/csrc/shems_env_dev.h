@@ -100,10 +100,12 @@ __device__ __forceinline__ double block_sum(double x, double *lds4, int nwaves =
 
 // One env, one hour: action -> flows -> next_state! -> bookkeeping.  obs is updated in place.
 // Returns false (and leaves obs untouched) when row idx+1 does not exist (Julia: BoundsError).
-__device__ __forceinline__ bool env_advance(const shems_config &c, const float *tables, float (&obs)[SHEMS_NSTATE],
-                                            int32_t &idx, int32_t &step, float a0, float a1, int track_mode,
-                                            double &reward, StepFlows &f, float &B, float &EV,
-                                            float &B_target, float &EV_target)
+// env_advance_rows takes the two table reads of next_state! (row idx+1 and h_countdown of row idx) as values, so that a caller
+// with latency to hide can fetch them ahead (k_act does, behind its layer-3 epilogue); env_advance reads them in place.
+__device__ __forceinline__ bool env_advance_rows(const shems_config &c, const Row &nx, float h_cur, float (&obs)[SHEMS_NSTATE],
+                                                 int32_t &idx, int32_t &step, float a0, float a1, int track_mode,
+                                                 double &reward, StepFlows &f, float &B, float &EV,
+                                                 float &B_target, float &EV_target)
 {
     if (idx < 1 || idx + 1 > c.nrow) return false;
     const EnvIn s{obs[0], obs[1], obs[2], obs[3], obs[4], obs[5]};
@@ -118,14 +120,23 @@ __device__ __forceinline__ bool env_advance(const shems_config &c, const float *
     step_flows(c, s, EV_target, B, EV, track_mode < 0, soc_b_n, soc_ev_n, reward, f);
 
     // next_state!  LU1:264-281
-    const Row nx = load_row(tables, c.table_row0, idx + 1);
-    const float h_cur = load_h(tables, c.table_row0, idx);
     if (nx.h >= 0.0f && h_cur == -1.0f) soc_ev_n = nx.soc_ev;     // newly connected EV
     obs[0] = soc_b_n; obs[1] = soc_ev_n; obs[2] = nx.h; obs[3] = nx.d_e; obs[4] = nx.g_e;
     obs[5] = nx.p_buy; obs[6] = nx.h_cos; obs[7] = nx.h_sin; obs[8] = nx.season;
     step += 1;                                   // LU1:455
     idx += 1;                                    // LU1:456
     return true;
+}
+
+__device__ __forceinline__ bool env_advance(const shems_config &c, const float *tables, float (&obs)[SHEMS_NSTATE],
+                                            int32_t &idx, int32_t &step, float a0, float a1, int track_mode,
+                                            double &reward, StepFlows &f, float &B, float &EV,
+                                            float &B_target, float &EV_target)
+{
+    if (idx < 1 || idx + 1 > c.nrow) return false;
+    const Row nx = load_row(tables, c.table_row0, idx + 1);
+    const float h_cur = load_h(tables, c.table_row0, idx);
+    return env_advance_rows(c, nx, h_cur, obs, idx, step, a0, a1, track_mode, reward, f, B, EV, B_target, EV_target);
 }
 
 __device__ __forceinline__ void write_results(double *r, int32_t idx_after, const float (&pre)[SHEMS_NSTATE],

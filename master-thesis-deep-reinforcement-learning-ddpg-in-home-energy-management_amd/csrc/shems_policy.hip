@@ -46,6 +46,7 @@ constexpr int kW1K = 12, kW1C = 256;            // layer-1 operand image: rows 0
 constexpr int kOffB1 = kIn * kH1, kOffW2 = kOffB1 + kH1, kOffB2 = kOffW2 + kH1 * kH2, kOffW3 = kOffB2 + kH2,
               kOffB3 = kOffW3 + kH2 * kOut;
 static_assert(kOffB3 + kOut == SHEMS_ACTOR_PARAMS, "actor layout");
+static_assert(kW1K == 12, "L1_GROUP's MFMA chain is written out for 6 k-steps");
 constexpr int kH2P = 512;                       // n padded to 16 MFMA tiles; pad rows carry zero bias / W3
 constexpr int kTailFloats = kH2P + kH2P * kOut + kOut;   // LDS image: b2[512], W3[512][2], b3[2]
 
@@ -167,43 +168,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     const float *__restrict__ s_min = gsh(A.p.s_min, goff), *__restrict__ s_max = gsh(A.p.s_max, goff);
 
     // ---- stage 0: x = normalize(s) -> xT[k][m]; layer-1 image, b2/W3/b3 -> LDS; W2 chunk 0 -> LDS --------------
-    for (int e = tid; e < BM * kIn; e += NT_) {
-        const int m = e / kIn, k = e - m * kIn;
-        const int64_t g = env0 * kIn + e;
-        float x = 0.0f;
-        if (g < A.m * kIn) {
-            const float s = A.obs[g];
-            x = (s - s_min[k]) / ((s_max[k] - s_min[k]) + 1e-8f);      // MPS:56
-        }
-        xT[k * BM + m] = x;
-    }
-    for (int e = tid; e < 3 * BM; e += NT_) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
-    {   // w1[j][k]: j < 9 -> W1[j][k], j == 11 -> b1[k], else 0; columns 250..255 zero (thread = column k)
-        float v[kW1K];
-        const int kc = min(tid, kH1 - 1);
-#pragma unroll
-        for (int j = 0; j < kW1K; ++j) v[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
-        if (tid < kW1C) {
-#pragma unroll
-            for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? v[j] : 0.0f;
-        }
-    }
-    {   // b2 | W3 | b3 are contiguous in the parameter block (1502 floats): 6 clamped loads in flight per thread
-        float v[6];
-#pragma unroll
-        for (int it = 0; it < 6; ++it) v[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int e = tid < 256 ? it * 256 + tid : 1 << 20;   // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
-            if (e < kH2) tl[e] = v[it];
-            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = v[it];
-            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = v[it];
-        }
-        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
-        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
-    }
-    if (tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
-
     // W2 chunk staging, global -> LDS directly (global_load_lds_dwordx4: no staging registers).  A chunk is 16 rows =
     // 32000 contiguous bytes = 31 full 1-KiB wave pieces + one of 256 B (16 lanes); wave w issues pieces w, w+4, ...
     // The LDS image is the linear copy (destination = M0 base + lane*16).  The last chunk holds only rows 240..249
@@ -220,25 +184,85 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     } while (0)
 #define W2_ISSUE(chunk, buf)                                                                      \
     do { _Pragma("unroll") for (int pc_ = wave; pc_ < 32; pc_ += NW) W2_PIECE(chunk, buf, pc_); } while (0)
+#define STAGE0_DMA() W2_ISSUE(0, 0)
+    // Every global load of the stage is issued before the first value is used (obs + normalisation, layer-1 image, b2|W3|b3;
+    // the first W2 chunk goes out by LDS-DMA right behind them): one exposed latency instead of one per block.  Addresses are
+    // clamped, never predicated -- a guarded load becomes a branch with its own s_waitcnt and serialises the batch.
+    constexpr int kIt = (BM * kIn + NT_ - 1) / NT_;
+    float sv[kIt], lo[kIt], hi[kIt], wv[kW1K], tv[6];
+    const int64_t last = A.m * kIn - 1;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = min(it * NT_ + tid, BM * kIn - 1), k = e % kIn;
+        sv[it] = A.obs[min(env0 * kIn + e, last)];
+        lo[it] = s_min[k];
+        hi[it] = s_max[k];
+    }
+    {   // w1[j][k]: j < 9 -> W1[j][k], j == 11 -> b1[k], else 0; columns 250..255 zero (thread = column k)
+        const int kc = min(tid, kH1 - 1);
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) wv[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
+    }
+    // b2 | W3 | b3 are contiguous in the parameter block (1502 floats)
+#pragma unroll
+    for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
+    STAGE0_DMA();
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
+        const float x = (sv[it] - lo[it]) / ((hi[it] - lo[it]) + 1e-8f);      // MPS:56
+        if (e < BM * kIn) xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f;
+    }
+    for (int e = tid; e < 3 * BM; e += NT_) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
+    if (tid < kW1C) {
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? wv[j] : 0.0f;
+    }
+    {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int e = tid < 256 ? it * 256 + tid : 1 << 20;   // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
+            if (e < kH2) tl[e] = tv[it];
+            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = tv[it];
+            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = tv[it];
+        }
+        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
+        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
+    }
+    if (tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
+
     // Layer 1 on the matrix pipe (K = 12 = 6 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
     // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
 #define L1_GROUP(g)                                                                               \
     do {                                                                                          \
         if (wave < TM) {                                                                          \
-            f32x16 t_;                                                                            \
-            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) t_[r_] = 0.0f;                      \
+            float a_[kW1K / 2], b_[kW1K / 2];                                                     \
             _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
                 const int j_ = 2 * s_ + lh;                                                       \
-                t_ = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j_ * kW1C + 32 * (g) + li],          \
-                                                          xT[j_ * BM + 32 * wave + li], t_, 0, 0, 0); \
+                a_[s_] = w1[j_ * kW1C + 32 * (g) + li];                                           \
+                b_[s_] = xT[j_ * BM + 32 * wave + li];                                            \
             }                                                                                     \
+            /* The accumulator of this tile must stay in VGPRs: given the builtin, the compiler parks it in a[0:15] and moves */ \
+            /* a layer-2 accumulator tile out and back around every group (drain + 48 register moves).  Wait states are ours */ \
+            /* inside the string: VALU-written operand -> MFMA (1), chain C = previous D (0), D -> VALU reader (16-pass: 19+). */ \
+            f32x16 t_;                                                                            \
+            asm volatile("s_nop 1\n\t"                                                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %1, %7, 0\n\t"                               \
+                         "v_mfma_f32_32x32x2_f32 %0, %2, %8, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %3, %9, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %4, %10, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %5, %11, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %6, %12, %0\n\t"                             \
+                         "s_nop 15\n\ts_nop 7"                                                    \
+                         : "=&v"(t_)                                                              \
+                         : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]), \
+                           "v"(b_[0]), "v"(b_[1]), "v"(b_[2]), "v"(b_[3]), "v"(b_[4]), "v"(b_[5])); \
             float *dst_ = Hc + ((g) & 1) * (32 * BM) + 32 * wave + li;                            \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
                 dst_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t_[r_], 0.0f);             \
         }                                                                                         \
     } while (0)
 
-    W2_ISSUE(0, 0);
     __syncthreads();                     // xT, w1 visible
     PSTAMP(1);
     L1_GROUP(0);
@@ -313,9 +337,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #pragma unroll
     for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
     const float *w3s = tl + kH2P;
-    // The accumulators live in AGPRs; read them out one row at a time with v_accvgpr_read (asm volatile keeps
-    // program order, which bounds VGPR pressure -- left to itself the compiler copies all 64*TM*4 values first).
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA D -> v_accvgpr_read hazard (nothing pads asm)
+    // The accumulators live in AGPRs; the sched_barrier every four rows keeps the compiler from hoisting all 64*TM*4
+    // v_accvgpr_reads to the top (VGPR pressure).  The reads are the compiler's own, so it pads the MFMA -> read hazard itself
+    // (hand-written asm reads also made it shuffle accumulators between AGPRs to satisfy the operand constraints).
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
@@ -325,9 +349,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);   // rows >= 500: zero weights (and finite h)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                float x;
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[a][b][r]));
-                const float h = fmaxf(x, 0.0f);
+                const float h = fmaxf(acc[a][b][r], 0.0f);
                 o0[b] = fmaf(h, w3.x, o0[b]);
                 o1[b] = fmaf(h, w3.y, o1[b]);
             }
