@@ -87,6 +87,29 @@ __device__ __forceinline__ void glds16(const void *g, void *lds)
                                      (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
 }
 
+// Piece q (0..7) of a wave's 8-KiB LDS-DMA stream.  The instruction's immediate offset is added to the global address AND to
+// the LDS address (M0 base + offset + lane * 16), so both bases point at piece 4 and the piece is chosen by (q - 4) KiB alone:
+// one 64-bit address and one M0 value per chunk.  The builtin wants an integer constant expression, hence the switch.
+template <int Q>
+__device__ __forceinline__ void glds16_imm(const char *base, char *lds)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)base,
+                                     (__attribute__((address_space(3))) void *)lds, 16, (Q - 4) * 1024, 0);
+}
+__device__ __forceinline__ void glds16_piece(const char *base, char *lds, int q)
+{
+    switch (q) {
+    case 0: glds16_imm<0>(base, lds); break;
+    case 1: glds16_imm<1>(base, lds); break;
+    case 2: glds16_imm<2>(base, lds); break;
+    case 3: glds16_imm<3>(base, lds); break;
+    case 4: glds16_imm<4>(base, lds); break;
+    case 5: glds16_imm<5>(base, lds); break;
+    case 6: glds16_imm<6>(base, lds); break;
+    default: glds16_imm<7>(base, lds); break;
+    }
+}
+
 // Standard-normal pair from one Philox block (Box-Muller, f32).
 __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64_t i)
 {
@@ -272,6 +295,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
     f32x16 acc[NA][TM];
     const int nbase = wave * (32 * NA);
+    const char *wbase_ = W2g + kChunkBytes + (8 * wave + 4) * 1024 + lane * 16;      // piece 8w+4 of chunk 1: the base of this wave's LDS-DMA stream
     // the accumulators start at b2[n] (rows >= 500: 0), so the epilogue is relu + two FMAs per element
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -308,7 +332,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                  \
                 if (NA == 4 ? ks < kDmaKs : ((ks & 1) == 0 && h_ == 0)) {                                       \
                     const int pc_ = NA == 4 ? wave + 4 * (2 * ks + h_) : wave + 8 * (ks >> 1);                  \
-                    if (ISSUE == 0 && !ABL_NODMA)                                                               \
+                    if (ISSUE == 0 && !ABL_NODMA && NA == 4) {                                                  \
+                        /* wave w moves the 8 consecutive pieces 8w..8w+7: one 64-bit address per chunk, the */   \
+                        /* piece selected by the instruction's immediate offset (-4096 .. 3072, both sides)  */   \
+                        glds16_piece(wbase_ + (size_t)(c) * kChunkBytes,                                        \
+                                     reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + (8 * wave + 4) * 1024, 2 * ks + h_); \
+                    } else if (ISSUE == 0 && !ABL_NODMA)                                                        \
                         glds16(W2g + ((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16,                          \
                                reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                   \
                     else if (ISSUE == 1 && !ABL_NODMA)   /* short last chunk: source clamped to the end of W2 */ \
