@@ -37,6 +37,10 @@
 namespace shems {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
+template <> struct FVec<1> { typedef float type; };
+template <int N> __device__ __forceinline__ float fvec_get(const typename FVec<N>::type &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float fvec_get<1>(const float &v, int) { return v; }
 
 constexpr int kIn = 9, kH1 = SHEMS_L1, kH2 = SHEMS_L2, kOut = 2;
 constexpr int kKC = 16;                         // k-rows per staged W2 chunk (8 MFMA k-steps)
@@ -132,7 +136,7 @@ constexpr int kDmaKs = 4;   // 4 waves: the 8 LDS-DMA pieces a wave issues per c
 template <int TM, int NA, bool DMA, int NKS>
 __device__ __forceinline__ void sched_chunk()
 {
-    constexpr int DS = (NA + 1) / 2 + (TM + 1) / 2;
+    constexpr int DS = 2;                       // one vector read per operand
     __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
                 const int j_ = 2 * s_ + lh;                                                       \
                 a_[s_] = w1[j_ * kW1C + 32 * (g) + li];                                           \
-                b_[s_] = xT[j_ * BM + 32 * wave + li];                                            \
+                b_[s_] = xT[j_ * BM + TM * li + wave];            /* env column m = TM*j + tile */  \
             }                                                                                     \
             /* The accumulator of this tile must stay in VGPRs: given the builtin, the compiler parks it in a[0:15] and moves */ \
             /* a layer-2 accumulator tile out and back around every group (drain + 48 register moves).  Wait states are ours */ \
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
                          : "=&v"(t_)                                                              \
                          : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]), \
                            "v"(b_[0]), "v"(b_[1]), "v"(b_[2]), "v"(b_[3]), "v"(b_[4]), "v"(b_[5])); \
-            float *dst_ = Hc + ((g) & 1) * (32 * BM) + 32 * wave + li;                            \
+            float *dst_ = Hc + ((g) & 1) * (32 * BM) + TM * li + wave;                            \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
                 dst_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t_[r_], 0.0f);             \
         }                                                                                         \
@@ -294,6 +298,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 
     // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
     f32x16 acc[NA][TM];
+    // Tile (a, b) of a wave covers the columns n = nbase + NA*i + a and the envs m = TM*j + b (i, j = the MFMA row / column index
+    // of a lane): the NA weights and TM activations a lane needs for a k-step are then contiguous in LDS -- ONE ds_read_b128 each
+    // for TM = NA = 4 instead of four strided reads, and a fixed DS count per k-step for the pinned schedule.
+    typedef typename FVec<NA>::type AVec;
+    typedef typename FVec<TM>::type BVec;
     const int nbase = wave * (32 * NA);
     const char *wbase_ = W2g + kChunkBytes + (8 * wave + 4) * 1024 + lane * 16;      // piece 8w+4 of chunk 1: the base of this wave's LDS-DMA stream
     // the accumulators start at b2[n] (rows >= 500: 0), so the epilogue is relu + two FMAs per element
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bias = tl[nbase + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            const float bias = tl[nbase + NA * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a];       // tile a holds the columns n = nbase + NA*i + a
 #pragma unroll
             for (int b = 0; b < TM; ++b) acc[a][b][r] = bias;
         }
@@ -315,20 +324,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     do {                                                                                                        \
         const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
         if (ODD && !ABL_NOL1) L1_GROUP(((c) + 1) >> 1);                                                         \
-        const float *Wb_ = Wc + cur_ * kWcFloats + nbase + li;                                                  \
-        const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + li;                     \
-        float af_[2][NA], bf_[2][TM];                                                                            \
-        _Pragma("unroll") for (int a = 0; a < NA; ++a) af_[0][a] = Wb_[lh * kH2 + 32 * a];                       \
-        _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[0][b] = Hb_[lh * BM + 32 * b];                       \
+        const float *Wb_ = Wc + cur_ * kWcFloats + nbase + NA * li;                                             \
+        const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + TM * li;                \
+        AVec af_[2];                                                                                            \
+        BVec bf_[2];                                                                                            \
+        af_[0] = *reinterpret_cast<const AVec *>(Wb_ + lh * kH2);                                               \
+        bf_[0] = *reinterpret_cast<const BVec *>(Hb_ + lh * BM);                                                \
         _Pragma("unroll") for (int ks = 0; ks < (NKS); ++ks) {                                                  \
             if (ks + 1 < (NKS)) {                                                                               \
                 const int kr_ = 2 * (ks + 1) + lh;                                                              \
-                _Pragma("unroll") for (int a = 0; a < NA; ++a) af_[(ks + 1) & 1][a] = Wb_[kr_ * kH2 + 32 * a];   \
-                _Pragma("unroll") for (int b = 0; b < TM; ++b) bf_[(ks + 1) & 1][b] = Hb_[kr_ * BM + 32 * b];   \
+                af_[(ks + 1) & 1] = *reinterpret_cast<const AVec *>(Wb_ + kr_ * kH2);                           \
+                bf_[(ks + 1) & 1] = *reinterpret_cast<const BVec *>(Hb_ + kr_ * BM);                            \
             }                                                                                                   \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                      \
                 _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                  \
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[ks & 1][a], bf_[ks & 1][b], acc[a][b], 0, 0, 0); \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[ks & 1], a), fvec_get<TM>(bf_[ks & 1], b), acc[a][b], 0, 0, 0); \
             _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                  \
                 if (NA == 4 ? ks < kDmaKs : ((ks & 1) == 0 && h_ == 0)) {                                       \
                     const int pc_ = NA == 4 ? wave + 4 * (2 * ks + h_) : wave + 8 * (ks >> 1);                  \
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the W3 LDS reads near their rows (VGPR pressure)
-            const int n = nbase + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * lh;     // C/D row of v_mfma_f32_32x32x*
+            const int n = nbase + NA * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;   // C/D row i of v_mfma_f32_32x32x* -> column n
             const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);   // rows >= 500: zero weights (and finite h)
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
@@ -389,8 +399,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         o0[b] += __shfl_xor(o0[b], 32, 64);
         o1[b] += __shfl_xor(o1[b], 32, 64);
         if (lh == 0) {
-            red[(wave * BM + 32 * b + li) * 2 + 0] = o0[b];
-            red[(wave * BM + 32 * b + li) * 2 + 1] = o1[b];
+            red[(wave * BM + TM * li + b) * 2 + 0] = o0[b];
+            red[(wave * BM + TM * li + b) * 2 + 1] = o1[b];
         }
     }
     __syncthreads();
