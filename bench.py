@@ -80,20 +80,11 @@ class EnvWorkload:
 
     def kernel_pass(self, reps):
         """HIP-event timing of the dominant kernel alone (events on the launch stream)."""
-        torch = self.torch
-        self.env.reset_(self.seed, episode=1000)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(ev):
-            if i and i % (EP_LEN - 1) == 0:
-                self.env.reset_(self.seed, episode=1000 + i)
-            a.record()
-            self.env.step_dev(self.actions[i % 8], 0, rewards_f32=self.rew32)
-            b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        avg = sum(ms) / len(ms)
-        return dict(kernel="shems::k_step", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+        T = importlib.import_module(PKG + ".timing")
+        reset = lambda g, i: self.env.reset_(self.seed, episode=1000 + i) if g % 8 == 0 else None      # 64 launches < one episode
+        avg, med, reps = T.time_launches(self.torch, lambda i: self.env.step_dev(self.actions[i % 8], 0, rewards_f32=self.rew32),
+                                         reps, before_group=reset)
+        return dict(kernel="shems::k_step", avg_us=avg, median_us=med, launches=reps,
                     bound="hbm", algorithmic=BYTES_PER_ENV_STEP * self.n, unit="GB/s", peak=HBM_PEAK_GBS)
 
     def extra(self):
@@ -131,22 +122,11 @@ class PolicyWorkload(EnvWorkload):
         self.t += 1
 
     def kernel_pass(self, reps):
-        torch = self.torch
-        reps = min(reps, 200)
-        self.env.reset_(self.seed, episode=1000)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(ev):
-            if i and i % (EP_LEN - 1) == 0:
-                self.env.reset_(self.seed, episode=1000 + i)
-            a.record()
-            self._launch(i)
-            b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        avg = sum(ms) / len(ms)
+        T = importlib.import_module(PKG + ".timing")
+        reset = lambda g, i: self.env.reset_(self.seed, episode=1000 + i) if g % 8 == 0 else None
+        avg, med, reps = T.time_launches(self.torch, self._launch, min(reps, 200), before_group=reset)
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n       # 256 500 FLOP per env-step
-        return dict(kernel="shems::k_act<TM>", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+        return dict(kernel="shems::k_act<TM>", avg_us=avg, median_us=med, launches=reps,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
 

@@ -510,19 +510,9 @@ class TrainWorkload:
     def kernel_pass(self, reps):
         """HIP-event timing of the dominant kernel (the fused actor/step launch) on its own stream."""
         torch = self.torch
-        reps = min(reps, 200)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        self.env.reset_(self.env_seed, episode=100000)
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(ev):
-            if i and i % (self.EP_LEN - 1) == 0:
-                self.env.reset_(self.env_seed, episode=100000 + i)
-            a.record()
-            self._act(i)
-            b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        avg = sum(ms) / len(ms)
+        from .timing import time_launches
+        reset = lambda g, i: self.env.reset_(self.env_seed, episode=100000 + i) if g % 8 == 0 else None     # 64 launches < one episode
+        avg_us, med_us, reps = time_launches(torch, self._act, min(reps, 200), before_group=reset)
         # one replay() alone, for the updates/sec breakdown.  This pass runs on rank 0 only: no collective may be issued
         # here (the other ranks are not in this code), so the gradient exchange is switched off for its duration.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -539,7 +529,7 @@ class TrainWorkload:
             self.agent.sync = saved_sync
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
-        return dict(kernel="shems::k_act<TM>", avg_us=avg * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+        return dict(kernel="shems::k_act<TM>", avg_us=avg_us, median_us=med_us, launches=reps,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
 
     def extra(self):

@@ -222,19 +222,11 @@ class GroupWorkload:
     def kernel_pass(self, reps):
         """HIP-event timing of the fused act/step launch (all learners' envs) and of one grouped replay()."""
         torch = self.torch
-        reps = min(reps, 100)
+        from .timing import time_launches
         g = self.group
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        self.env.reset_(self.env_seed, episode=100000)
-        torch.cuda.synchronize()
-        for i, (a, b) in enumerate(ev):
-            if i and i % (self.EP_LEN - 1) == 0:
-                self.env.reset_(self.env_seed, episode=100000 + i)
-            a.record()
-            g.act_step(self.env, train=True, tick=i, window=(g.rings[0].pos, self.win, (i * self.win) % g.envs_per_learner))
-            b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        reset = lambda k, i: self.env.reset_(self.env_seed, episode=100000 + i) if k % 8 == 0 else None
+        act = lambda i: g.act_step(self.env, train=True, tick=i, window=(g.rings[0].pos, self.win, (i * self.win) % g.envs_per_learner))
+        avg_us, med_us, reps = time_launches(torch, act, min(reps, 96), before_group=reset)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         nup = 20
         e0.record()
@@ -244,7 +236,7 @@ class GroupWorkload:
         torch.cuda.synchronize()
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
-        return dict(kernel="shems::k_act<TM>", avg_us=sum(ms) / len(ms) * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=reps,
+        return dict(kernel="shems::k_act<TM>", avg_us=avg_us, median_us=med_us, launches=reps,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
 
     def extra(self):
