@@ -1,0 +1,25 @@
+import sys, os, importlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+PKG="master-thesis-deep-reinforcement-learning-ddpg-in-home-energy-management_amd"
+S=importlib.import_module(PKG); D=importlib.import_module(PKG+".ddpg")
+n=65536
+tab=S.tables.synthetic_table("train",98)
+env=S.ShemsBatch(n,72,[tab],[S.make_config(98,0,tab.shape[0])]).use_torch_stream()
+ag=D.Agent(seed=1)
+env.reset_(1,episode=0)
+st=env.state; ag.set_norm(st.min(0), st.max(0))
+blk=torch.zeros(1024,dtype=torch.float64,device='cuda')
+res=[]
+for t in range(8):
+    ag.act_step(env, train=True, tick=t, block_reward=blk)
+    torch.cuda.synchronize()
+    v=blk.cpu().numpy().view(np.uint64)[:26].reshape(13,2).astype(np.int64)
+    res.append(v.copy())
+v=res[-1]
+t=v[:,0]-v[0,0]; rt=v[:,1]-v[0,1]
+e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+e0.record()
+for k in range(20): ag.act_step(env, train=True, tick=100+k, block_reward=blk)
+e1.record(); torch.cuda.synchronize()
+print(f"{os.path.basename(os.environ.get('SHEMS_HIP_LIB','default')):22s} pro {t[2]:6d}  cyc/chunk(0-13) {(t[3]-t[2])/14:8.1f}  c14 {t[4]-t[3]:6d} c15 {t[10]-t[4]:6d} epi {t[11]-t[10]:6d} env {t[12]-t[11]:6d} total_us {rt[12]/100:6.2f} clk {t[12]/max(1,rt[12])*0.1:.3f}  kernel_us {e0.elapsed_time(e1)*50:.1f}")
