@@ -13,14 +13,17 @@
 //     (A[i = n][k] = W[k][n0+i]: Flux's column-major out x in matrix IS [k][n]) and the activations as
 //     the B operand (B[k][j = m]).  v_mfma_f32_32x32x2_f32: lane l holds A[l&31][l>>5], B[l>>5][l&31].
 //   * layer 2 (97.5 % of the FLOPs): wave w accumulates the 128(n) x BM(m) slab n in [128w, 128w+128)
-//     = 4 x TM tiles of 32x32 (16*4*TM accumulator registers) over K = 250 = 125 MFMA k-steps.
+//     = 4 x TM tiles of 32x32 (16*4*TM accumulator registers) over K = 250 = 125 MFMA k-steps.  Tile (a, b) holds the
+//     columns n = 128w + 4i + a and the envs m = TM*j + b (i, j = a lane's MFMA row / column index), so what a lane needs
+//     per k-step is contiguous in LDS: one ds_read_b128 of weights, one of activations, fetched one k-step ahead.
 //     Both operands are streamed through LDS, double-buffered: W2 in chunks of 16 k-rows by LDS-DMA
-//     (global_load_lds_dwordx4, issued one chunk ahead), and the layer-1 activations relu(W1 x + b1) in
-//     32-row groups that are RECOMPUTED ON THE MATRIX PIPE as well (K = 9 inputs + a bias row, padded to
-//     12 = 6 MFMA k-steps per 32x32 tile, +2.3 % MFMA work) -- cheaper than holding the 250 x BM
-//     activation tile (125 KB at BM = 128) in LDS, and it keeps the VALU out of the main loop (the first
-//     version computed them with FMAs: profiles/r01_train_v1_*).  K is padded 250 -> 256; the pad rows of
-//     layer 1 are exactly zero.
+//     (global_load_lds_dwordx4: wave w moves the 8 consecutive 1-KiB pieces 8w..8w+7 during the first half of the previous
+//     chunk, one 64-bit address and one M0 value per chunk, the piece chosen by the instruction's immediate offset), and the
+//     layer-1 activations relu(W1 x + b1) in 32-row groups that are RECOMPUTED ON THE MATRIX PIPE as well (K = 9 inputs +
+//     a bias row, padded to 12 = 6 MFMA k-steps per 32x32 tile, +2.3 % MFMA work; an inline-asm chain so that its
+//     accumulator stays in VGPRs) -- cheaper than holding the 250 x BM activation tile (125 KB at BM = 128) in LDS, and it
+//     keeps the VALU out of the main loop (the first version computed them with FMAs: profiles/r01_train_v1_*).  N is padded
+//     500 -> 512 (zero bias / W3 rows), the last chunk runs only its 5 real k-steps.
 //   * epilogue: bias + relu on the accumulators, layer 3 (500 -> 2) as per-lane partial dot products
 //     reduced across lane halves (DPP) and the 4 waves (LDS), + b3, tanh, noise, clamp.
 //   * one thread per env then runs scale_action + step! (shems_core.h, exact reference arithmetic)
