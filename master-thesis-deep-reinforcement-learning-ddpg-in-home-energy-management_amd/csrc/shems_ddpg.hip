@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, c
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
 // Single-replica form (shems_ddpg.fuse_l1): no gradient exchange sits between backward and ADAM, so the layer-1 gradient rows are
 // produced HERE instead of by a k_l1bwd launch of their own: workgroup b < 63 computes the rows of hidden units 4b..4b+3 (one wave
-// each, same arithmetic as k_l1bwd), stores them to the gradient block and applies ADAM to exactly those (in + 1) * 4 elements; all
-// workgroups then sweep the elements from b1's end onwards.  No element is read by one workgroup and written by another.
+// each, same arithmetic as k_l1bwd), stores them to the gradient block and applies ADAM to exactly those (in + 1) * 4 elements; the
+// other workgroups sweep the elements from b1's end onwards.  No element is read by one workgroup and written by another.
 struct AdamCtx {
     float *p; const float *g; float *mt, *vt, *target; float *w1t_g; float *publish;
     int n, in; double eta, bp1, bp2, gscale; float tau;
@@ -805,14 +805,17 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t 
         c.w1t_g = gsh(c.w1t_g, off);
         l1.P = gsh(l1.P, off); gshift(l1.x, off); l1.D1P = gsh(l1.D1P, off); l1.grad = gsh(l1.grad, off);
     }
-    int first = 0;
-    if (l1.on) {
-        first = (c.in + 1) * H1N;
-        if ((int)blockIdx.x < (H1N + 3) / 4) {
+    int first = 0, blk = blockIdx.x;
+    if (l1.on) {                                  // the first 63 workgroups ONLY produce + apply the layer-1 rows; the sweep follows them
+        constexpr int kRowWgs = (H1N + 3) / 4;
+        if (blk < kRowWgs) {
             if (c.in == SIN) adam_l1_rows<SIN>(c, l1, xs); else adam_l1_rows<CIN>(c, l1, xs);
+            return;
         }
+        first = (c.in + 1) * H1N;
+        blk -= kRowWgs;
     }
-    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = first + blk * blockDim.x + threadIdx.x;
     if (i < c.n) adam_elem(c, i, c.g[i]);
 }
 
@@ -996,7 +999,8 @@ static int adam_launch(float *p, const float *g, float *m, float *v, float *targ
     if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
     const AdamCtx c{p, g, m, v, target, w1t_g, publish, n, in, eta, bp1, bp2, gscale, tau};
     const int sweep = l1.on ? n - (in + 1) * H1N : n;             // elements the plain sweep covers
-    hipLaunchKernelGGL(k_adam_soft, dim3((sweep + 255) / 256, 1, L), dim3(256), 0, st, c, l1, gs);
+    const int row_wgs = l1.on ? (H1N + 3) / 4 : 0;                // + the workgroups that produce and apply the layer-1 rows
+    hipLaunchKernelGGL(k_adam_soft, dim3(row_wgs + (sweep + 255) / 256, 1, L), dim3(256), 0, st, c, l1, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -1079,8 +1083,6 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
     if (int rc = check_ddpg(d, "shems_ddpg_actor_apply")) return rc;
     if (d->fuse_l1 && grad_scale != 1.0)
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_actor_apply: fuse_l1 is the single-replica form (grad_scale must be 1)");
-    static_assert((SHEMS_CRITIC_PARAMS - (CIN + 1) * H1N + 255) / 256 >= (H1N + 3) / 4 && (SHEMS_ACTOR_PARAMS - (SIN + 1) * H1N + 255) / 256 >= (H1N + 3) / 4,
-                  "the fused ADAM launch needs at least 63 workgroups");
     return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, grad_scale,
                        d->tau, nullptr, (int)SIN, d_publish, (hipStream_t)stream, 1, 0, l1_actor(d, d->fuse_l1 != 0));
 }
