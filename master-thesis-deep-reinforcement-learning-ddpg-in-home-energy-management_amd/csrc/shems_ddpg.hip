@@ -143,7 +143,7 @@ __device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*
 // Layer 1 also runs on the matrix pipe: pre[k][m] = sum_j w1m[j][k] * xs[j][m] with K = 12 = 6 MFMA k-steps, where
 //   w1m [12][256] = rows 0..in-1: W1[j][k]; row 11: b1[k]; everything else (rows in..10, columns 250..255) zero
 //   xs  [12][BP]  = rows 0..in-1: the network input; row 11: 1.0 (bias); rows in..10 zero.
-// The packed image w1m lives in the workspace (k_prep builds it for all four networks at the start of every update, the
+// The packed image w1m lives in the workspace (the update's first launch builds it for all four networks, the
 // critic's ADAM launch refreshes the critic's); staging it is a straight 12 KB float4 copy, three loads per thread.
 constexpr int W1K = 12, W1C = 256;
 __device__ __forceinline__ void stage_w1m(const float *__restrict__ g, float *l)
@@ -180,45 +180,57 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int
     return t;
 }
 
-// ---- kernel A: sample + gather + normalize -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep(shems_ddpg d, shems_replay ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                                              int64_t excl_pos, int64_t excl_count, int64_t gstride)
+// ---- sample + gather + normalize ---------------------------------------------------------------------
+struct PrepArgs {
+    shems_ddpg d;
+    shems_replay ring;
+    int64_t ring_len;
+    uint64_t seed;
+    uint32_t tick;
+    int64_t excl_pos, excl_count;
+};
+// Thread m < BP: minibatch column m.  Samples the ring slot (StatsBase.sample with replacement, MPS:33), gathers the transition and
+// normalises.  xs2 (LDS [.][BP], may be null) receives normalize(s'); when `publish`, everything later launches read goes to the
+// workspace: normalize(s), normalize(s'), a, r, done, d(-mean q)/dq and the sampled slots.
+__device__ __forceinline__ void prep_column(const PrepArgs &A, int m, float *xs2, bool publish)
 {
-    if (gstride) { gshift(d, blockIdx.z * gstride); gshift(ring, blockIdx.z * gstride); seed += blockIdx.z; }   // learner blockIdx.z
+    const shems_ddpg &d = A.d;
+    const shems_replay &ring = A.ring;
     float *ws = d.ws;
-    if (blockIdx.x > 0) {          // workgroups 1..4: packed layer-1 images of actor_t, critic_t, critic, actor
-        const int net = blockIdx.x - 1;
-        const float *P = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
-        pack_w1m(P, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(ws, net));
-        return;
-    }
-    const int m = threadIdx.x;
-    if (m >= BP) return;
     float s[SIN], s2[SIN], a0 = 0.f, a1 = 0.f, r = 0.f, dn = 0.f;
     int64_t j = -1;
     const bool live = m < d.batch;
     if (live) {
-        // StatsBase.sample(rng, memory, BATCH) -- with replacement (MPS:33)
-        const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, A.tick, kStreamSample, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
         const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
-        j = (int64_t)(w % (uint32_t)(ring_len - excl_count));
-        if (excl_count > 0) j = (excl_pos + excl_count + j) % ring.capacity;     // skip the window another stream is writing
+        j = (int64_t)(w % (uint32_t)(A.ring_len - A.excl_count));
+        if (A.excl_count > 0) j = (A.excl_pos + A.excl_count + j) % ring.capacity;     // skip the window another stream is writing
 #pragma unroll
-        for (int k = 0; k < SIN; ++k) { s[k] = ring.s[j * SIN + k]; s2[k] = ring.s2[j * SIN + k]; }
-        a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
-        r = ring.r[j];
-        dn = ring.done[j] ? 1.0f : 0.0f;
+        for (int k = 0; k < SIN; ++k) s2[k] = ring.s2[j * SIN + k];
+        if (publish) {
+#pragma unroll
+            for (int k = 0; k < SIN; ++k) s[k] = ring.s[j * SIN + k];
+            a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
+            r = ring.r[j];
+            dn = ring.done[j] ? 1.0f : 0.0f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < SIN; ++k) {
         const float lo = d.s_min[k], den = (d.s_max[k] - lo) + 1e-8f;                 // MPS:56
-        ws[WS_XT + k * BP + m] = live ? (s[k] - lo) / den : 0.0f;
-        ws[WS_X2T + k * BP + m] = live ? (s2[k] - lo) / den : 0.0f;
+        const float x2 = live ? (s2[k] - lo) / den : 0.0f;
+        if (xs2) xs2[k * BP + m] = x2;
+        if (publish) {
+            ws[WS_XT + k * BP + m] = live ? (s[k] - lo) / den : 0.0f;
+            ws[WS_X2T + k * BP + m] = x2;
+        }
     }
-    ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
-    ws[WS_R + m] = r; ws[WS_DONE + m] = dn;
-    ws[WS_D3Q + m] = live ? -1.0f / (float)d.batch : 0.0f;                            // d(-mean q)/dq
-    reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = (int32_t)j;
+    if (publish) {
+        ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
+        ws[WS_R + m] = r; ws[WS_DONE + m] = dn;
+        ws[WS_D3Q + m] = live ? -1.0f / (float)d.batch : 0.0f;                        // d(-mean q)/dq
+        reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = (int32_t)j;
+    }
 }
 
 // ---- kernel B: layers 1+2 forward for one 32-wide n-tile and all 128 columns --------------------------
@@ -231,7 +243,7 @@ struct FwdJob {
     float *H2;             // [500][BP] or null (target nets: nothing downstream needs it)
     float *P3;             // [NT][2][BP] layer-3 partials of this n-tile
 };
-struct FwdArgs { FwdJob job[3]; int64_t gstride; };
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; };    // prep: this launch opens the update (see fwd_body)
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
     J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
@@ -248,8 +260,8 @@ constexpr int FWD_LDS = (4 * FWD_KH * 32 + 2 * FWD_KH * 32 + W1K * BP + W1K * W1
 #else
 #define STAMP(i)
 #endif
-template <int IN>
-__device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
+template <int IN, bool PREP>
+__device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const PrepArgs *pa)
 {
 #ifdef ABL_STAMP
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(const_cast<float *>(J.P3) + 100000);   // unused part of the slot
@@ -281,8 +293,25 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem)
         const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c);
         wv[it] = k < H1N ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    build_x<IN>(J.x, xs, blockIdx.x == 0);
-    stage_w1m(J.w1t, w1);
+    if (PREP) {
+        // First launch of an update (actor_target on s'): no separate sample/gather/pack launch.  Every workgroup samples the
+        // minibatch and gathers + normalises s' straight into its LDS input block; workgroup 0 also publishes what the later
+        // launches read from the workspace, workgroups 1..4 the packed layer-1 images of the four networks; the image this
+        // launch needs itself is packed from the parameter block.
+        if (tid < BP) prep_column(*pa, tid, xs, blockIdx.x == 0);
+        xs[9 * BP + tid] = 0.0f;                                                    // rows 9, 10 (2 * BP == blockDim)
+        if (tid < BP) xs[11 * BP + tid] = 1.0f;                                     // bias row
+        pack_w1m(P, IN, w1);
+        if (blockIdx.x >= 1 && blockIdx.x <= 4) {
+            const int net = blockIdx.x - 1;
+            const shems_ddpg &d = pa->d;
+            const float *Pn = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
+            pack_w1m(Pn, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(d.ws, net));
+        }
+    } else {
+        build_x<IN>(J.x, xs, blockIdx.x == 0);
+        stage_w1m(J.w1t, w1);
+    }
     if (tid < 96) ep[tid] = epv;
 #pragma unroll
     for (int it = 0; it < 8; ++it) reinterpret_cast<float4 *>(Wc)[it * 256 + tid] = wv[it];
@@ -374,7 +403,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     FwdJob J = A.job[blockIdx.y];
     if (A.gstride) gshift(J, blockIdx.z * A.gstride);
-    if (J.in == SIN) fwd_body<SIN>(J, smem); else fwd_body<CIN>(J, smem);
+    if (A.prep) {                                  // one job, an actor network
+        PrepArgs pa = A.pa;
+        if (A.gstride) { gshift(pa.d, blockIdx.z * A.gstride); gshift(pa.ring, blockIdx.z * A.gstride); pa.seed += blockIdx.z; }   // learner blockIdx.z
+        fwd_body<SIN, true>(J, smem, &pa);
+        return;
+    }
+    if (J.in == SIN) fwd_body<SIN, false>(J, smem, nullptr); else fwd_body<CIN, false>(J, smem, nullptr);
 }
 
 // ---- critic loss head, evaluated in the prologue of every bwd(critic) workgroup (cheaper than a launch boundary) --------
@@ -951,7 +986,6 @@ static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64
         return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad_ex: an exclusion window needs a full ring and 0 <= count < capacity");
     hipStream_t st = (hipStream_t)stream;
     float *ws = d->ws;
-    hipLaunchKernelGGL(k_prep, dim3(5, 1, L), dim3(256), 0, st, *d, *ring, ring_len, seed, tick, excl_pos, excl_count, gs);
     const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
     const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
@@ -960,7 +994,10 @@ static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64
     std::memset(&f, 0, sizeof f);
     f.gstride = gs;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
+    f.prep = 1;                                    // sample + gather + normalise + layer-1 image packing ride in this launch
+    f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
     hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1, L), dim3(256), FWD_LDS, st, f);
+    f.prep = 0;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
     f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
     f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
