@@ -534,6 +534,23 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
     const int kt = b >> 2, nq = b & 3;
     const int mcol = tid & 127, half = tid >> 7;
 
+    // The H2 panel (and, for the input-gradient tiles, the W2 panel) does not depend on the error signal: its loads go out before
+    // the head is evaluated, so the two global latencies overlap instead of following each other.
+    float hv[64], wvp[16];
+    const float *__restrict__ W2p = P + off_w2(IN);
+    if (is_w) {
+#pragma unroll
+        for (int u = 0; u < 64; ++u) hv[u] = A.H2[min(nq * 128 + 2 * u + half, H2N - 1) * BP + mcol];
+    } else if (!is_g) {
+#pragma unroll
+        for (int u = 0; u < 63; ++u) hv[u] = A.H2[(nq * NQW + min(2 * u + half, NQW - 1)) * BP + mcol];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = min(u * 256 + tid, 32 * 126 - 1), kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
+            const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + nq * NQW + min(nl, NQW - 1)];
+            wvp[u] = (k < H1N && nl < NQW) ? t : 0.0f;
+        }
+    }
     build_x<IN>(A.x, xs, false);
     stage_w1m(A.w1t, w1);
     if (A.head == 1) head_loss(A.dd, d3, red, blockIdx.x == 0);
@@ -563,9 +580,6 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         const int nbase = nq * 128;
         // D2^T panel Bt[m][nl], nl = 2*it + half: 64 rows per thread, all 64 H2 loads in flight at once (W3 comes from LDS)
         {
-            float hv[64];
-#pragma unroll
-            for (int u = 0; u < 64; ++u) hv[u] = A.H2[min(nbase + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
             for (int u = 0; u < 64; ++u) {
                 const int nl = 2 * u + half, n = nbase + nl;                    // rows >= 500: W3 image is zero there
@@ -638,9 +652,6 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         const int nb = nq * NQW;                // 125 n, padded with one zero row to 63 MFMA pairs
         // D2 panel Bt[nl][m], nl = 2*it + half, it < 63 (row 125 = 0): all H2 loads of the thread in flight at once
         {
-            float hv[63];
-#pragma unroll
-            for (int u = 0; u < 63; ++u) hv[u] = A.H2[(nb + min(2 * u + half, NQW - 1)) * BP + mcol];
 #pragma unroll
             for (int u = 0; u < 63; ++u) {
                 const int nl = 2 * u + half;
@@ -649,19 +660,11 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
         // W2 panel At[kl][nl] (row stride 127): 32 x 126 elements, 16 loads in flight per thread
-        const float *__restrict__ W2 = P + off_w2(IN);
         {
-            float wv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = min(u * 256 + tid, 32 * 126 - 1), kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
-                const float t = W2[(int64_t)min(k, H1N - 1) * H2N + nb + min(nl, NQW - 1)];
-                wv[u] = (k < H1N && nl < NQW) ? t : 0.0f;
-            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int e = u * 256 + tid, kl = e / 126, nl = e - kl * 126;
-                if (e < 32 * 126) At[kl * 127 + nl] = wv[u];
+                if (e < 32 * 126) At[kl * 127 + nl] = wvp[u];
             }
         }
         __syncthreads();
