@@ -518,6 +518,14 @@ __device__ __forceinline__ float d2_val(float h2, int out, float w3a, float w3b,
 template <int IN>
 __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 {
+#ifdef ABL_STAMP
+    unsigned long long *bst = reinterpret_cast<unsigned long long *>(A.D1P + NQ * H1N * BP - 4096) + (((int)blockIdx.x == 0) ? 0 : 32);
+    const bool bst_on = threadIdx.x == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == A.n_w + (A.n_w > 0 ? (int)BWD_NG : 0));
+#define BSTAMP(i) do { if (bst_on) { bst[2*(i)] = __builtin_amdgcn_s_memtime(); bst[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BSTAMP(i)
+#endif
+    BSTAMP(0);
     float *Bt = smem;                          // W: [128 m][129] D2^T panel;  I: [126 n][128 m] D2 panel
     float *At = Bt + BP * 129;                 // W: [128 m][33] h1^T panel; I: [32 k][127] W2 panel
     float *xs = At + 33 * 128;                 // [12][BP]
@@ -570,6 +578,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         }
     }
     __syncthreads();
+    BSTAMP(1);
     const float d3a = d3[mcol], d3b = d3[BP + mcol];
 
     f32x16 acc;
@@ -594,6 +603,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
         }
         __syncthreads();
+        BSTAMP(2);
         const float *pa = At + li, *pb = Bt + wave * 32 + li;
         {   // 64 MFMA pairs, operand fetch software-pipelined one group (8 pairs) ahead
             float ac[8], bc[8], an[8], bn[8];
@@ -614,6 +624,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
                 for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
             }
         }
+        BSTAMP(3);
         float *gW2 = A.grad + off_w2(IN);
         const int n = nbase + wave * 32 + li;
 #pragma unroll
@@ -668,6 +679,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
         __syncthreads();
+        BSTAMP(2);
         const float *pa = At + li * 127, *pb = Bt + wave * 32 + li;
         {   // 63 MFMA pairs (7 groups of 9), operand fetch one group ahead
             float ac[9], bc[9], an[9], bn[9];
@@ -688,6 +700,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
                 for (int u = 0; u < 9; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
             }
         }
+        BSTAMP(3);
         const int m = wave * 32 + li;
         float *D1 = A.D1P + (int64_t)nq * H1N * BP;
         float da0 = 0.0f, da1 = 0.0f;
@@ -714,6 +727,7 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
     }
+    BSTAMP(4);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_bwd(BwdArgs A)
