@@ -20,7 +20,7 @@
 //     (global_load_lds_dwordx4: wave w moves the 8 consecutive 1-KiB pieces 8w..8w+7 during the first half of the previous
 //     chunk, one 64-bit address and one M0 value per chunk, the piece chosen by the instruction's immediate offset), and the
 //     layer-1 activations relu(W1 x + b1) in 32-row groups that are RECOMPUTED ON THE MATRIX PIPE as well (K = 9 inputs +
-//     a bias row, padded to 12 = 6 MFMA k-steps per 32x32 tile, +2.3 % MFMA work; an inline-asm chain so that its
+//     a bias row = 10 = 5 MFMA k-steps per 32x32 tile, +1.9 % MFMA work; an inline-asm chain so that its
 //     accumulator stays in VGPRs) -- cheaper than holding the 250 x BM activation tile (125 KB at BM = 128) in LDS, and it
 //     keeps the VALU out of the main loop (the first version computed them with FMAs: profiles/r01_train_v1_*).  N is padded
 //     500 -> 512 (zero bias / W3 rows), the last chunk runs only its 5 real k-steps.
@@ -28,7 +28,7 @@
 //     reduced across lane halves (DPP) and the 4 waves (LDS), + b3, tanh, noise, clamp.
 //   * one thread per env then runs scale_action + step! (shems_core.h, exact reference arithmetic)
 //     and pushes the transition into the HBM replay ring.
-// LDS: 2 x 32 KB (W2 chunks) + 2 x 32*BM*4 (layer-1 groups) + x (12*BM*4) + layer-1 image 12 KB + b2/W3/b3 6 KB.
+// LDS: 2 x 32 KB (W2 chunks) + 2 x 32*BM*4 (layer-1 groups) + x (10*BM*4) + layer-1 image 10 KB + b2/W3/b3 6 KB.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -49,11 +49,11 @@ constexpr int kIn = 9, kH1 = SHEMS_L1, kH2 = SHEMS_L2, kOut = 2;
 constexpr int kKC = 16;                         // k-rows per staged W2 chunk (8 MFMA k-steps)
 constexpr int kChunks = 16;                     // K = 250 padded to 256: the padded rows of layer 1 are exactly 0
 constexpr int kWcFloats = 8192 + 16;             // 32 whole 1-KiB LDS-DMA pieces (16 rows = 8000 floats, + 192 of the next row) + read pad
-constexpr int kW1K = 12, kW1C = 256;            // layer-1 operand image: rows 0..8 W1[j][k], row 11 b1[k], rest 0
+constexpr int kW1K = 10, kW1C = 256;            // layer-1 operand image: rows 0..8 W1[j][k], row 9 b1[k] (K = 9 inputs + bias = 5 MFMA k-steps)
 constexpr int kOffB1 = kIn * kH1, kOffW2 = kOffB1 + kH1, kOffB2 = kOffW2 + kH1 * kH2, kOffW3 = kOffB2 + kH2,
               kOffB3 = kOffW3 + kH2 * kOut;
 static_assert(kOffB3 + kOut == SHEMS_ACTOR_PARAMS, "actor layout");
-static_assert(kW1K == 12, "L1_GROUP's MFMA chain is written out for 6 k-steps");
+static_assert(kW1K == 10 && kIn == 9, "L1_GROUP's MFMA chain is written out for 5 k-steps: 9 inputs + the bias row");
 constexpr int kH2P = 512;                       // n padded to 16 MFMA tiles; pad rows carry zero bias / W3
 constexpr int kTailFloats = kH2P + kH2P * kOut + kOut;   // LDS image: b2[512], W3[512][2], b3[2]
 
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Wc = reinterpret_cast<float *>(smem);             // [2][kWcFloats]   W2 chunks (16 rows x 500)
     float *Hc = Wc + 2 * kWcFloats;                          // [2][32][BM]      relu(layer 1), 32-row groups
-    float *xT = Hc + 2 * 32 * BM;                            // [12][BM]  normalised obs (rows 0..8), row 11 = 1 (bias), rest 0
-    float *w1 = xT + kW1K * BM;                              // [12][256] layer-1 operand image
+    float *xT = Hc + 2 * 32 * BM;                            // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
+    float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
     float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
 
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         lo[it] = s_min[k];
         hi[it] = s_max[k];
     }
-    {   // w1[j][k]: j < 9 -> W1[j][k], j == 11 -> b1[k], else 0; columns 250..255 zero (thread = column k)
+    {   // w1[j][k]: j < 9 -> W1[j][k], j == 9 -> b1[k]; columns 250..255 zero (thread = column k)
         const int kc = min(tid, kH1 - 1);
 #pragma unroll
         for (int j = 0; j < kW1K; ++j) wv[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         const float x = (sv[it] - lo[it]) / ((hi[it] - lo[it]) + 1e-8f);      // MPS:56
         if (e < BM * kIn) xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f;
     }
-    for (int e = tid; e < 3 * BM; e += NT_) xT[kIn * BM + e] = e < 2 * BM ? 0.0f : 1.0f;      // rows 9, 10 = 0; row 11 = 1
+    for (int e = tid; e < BM; e += NT_) xT[kIn * BM + e] = 1.0f;                               // row 9 = 1: the bias input
     if (tid < kW1C) {
 #pragma unroll
         for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? wv[j] : 0.0f;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     }
     if (tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
 
-    // Layer 1 on the matrix pipe (K = 12 = 6 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
+    // Layer 1 on the matrix pipe (K = 10 = 5 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
     // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
 #define L1_GROUP(g)                                                                               \
     do {                                                                                          \
@@ -277,16 +277,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             /* inside the string: VALU-written operand -> MFMA (1), chain C = previous D (0), D -> VALU reader (16-pass: 19+). */ \
             f32x16 t_;                                                                            \
             asm volatile("s_nop 1\n\t"                                                            \
-                         "v_mfma_f32_32x32x2_f32 %0, %1, %7, 0\n\t"                               \
-                         "v_mfma_f32_32x32x2_f32 %0, %2, %8, %0\n\t"                              \
-                         "v_mfma_f32_32x32x2_f32 %0, %3, %9, %0\n\t"                              \
-                         "v_mfma_f32_32x32x2_f32 %0, %4, %10, %0\n\t"                             \
-                         "v_mfma_f32_32x32x2_f32 %0, %5, %11, %0\n\t"                             \
-                         "v_mfma_f32_32x32x2_f32 %0, %6, %12, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %1, %6, 0\n\t"                               \
+                         "v_mfma_f32_32x32x2_f32 %0, %2, %7, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %3, %8, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %4, %9, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"                             \
                          "s_nop 15\n\ts_nop 7"                                                    \
                          : "=&v"(t_)                                                              \
-                         : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]), "v"(a_[5]), \
-                           "v"(b_[0]), "v"(b_[1]), "v"(b_[2]), "v"(b_[3]), "v"(b_[4]), "v"(b_[5])); \
+                         : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]),            \
+                           "v"(b_[0]), "v"(b_[1]), "v"(b_[2]), "v"(b_[3]), "v"(b_[4]));           \
             float *dst_ = Hc + ((g) & 1) * (32 * BM) + TM * li + wave;                            \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
                 dst_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t_[r_], 0.0f);             \
