@@ -36,8 +36,8 @@ constexpr int H1N = SHEMS_L1, H2N = SHEMS_L2;
 constexpr int SIN = 9, AIN = 2, CIN = 11;
 constexpr int NT = 16;             // n-tiles of 32 over the 500 (512) layer-2 outputs
 constexpr int KT = 8;              // k-tiles of 32 over the 250 (256) layer-1 outputs
-constexpr int NQ = 4;              // quarters of the n range for the input-gradient tiles
-constexpr int NQW = H2N / NQ;      // 125 n per quarter
+constexpr int NQ = 8;              // blocks of the n range for the backward tiles
+constexpr int NQW = 64;            // n per block (the last block holds the 52 columns 448..499)
 
 __host__ __device__ constexpr int off_b1(int in) { return in * H1N; }
 __host__ __device__ constexpr int off_w2(int in) { return in * H1N + H1N; }
@@ -506,7 +506,9 @@ __device__ __forceinline__ void gshift(BwdArgs &B, int64_t off)
 }
 enum { BWD_NG = 8 };
 
-constexpr int BWD_LDS = (BP * 129 + 33 * 128 + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8) * 4;
+constexpr int BWD_BT = BP * (NQW + 1);                       // W: [128 m][65] D2^T panel (>= I: [64 n][128 m] D2 panel)
+constexpr int BWD_AT = BP * 33;                              // W: [128 m][33] h1^T panel (>= I: [32 k][65] W2 panel)
+constexpr int BWD_LDS = (BWD_BT + BWD_AT + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8) * 4;
 
 // D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
 __device__ __forceinline__ float d2_val(float h2, int out, float w3a, float w3b, float d3a, float d3b)
@@ -526,9 +528,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 #define BSTAMP(i)
 #endif
     BSTAMP(0);
-    float *Bt = smem;                          // W: [128 m][129] D2^T panel;  I: [126 n][128 m] D2 panel
-    float *At = Bt + BP * 129;                 // W: [128 m][33] h1^T panel; I: [32 k][127] W2 panel
-    float *xs = At + 33 * 128;                 // [12][BP]
+    float *Bt = smem;                          // W: [128 m][65] D2^T panel;  I: [64 n][128 m] D2 panel
+    float *At = Bt + BWD_BT;                   // W: [128 m][33] h1^T panel; I: [32 k][65] W2 panel
+    float *xs = At + BWD_AT;                   // [12][BP]
     float *w1 = xs + W1K * BP;                 // w1m [12][256]
     float *d3 = w1 + W1K * W1C;                // [2][BP]
     float *w3s = d3 + AIN * BP;                // W3 [512][2] (out == 1: [.][0] only), zero beyond row 499
@@ -539,24 +541,23 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
     const int n_g = A.n_w > 0 ? (int)BWD_NG : 0;
     const bool is_w = (int)blockIdx.x < A.n_w, is_g = !is_w && (int)blockIdx.x < A.n_w + n_g;
     const int b = is_w ? blockIdx.x : blockIdx.x - A.n_w - n_g;
-    const int kt = b >> 2, nq = b & 3;
+    const int kt = b >> 3, nq = b & 7;                           // (k-tile of 32, n-block of 64)
     const int mcol = tid & 127, half = tid >> 7;
 
     // The H2 panel (and, for the input-gradient tiles, the W2 panel) does not depend on the error signal: its loads go out before
     // the head is evaluated, so the two global latencies overlap instead of following each other.
-    float hv[64], wvp[16];
+    float hv[32], wvp[8];
     const float *__restrict__ W2p = P + off_w2(IN);
-    if (is_w) {
+    if (!is_g) {                                  // W and I tiles of a block read the same 64 rows of H2
 #pragma unroll
-        for (int u = 0; u < 64; ++u) hv[u] = A.H2[min(nq * 128 + 2 * u + half, H2N - 1) * BP + mcol];
-    } else if (!is_g) {
+        for (int u = 0; u < 32; ++u) hv[u] = A.H2[min(nq * NQW + 2 * u + half, H2N - 1) * BP + mcol];
+        if (!is_w) {
 #pragma unroll
-        for (int u = 0; u < 63; ++u) hv[u] = A.H2[(nq * NQW + min(2 * u + half, NQW - 1)) * BP + mcol];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = min(u * 256 + tid, 32 * 126 - 1), kl = e / 126, nl = e - kl * 126, k = kt * 32 + kl;
-            const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + nq * NQW + min(nl, NQW - 1)];
-            wvp[u] = (k < H1N && nl < NQW) ? t : 0.0f;
+            for (int u = 0; u < 8; ++u) {
+                const int e = u * 256 + tid, kl = e >> 6, nl = e & 63, k = kt * 32 + kl, n = nq * NQW + nl;
+                const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + min(n, H2N - 1)];
+                wvp[u] = (k < H1N && n < H2N) ? t : 0.0f;
+            }
         }
     }
     build_x<IN>(A.x, xs, false);
@@ -586,14 +587,15 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
     if (is_w) {
-        const int nbase = nq * 128;
-        // D2^T panel Bt[m][nl], nl = 2*it + half: 64 rows per thread, all 64 H2 loads in flight at once (W3 comes from LDS)
+        const int nbase = nq * NQW;
+        // D2^T panel Bt[m][nl] (row stride 65), nl = 2*u + half: 32 rows per thread from the loads issued above (W3 comes from LDS;
+        // rows >= 500 meet the zero rows of its image)
         {
 #pragma unroll
-            for (int u = 0; u < 64; ++u) {
-                const int nl = 2 * u + half, n = nbase + nl;                    // rows >= 500: W3 image is zero there
+            for (int u = 0; u < 32; ++u) {
+                const int nl = 2 * u + half, n = nbase + nl;
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
-                Bt[mcol * 129 + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
+                Bt[mcol * (NQW + 1) + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
             }
         }
         // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe
@@ -604,18 +606,21 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         }
         __syncthreads();
         BSTAMP(2);
-        const float *pa = At + li, *pb = Bt + wave * 32 + li;
-        {   // 64 MFMA pairs, operand fetch software-pipelined one group (8 pairs) ahead
+        // wave (nt, mh): the 32 x 32 tile of columns [32 nt, +32) over the batch half [64 mh, +64): 32 MFMA pairs, operand fetch
+        // one group (8 pairs) ahead; the two halves are added through LDS
+        const int nt = wave & 1, mh = wave >> 1;
+        const float *pa = At + (64 * mh) * 33 + li, *pb = Bt + (64 * mh) * (NQW + 1) + nt * 32 + li;
+        {
             float ac[8], bc[8], an[8], bn[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * 129]; }
+            for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * (NQW + 1)]; }
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if (g < 7) {
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int mm = 2 * ((g + 1) * 8 + u) + lh;
-                        an[u] = pa[mm * 33]; bn[u] = pb[mm * 129];
+                        an[u] = pa[mm * 33]; bn[u] = pb[mm * (NQW + 1)];
                     }
                 }
 #pragma unroll
@@ -625,12 +630,21 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
         BSTAMP(3);
-        float *gW2 = A.grad + off_w2(IN);
-        const int n = nbase + wave * 32 + li;
+        __syncthreads();                            // everybody is done with the panels: Bt doubles as the exchange buffer
+        float *xch = Bt + nt * (16 * 64);
+        if (mh == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r];
+            for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (mh == 0) {
+            float *gW2 = A.grad + off_w2(IN);
+            const int n = nbase + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r] + xch[r * 64 + lane];
+            }
         }
     } else if (is_g) {
         // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: 8 workgroups x 64 rows, one wave per row, 8 rows in flight
@@ -660,44 +674,44 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
     } else {
-        const int nb = nq * NQW;                // 125 n, padded with one zero row to 63 MFMA pairs
-        // D2 panel Bt[nl][m], nl = 2*it + half, it < 63 (row 125 = 0): all H2 loads of the thread in flight at once
+        const int nb = nq * NQW;
+        // D2 panel Bt[nl][m], nl = 2*u + half < 64 (rows >= 500: zero through the W3 image)
         {
 #pragma unroll
-            for (int u = 0; u < 63; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int nl = 2 * u + half;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * (nb + min(nl, NQW - 1)));
-                Bt[nl * BP + mcol] = nl < NQW ? d2_val(hv[u], 2, w.x, w.y, d3a, d3b) : 0.0f;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * (nb + nl));
+                Bt[nl * BP + mcol] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
             }
         }
-        // W2 panel At[kl][nl] (row stride 127): 32 x 126 elements, 16 loads in flight per thread
+        // W2 panel At[kl][nl] (row stride 65): 32 x 64 elements from the loads issued above
         {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = u * 256 + tid, kl = e / 126, nl = e - kl * 126;
-                if (e < 32 * 126) At[kl * 127 + nl] = wvp[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = u * 256 + tid, kl = e >> 6, nl = e & 63;
+                At[kl * (NQW + 1) + nl] = wvp[u];
             }
         }
         __syncthreads();
         BSTAMP(2);
-        const float *pa = At + li * 127, *pb = Bt + wave * 32 + li;
-        {   // 63 MFMA pairs (7 groups of 9), operand fetch one group ahead
-            float ac[9], bc[9], an[9], bn[9];
+        const float *pa = At + li * (NQW + 1), *pb = Bt + wave * 32 + li;
+        {   // 32 MFMA pairs (4 groups of 8), operand fetch one group ahead
+            float ac[8], bc[8], an[8], bn[8];
 #pragma unroll
-            for (int u = 0; u < 9; ++u) { ac[u] = pa[2 * u + lh]; bc[u] = pb[(2 * u + lh) * BP]; }
+            for (int u = 0; u < 8; ++u) { ac[u] = pa[2 * u + lh]; bc[u] = pb[(2 * u + lh) * BP]; }
 #pragma unroll
-            for (int g = 0; g < 7; ++g) {
-                if (g < 6) {
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) {
 #pragma unroll
-                    for (int u = 0; u < 9; ++u) {
-                        const int nn = 2 * ((g + 1) * 9 + u) + lh;
+                    for (int u = 0; u < 8; ++u) {
+                        const int nn = 2 * ((g + 1) * 8 + u) + lh;
                         an[u] = pa[nn]; bn[u] = pb[nn * BP];
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 9; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 9; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+                for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
             }
         }
         BSTAMP(3);
