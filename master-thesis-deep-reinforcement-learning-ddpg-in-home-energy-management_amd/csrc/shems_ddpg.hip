@@ -243,38 +243,51 @@ struct FwdJob {
     float *H2;             // [500][BP] or null (target nets: nothing downstream needs it)
     float *P3;             // [NT][2][BP] layer-3 partials of this n-tile
 };
-struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; };    // prep: this launch opens the update (see fwd_body)
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; int mt; PrepArgs pa; };    // prep: this launch opens the update (see fwd_body)
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
     J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
 }
 
-// Workgroup = one 32-wide n-tile x one 64-column half of the batch; its 4 waves split the work as (m-tile, K-half):
-// wave w computes columns [64*mh + 32*(w&1), +32) over hidden units [128*(w>>1), +128) (125 real rows + zero pad), so the two
-// K halves run concurrently on different SIMDs; the upper pair's accumulators are added through LDS at the end.
-constexpr int FWD_KH = 128;                                   // k rows per K-half (64 MFMA pairs; rows 250..255 are zero)
-constexpr int FWD_LDS = (4 * FWD_KH * 32 + 2 * FWD_KH * 32 + W1K * BP + W1K * W1C + 96) * 4;
+// Workgroup = one 32-wide n-tile x MT columns of the batch.  K is always cut into four quarters of 64 hidden units (rows 250..255 are
+// zero), each accumulated as its own 32-MFMA chain and added in the fixed order ((q0 + q1) + q2) + q3, so both shapes give the
+// same bits:
+//   MT = 32 (a single learner: 64 workgroups per network, latency): the 4 waves take one K quarter each;
+//   MT = 64 (learner groups of >= 8: 32 workgroups per network, half the redundant panel loads): wave w takes the column tile
+//            w & 1 and the K half w >> 1, i.e. two quarters with an accumulator each.
+// Waves with a K part other than the first hand their accumulators to the first through LDS at the end.
+constexpr int FWD_KQ = 64;                                    // k rows per K-quarter (32 MFMA pairs)
+template <int MT> struct FwdShape {
+    static constexpr int NMW = MT / 32;                       // column tiles (waves) per workgroup
+    static constexpr int NKW = 4 / NMW;                       // K parts (waves) per column tile
+    static constexpr int KPW = 256 / NKW;                     // k rows per wave
+    static constexpr int QPW = KPW / FWD_KQ;                  // K quarters per wave
+    static constexpr int LDS = (4 * KPW * 32 + 256 * 32 + W1K * BP + W1K * W1C + 96) * 4;
+};
+constexpr int FWD_LDS = FwdShape<64>::LDS;                    // the larger of the two
 
 #ifdef ABL_STAMP
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { stamps[2*(i)] = __builtin_amdgcn_s_memtime(); stamps[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(i)
 #endif
-template <int IN, bool PREP>
+template <int IN, bool PREP, int MT>
 __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const PrepArgs *pa)
 {
+    typedef FwdShape<MT> SH;
 #ifdef ABL_STAMP
     unsigned long long *stamps = reinterpret_cast<unsigned long long *>(const_cast<float *>(J.P3) + 100000);   // unused part of the slot
 #endif
     STAMP(0);
-    float *Hc = smem;                          // [4 waves][128][32]  relu(layer 1): this wave's K-half x its 32 columns
-    float *Wc = Hc + 4 * FWD_KH * 32;          // [2 K-halves][128][32]  W2 panel (rows >= 250: zero)
-    float *xs = Wc + 2 * FWD_KH * 32;          // [12][BP]
+    float *Hc = smem;                          // [4 waves][KPW][32]  relu(layer 1): this wave's K part x its 32 columns
+    float *Wc = Hc + 4 * SH::KPW * 32;         // [256][32]  W2 panel (rows >= 250: zero)
+    float *xs = Wc + 256 * 32;                 // [12][BP]
     float *w1 = xs + W1K * BP;                 // w1m [12][256]
     float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int n0 = (blockIdx.x >> 1) * 32, mh = blockIdx.x & 1;
-    const int kh = wave >> 1, mbase = 64 * mh + 32 * (wave & 1);
+    constexpr int kMTiles = BP / MT;           // workgroups per n-tile
+    const int n0 = ((int)blockIdx.x / kMTiles) * 32;
+    const int mt = wave % SH::NMW, kh = wave / SH::NMW, mbase = MT * ((int)blockIdx.x % kMTiles) + 32 * mt;
     const float *__restrict__ P = J.P;
 
     float epv = 0.0f;
@@ -318,13 +331,14 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     __syncthreads();
     STAMP(1);
 
-    // layer 1 on the matrix pipe: 4 tiles (128 rows of this K-half) x this wave's 32 columns; the four accumulator chains
-    // are independent, so their MFMAs interleave
-    float *Hw = Hc + wave * (FWD_KH * 32);
+    // layer 1 on the matrix pipe: KPW / 32 tiles (the rows of this wave's K part) x its 32 columns; the accumulator chains are
+    // independent, so their MFMAs interleave
+    float *Hw = Hc + wave * (SH::KPW * 32);
     {
-        f32x16 t[4];
+        constexpr int NT1 = SH::KPW / 32;
+        f32x16 t[NT1];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT1; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[q][r] = 0.0f;
 #pragma unroll
@@ -332,28 +346,29 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
             const int j = 2 * sidx + lh;
             const float xb = xs[j * BP + mbase + li];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j * W1C + FWD_KH * kh + 32 * q + li], xb, t[q], 0, 0, 0);
+            for (int q = 0; q < NT1; ++q)
+                t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j * W1C + SH::KPW * kh + 32 * q + li], xb, t[q], 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT1; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Hw[(32 * q + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = fmaxf(t[q][r], 0.0f);
     }
     STAMP(2);
     // this wave reads only its own Hw columns: no barrier needed between the layer-1 writes and the main loop
-    f32x16 acc;
+    f32x16 accq[SH::QPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    {
-        // 64 MFMA pairs over this K-half, operand fetch software-pipelined one group (8 pairs) ahead
-        const float *pa = Wc + kh * (FWD_KH * 32) + li, *pb = Hw + li;
+    for (int qq = 0; qq < SH::QPW; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accq[qq][r] = 0.0f;
+        // 32 MFMA pairs over one K quarter, operand fetch software-pipelined one group (8 pairs) ahead
+        const float *pa = Wc + (SH::KPW * kh + FWD_KQ * qq) * 32 + li, *pb = Hw + FWD_KQ * qq * 32 + li;
         float ac[8], bc[8], an[8], bn[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 32]; bc[u] = pb[(2 * u + lh) * 32]; }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g < 7) {
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int kk = 2 * ((g + 1) * 8 + u) + lh;
@@ -361,23 +376,30 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) accq[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], accq[qq], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
         }
     }
     STAMP(3);
-    // add the two K halves: waves 2,3 hand their accumulators to waves 0,1 through LDS (Hc is free once everybody is here)
+    // add the four K quarters in the fixed order ((q0 + q1) + q2) + q3: the waves of the later K parts hand their accumulators to the
+    // first one of their column tile through LDS (Hc is free once everybody is here)
     __syncthreads();
-    float *xch = Hc + (wave & 1) * (16 * 64);
-    if (kh == 1) {
+    float *xch = Hc + mt * (3 * 16 * 64);                     // [quarter 1..3][16][64] of this column tile
+    if (kh != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
+        for (int qq = 0; qq < SH::QPW; ++qq)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[((SH::QPW * kh + qq - 1) * 16 + r) * 64 + lane] = accq[qq][r];
     }
     __syncthreads();
-    if (kh == 1) return;
+    if (kh != 0) return;
+    f32x16 acc = accq[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += xch[r * 64 + lane];
+    for (int q = 1; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += (q < SH::QPW) ? accq[q < SH::QPW ? q : 0][r] : xch[((q - 1) * 16 + r) * 64 + lane];
+    }
     // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
     const int m = mbase + li;
     float p0 = 0.0f, p1 = 0.0f;
@@ -392,8 +414,8 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     p0 += __shfl_xor(p0, 32, 64);
     p1 += __shfl_xor(p1, 32, 64);
     if (lh == 0) {
-        J.P3[((blockIdx.x >> 1) * 2 + 0) * BP + m] = p0;
-        J.P3[((blockIdx.x >> 1) * 2 + 1) * BP + m] = p1;
+        J.P3[(((int)blockIdx.x / kMTiles) * 2 + 0) * BP + m] = p0;
+        J.P3[(((int)blockIdx.x / kMTiles) * 2 + 1) * BP + m] = p1;
     }
     STAMP(12);
 }
@@ -406,10 +428,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (A.prep) {                                  // one job, an actor network
         PrepArgs pa = A.pa;
         if (A.gstride) { gshift(pa.d, blockIdx.z * A.gstride); gshift(pa.ring, blockIdx.z * A.gstride); pa.seed += blockIdx.z; }   // learner blockIdx.z
-        fwd_body<SIN, true>(J, smem, &pa);
+        if (A.mt == 64) fwd_body<SIN, true, 64>(J, smem, &pa); else fwd_body<SIN, true, 32>(J, smem, &pa);
         return;
     }
-    if (J.in == SIN) fwd_body<SIN, false>(J, smem, nullptr); else fwd_body<CIN, false>(J, smem, nullptr);
+    if (A.mt == 64) {
+        if (J.in == SIN) fwd_body<SIN, false, 64>(J, smem, nullptr); else fwd_body<CIN, false, 64>(J, smem, nullptr);
+    } else {
+        if (J.in == SIN) fwd_body<SIN, false, 32>(J, smem, nullptr); else fwd_body<CIN, false, 32>(J, smem, nullptr);
+    }
 }
 
 // ---- critic loss head, evaluated in the prologue of every bwd(critic) workgroup (cheaper than a launch boundary) --------
@@ -1024,15 +1050,18 @@ static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
     f.gstride = gs;
+    f.mt = L >= 8 ? 64 : 32;                       // column-tile width (same bits either way, see FwdShape)
+    const unsigned fgx = NT * (BP / f.mt);
+    const int flds = f.mt == 64 ? FwdShape<64>::LDS : FwdShape<32>::LDS;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
     f.prep = 1;                                    // sample + gather + normalise + layer-1 image packing ride in this launch
     f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1, L), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), flds, st, f);
     f.prep = 0;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
     f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
     f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 3, L), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 3, L), dim3(256), flds, st, f);
     float *S = slot(ws, SLOT_CRITIC);
     const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d, gs};
     hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
@@ -1115,8 +1144,11 @@ static int actor_grad_impl(const shems_ddpg *d, unsigned L, int64_t gs, void *st
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
     f.gstride = gs;
+    f.mt = L >= 8 ? 64 : 32;                       // column-tile width (same bits either way, see FwdShape)
+    const unsigned fgx = NT * (BP / f.mt);
+    const int flds = f.mt == 64 ? FwdShape<64>::LDS : FwdShape<32>::LDS;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(2 * NT, 1, L), dim3(256), FWD_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), flds, st, f);
     const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d, gs};
     hipLaunchKernelGGL(k_bwd, dim3(KT * NQ, 1, L), dim3(256), BWD_LDS, st, bi);
     float *S = slot(ws, SLOT_ACTOR);

@@ -44,8 +44,9 @@ def test_learners_are_independent_and_populated():
         assert float((ag.s_max - ag.s_min).max()) > 0.5
 
 
-def test_group_step_and_update_match_single_learner_calls_bitwise():
-    torch, S, D, G, env, grp = _setup()
+@pytest.mark.parametrize("L,E", [(3, 256), (8, 128)])       # 8 learners: the grouped update switches to its wider forward tile
+def test_group_step_and_update_match_single_learner_calls_bitwise(L, E):
+    torch, S, D, G, env, grp = _setup(L=L, E=E)
     L, E, n = grp.count, grp.envs_per_learner, grp.n_envs
     snap = grp.slab.clone()
     st0, idx0, step0 = env.state, env.idx, env.step
