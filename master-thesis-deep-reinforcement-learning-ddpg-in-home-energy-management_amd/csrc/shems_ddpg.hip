@@ -785,24 +785,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // ---- kernel E: layer-1 gradients, one wave per hidden unit k --------------------------------------------------
 //   D1[k][m] = (h1[k][m] > 0) * sum_q D1part[q][k][m];  gb1[k] = sum_m D1;  gW1[j][k] = sum_m x[j][m] D1[k][m]
 // One wave, xs = the network input [12][BP] in LDS.  gout[j] = gW1[j][k] (j < IN), gout[IN] = gb1[k], valid in every lane.
+// The global operands of a row (its W1 column, b1 and the NQ partial slabs) do not depend on the input block: l1row_load issues
+// them before the block is built and its barrier passed; l1bwd_wave then only touches LDS.
+template <int IN> struct L1Row { float w[IN]; float b; float part[2][NQ]; };
 template <int IN>
-__device__ __forceinline__ void l1bwd_wave(const float *__restrict__ P, const float *xs, const float *__restrict__ D1P, int k, int lane,
-                                           float (&gout)[IN + 1])
+__device__ __forceinline__ void l1row_load(const float *__restrict__ P, const float *__restrict__ D1P, int k, int lane, L1Row<IN> &R)
 {
-    float w[IN];
 #pragma unroll
-    for (int j = 0; j < IN; ++j) w[j] = P[j * H1N + k];
-    const float b = P[off_b1(IN) + k];
+    for (int j = 0; j < IN; ++j) R.w[j] = P[j * H1N + k];
+    R.b = P[off_b1(IN) + k];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) R.part[h][q] = D1P[((int64_t)q * H1N + k) * BP + lane + 64 * h];
+}
+template <int IN>
+__device__ __forceinline__ void l1bwd_wave(const L1Row<IN> &R, const float *xs, int lane, float (&gout)[IN + 1])
+{
     float dv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int m = lane + 64 * h;
-        float pre = b;
+        float pre = R.b;
 #pragma unroll
-        for (int j = 0; j < IN; ++j) pre = fmaf(w[j], xs[j * BP + m], pre);
+        for (int j = 0; j < IN; ++j) pre = fmaf(R.w[j], xs[j * BP + m], pre);
         float s = 0.0f;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s += D1P[((int64_t)q * H1N + k) * BP + m];
+        for (int q = 0; q < NQ; ++q) s += R.part[h][q];
         dv[h] = pre > 0.0f ? s : 0.0f;
     }
     gout[IN] = __shfl(wave_sum(dv[0] + dv[1]), 0, 64);
@@ -814,12 +823,14 @@ template <int IN>
 __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
                                            float *__restrict__ grad, float *xs)
 {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    L1Row<IN> R;
+    l1row_load<IN>(P, D1P, min(k, H1N - 1), lane, R);
     build_x<IN>(x, xs, false);
     __syncthreads();
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= H1N) return;
     float gout[IN + 1];
-    l1bwd_wave<IN>(P, xs, D1P, k, lane, gout);
+    l1bwd_wave<IN>(R, xs, lane, gout);
     if (lane == 0) {
         grad[off_b1(IN) + k] = gout[IN];
 #pragma unroll
@@ -872,12 +883,14 @@ __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
 template <int IN>
 __device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1, float *xs)
 {
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    L1Row<IN> R;
+    l1row_load<IN>(l1.P, l1.D1P, min(k, H1N - 1), lane, R);
     build_x<IN>(l1.x, xs, false);
     __syncthreads();
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= H1N) return;
     float gout[IN + 1];
-    l1bwd_wave<IN>(l1.P, xs, l1.D1P, k, lane, gout);
+    l1bwd_wave<IN>(R, xs, lane, gout);
     float mine = 0.0f;
 #pragma unroll
     for (int j = 0; j <= IN; ++j) mine = lane == j ? gout[j] : mine;
