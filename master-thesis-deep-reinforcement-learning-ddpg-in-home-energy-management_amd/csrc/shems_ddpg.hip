@@ -107,37 +107,56 @@ __device__ __forceinline__ void gshift(shems_replay &r, int64_t off)
     r.s = gsh(r.s, off); r.a = gsh(r.a, off); r.r = gsh(r.r, off); r.s2 = gsh(r.s2, off); r.done = gsh(r.done, off);
 }
 
+// Split in two so that a kernel can issue these loads together with everything else it fetches and only then start consuming
+// (one exposed global latency per kernel phase instead of one per helper).  blockDim = 256: one action element per thread.
+template <int IN> struct XRegs { float v[5]; float a; float b3v; float p[NT]; };
 template <int IN>
-__device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
+__device__ __forceinline__ void build_x_load(const XSrc &s, XRegs<IN> &R)
 {
-    {   // 1152 floats, all loads in flight at once (blockDim = 256)
-        float v[5];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; v[it] = s.X[min(e, SIN * BP - 1)]; }   // clamped, never predicated:
-        // a guarded load becomes a branch + its own s_waitcnt, which serialises the batch
+    for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; R.v[it] = s.X[min(e, SIN * BP - 1)]; }   // clamped, never predicated:
+    // a guarded load becomes a branch + its own s_waitcnt, which serialises the batch
+    if (IN == CIN) {
+        const int e = threadIdx.x, o = e / BP, m = e - o * BP;
+        if (s.A) {
+            R.a = s.A[e];
+        } else {
+            R.b3v = s.b3[o];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; if (e < SIN * BP) xs[e] = v[it]; }
+            for (int t = 0; t < NT; ++t) R.p[t] = s.P3[(t * 2 + o) * BP + m];
+        }
     }
+}
+template <int IN>
+__device__ __forceinline__ void build_x_store(const XSrc &s, const XRegs<IN> &R, float *xs /*LDS [IN][BP]*/, bool publisher)
+{
+#pragma unroll
+    for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; if (e < SIN * BP) xs[e] = R.v[it]; }
     if (threadIdx.x < BP) xs[11 * BP + threadIdx.x] = 1.0f;                     // bias row
     if (IN == SIN) {
         xs[9 * BP + threadIdx.x] = 0.0f;                                          // rows 9, 10 (2 * BP == blockDim)
     }
     if (IN == CIN) {
-        for (int e = threadIdx.x; e < AIN * BP; e += blockDim.x) {
-            float a;
-            if (s.A) {
-                a = s.A[e];
-            } else {
-                const int o = e / BP, m = e - o * BP;
-                float acc = s.b3[o];
+        const int e = threadIdx.x;                                                // AIN * BP == blockDim
+        float a;
+        if (s.A) {
+            a = R.a;
+        } else {
+            float acc = R.b3v;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc += s.P3[(t * 2 + o) * BP + m];
-                a = tanhf(acc);                                   // Dense(500, 2, tanh)
-                if (publisher && s.publish) s.publish[e] = a;
-            }
-            xs[SIN * BP + e] = a;
+            for (int t = 0; t < NT; ++t) acc += R.p[t];
+            a = tanhf(acc);                                       // Dense(500, 2, tanh)
+            if (publisher && s.publish) s.publish[e] = a;
         }
+        xs[SIN * BP + e] = a;
     }
+}
+template <int IN>
+__device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
+{
+    XRegs<IN> R;
+    build_x_load<IN>(s, R);
+    build_x_store<IN>(s, R, xs, publisher);
 }
 
 // Layer 1 also runs on the matrix pipe: pre[k][m] = sum_j w1m[j][k] * xs[j][m] with K = 12 = 6 MFMA k-steps, where
@@ -146,13 +165,22 @@ __device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*
 // The packed image w1m lives in the workspace (the update's first launch builds it for all four networks, the
 // critic's ADAM launch refreshes the critic's); staging it is a straight 12 KB float4 copy, three loads per thread.
 constexpr int W1K = 12, W1C = 256;
+struct W1mRegs { float4 v[3]; };
+__device__ __forceinline__ void stage_w1m_load(const float *__restrict__ g, W1mRegs &R)
+{
+#pragma unroll
+    for (int it = 0; it < 3; ++it) R.v[it] = reinterpret_cast<const float4 *>(g)[it * 256 + threadIdx.x];
+}
+__device__ __forceinline__ void stage_w1m_store(const W1mRegs &R, float *l)
+{
+#pragma unroll
+    for (int it = 0; it < 3; ++it) reinterpret_cast<float4 *>(l)[it * 256 + threadIdx.x] = R.v[it];
+}
 __device__ __forceinline__ void stage_w1m(const float *__restrict__ g, float *l)
 {
-    float4 v[3];
-#pragma unroll
-    for (int it = 0; it < 3; ++it) v[it] = reinterpret_cast<const float4 *>(g)[it * 256 + threadIdx.x];
-#pragma unroll
-    for (int it = 0; it < 3; ++it) reinterpret_cast<float4 *>(l)[it * 256 + threadIdx.x] = v[it];
+    W1mRegs R;
+    stage_w1m_load(g, R);
+    stage_w1m_store(R, l);
 }
 __device__ __forceinline__ void pack_w1m(const float *__restrict__ P, int in, float *__restrict__ g)
 {
@@ -306,6 +334,12 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
         const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c);
         wv[it] = k < H1N ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    XRegs<IN> xr;
+    W1mRegs wr;
+    if (!PREP) {                                   // every global load of the stage goes out before the first one is consumed
+        build_x_load<IN>(J.x, xr);
+        stage_w1m_load(J.w1t, wr);
+    }
     if (PREP) {
         // First launch of an update (actor_target on s'): no separate sample/gather/pack launch.  Every workgroup samples the
         // minibatch and gathers + normalises s' straight into its LDS input block; workgroup 0 also publishes what the later
@@ -322,8 +356,8 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
             pack_w1m(Pn, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(d.ws, net));
         }
     } else {
-        build_x<IN>(J.x, xs, blockIdx.x == 0);
-        stage_w1m(J.w1t, w1);
+        build_x_store<IN>(J.x, xr, xs, blockIdx.x == 0);
+        stage_w1m_store(wr, w1);
     }
     if (tid < 96) ep[tid] = epv;
 #pragma unroll
@@ -586,22 +620,26 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
     }
-    build_x<IN>(A.x, xs, false);
-    stage_w1m(A.w1t, w1);
+    XRegs<IN> xr;
+    W1mRegs wr;
+    float w3v[4];
+    build_x_load<IN>(A.x, xr);
+    stage_w1m_load(A.w1t, wr);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, n = e >> 1, o = e & 1;
+        w3v[it] = W3[min(n, H2N - 1) * A.out + min(o, A.out - 1)];
+    }
+    build_x_store<IN>(A.x, xr, xs, false);
+    stage_w1m_store(wr, w1);
     if (A.head == 1) head_loss(A.dd, d3, red, blockIdx.x == 0);
     else if (A.head == 2) head_actor(A.dd, d3, red, blockIdx.x == 0);
     else { const float t = A.d3[min(tid, A.out * BP - 1)]; d3[tid] = tid < A.out * BP ? t : 0.0f; }   // AIN * BP == 256 == blockDim
-    {   // W3 -> LDS as [n][2] (second column 0 for the critic), 4 independent loads per thread
-        float v[4];
+    {   // W3 -> LDS as [n][2] (second column 0 for the critic), from the loads issued above
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int e = it * 256 + tid, n = e >> 1, o = e & 1;
-            v[it] = W3[min(n, H2N - 1) * A.out + min(o, A.out - 1)];
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = it * 256 + tid, n = e >> 1, o = e & 1;
-            w3s[e] = (n < H2N && o < A.out) ? v[it] : 0.0f;
+            w3s[e] = (n < H2N && o < A.out) ? w3v[it] : 0.0f;
         }
     }
     __syncthreads();
