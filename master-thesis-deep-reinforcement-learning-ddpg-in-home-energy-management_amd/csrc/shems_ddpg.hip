@@ -474,20 +474,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 // ---- critic loss head, evaluated in the prologue of every bwd(critic) workgroup (cheaper than a launch boundary) --------
 // d3[0][m] = dq[m] = 2 (q - y) / B into LDS; workgroup 0 also publishes y, q, the loss and gb3.
-__device__ __forceinline__ void head_loss(const shems_ddpg &d, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
+// The global operands of the two heads, fetched with the rest of a backward workgroup's first batch of loads (all threads load;
+// the critic head uses the values of threads < BP only).
+struct HeadRegs { float v[KT * NQ]; float a, b, c, e; };
+static_assert(KT * NQ >= 2 * NT, "HeadRegs.v holds the 2 x NT layer-3 partials of the critic head");
+__device__ __forceinline__ void head_loss_load(const shems_ddpg &d, HeadRegs &R)
+{
+    const float *ws = d.ws;
+    const int m = threadIdx.x & 127;
+    const float *Pt = slot(d.ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(d.ws, SLOT_CRITIC) + SL_P3;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { R.v[i] = Pt[(i * 2) * BP + m]; R.v[NT + i] = Pc[(i * 2) * BP + m]; }
+    R.a = d.critic_t[off_b3(CIN, 1)];
+    R.b = d.critic[off_b3(CIN, 1)];
+    R.c = ws[WS_R + m];
+    R.e = ws[WS_DONE + m];
+}
+__device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R)
+{
+    const float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+#pragma unroll
+    for (int p = 0; p < KT * NQ; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
+    R.a = ws[WS_API + t];
+}
+
+__device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
 {
     float *ws = d.ws;
     const int t = threadIdx.x, m = t & 127;
     float dq = 0.0f, diff = 0.0f;
     if (t < BP) {
-        const float *Pt = slot(ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(ws, SLOT_CRITIC) + SL_P3;
-        float pt[NT], pc[NT];
+        float q2 = R.a, q = R.b;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) { pt[i] = Pt[(i * 2) * BP + m]; pc[i] = Pc[(i * 2) * BP + m]; }
-        float q2 = d.critic_t[off_b3(CIN, 1)], q = d.critic[off_b3(CIN, 1)];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) { q2 += pt[i]; q += pc[i]; }
-        const float y = ws[WS_R + m] + d.gamma * (1.0f - ws[WS_DONE + m]) * q2;            // DDPG.jl:133
+        for (int i = 0; i < NT; ++i) { q2 += R.v[i]; q += R.v[NT + i]; }
+        const float y = R.c + d.gamma * (1.0f - R.e) * q2;                                  // DDPG.jl:133
         diff = m < d.batch ? q - y : 0.0f;
         dq = 2.0f * diff / (float)d.batch;                                                  // d mse / d q
         if (publisher) { ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq; }
@@ -506,17 +527,14 @@ __device__ __forceinline__ void head_loss(const shems_ddpg &d, float *d3 /*LDS [
 
 // ---- actor head backward, evaluated in the prologue of every bwd(actor) workgroup ------------------------------------
 // d3[o][m] = (sum of the 32 partial d loss / d a_pi) * (1 - a_pi^2); workgroup 0 publishes d3, the actor loss and gb3.
-__device__ __forceinline__ void head_actor(const shems_ddpg &d, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
+__device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
 {
     float *ws = d.ws;
     const int t = threadIdx.x, o = t >> 7, m = t & 127;
-    float pv[KT * NQ];
-#pragma unroll
-    for (int p = 0; p < KT * NQ; ++p) pv[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
-    const float a = ws[WS_API + t];
+    const float a = R.a;
     float da = 0.0f;
 #pragma unroll
-    for (int p = 0; p < KT * NQ; ++p) da += pv[p];
+    for (int p = 0; p < KT * NQ; ++p) da += R.v[p];
     const float g = da * (1.0f - a * a);                       // through tanh
     d3[t] = g;
     if (publisher) {
@@ -630,11 +648,16 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         const int e = it * 256 + tid, n = e >> 1, o = e & 1;
         w3v[it] = W3[min(n, H2N - 1) * A.out + min(o, A.out - 1)];
     }
+    HeadRegs hr;
+    float d3v = 0.0f;
+    if (A.head == 1) head_loss_load(A.dd, hr);
+    else if (A.head == 2) head_actor_load(A.dd, hr);
+    else d3v = A.d3[min(tid, A.out * BP - 1)];
     build_x_store<IN>(A.x, xr, xs, false);
     stage_w1m_store(wr, w1);
-    if (A.head == 1) head_loss(A.dd, d3, red, blockIdx.x == 0);
-    else if (A.head == 2) head_actor(A.dd, d3, red, blockIdx.x == 0);
-    else { const float t = A.d3[min(tid, A.out * BP - 1)]; d3[tid] = tid < A.out * BP ? t : 0.0f; }   // AIN * BP == 256 == blockDim
+    if (A.head == 1) head_loss(A.dd, hr, d3, red, blockIdx.x == 0);
+    else if (A.head == 2) head_actor(A.dd, hr, d3, red, blockIdx.x == 0);
+    else d3[tid] = tid < A.out * BP ? d3v : 0.0f;                                           // AIN * BP == 256 == blockDim
     {   // W3 -> LDS as [n][2] (second column 0 for the critic), from the loads issued above
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
