@@ -200,11 +200,16 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int
     f32x16 t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+    float a[W1K / 2], b[W1K / 2];                 // all 12 operand reads in one batch: with one wave per SIMD nothing else hides them
 #pragma unroll
     for (int s = 0; s < W1K / 2; ++s) {
         const int j = 2 * s + lh;
-        t = __builtin_amdgcn_mfma_f32_32x32x2f32(w1m[j * W1C + kbase + li], xs[j * BP + mbase + li], t, 0, 0, 0);
+        a[s] = w1m[j * W1C + kbase + li];
+        b[s] = xs[j * BP + mbase + li];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < W1K / 2; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], t, 0, 0, 0);
     return t;
 }
 
@@ -375,14 +380,20 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
         for (int q = 0; q < NT1; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[q][r] = 0.0f;
+        float xb[W1K / 2], wa[W1K / 2][NT1];      // operand reads in one batch (see l1_tile)
 #pragma unroll
         for (int sidx = 0; sidx < W1K / 2; ++sidx) {
             const int j = 2 * sidx + lh;
-            const float xb = xs[j * BP + mbase + li];
+            xb[sidx] = xs[j * BP + mbase + li];
+#pragma unroll
+            for (int q = 0; q < NT1; ++q) wa[sidx][q] = w1[j * W1C + SH::KPW * kh + 32 * q + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sidx = 0; sidx < W1K / 2; ++sidx)
 #pragma unroll
             for (int q = 0; q < NT1; ++q)
-                t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[j * W1C + SH::KPW * kh + 32 * q + li], xb, t[q], 0, 0, 0);
-        }
+                t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[sidx][q], xb[sidx], t[q], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < NT1; ++q)
 #pragma unroll
@@ -437,13 +448,22 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
     const int m = mbase + li;
     float p0 = 0.0f, p1 = 0.0f;
+    // only this wave is still running: nothing hides an LDS latency, so all 48 epilogue constants are read in one batch (left to
+    // the compiler each row's three reads sit right in front of their use: 16 exposed round trips)
+    float eb[16], e0[16], e1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        eb[r] = ep[nl * 3]; e0[r] = ep[nl * 3 + 1]; e1[r] = ep[nl * 3 + 2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nl;
-        const float h = n < H2N ? fmaxf(acc[r] + ep[nl * 3], 0.0f) : 0.0f;
+        const float h = n < H2N ? fmaxf(acc[r] + eb[r], 0.0f) : 0.0f;
         if (J.H2 && n < H2N) J.H2[n * BP + m] = h;
-        p0 = fmaf(h, ep[nl * 3 + 1], p0);
-        p1 = fmaf(h, ep[nl * 3 + 2], p1);
+        p0 = fmaf(h, e0[r], p0);
+        p1 = fmaf(h, e1[r], p1);
     }
     p0 += __shfl_xor(p0, 32, 64);
     p1 += __shfl_xor(p1, 32, 64);
@@ -727,10 +747,14 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         if (mh == 0) {
             float *gW2 = A.grad + off_w2(IN);
             const int n = nbase + nt * 32 + li;
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = xch[r * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r] + xch[r * 64 + lane];
+                if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r] + xv[r];
             }
         }
     } else if (is_g) {
@@ -806,7 +830,16 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
         float *D1 = A.D1P + (int64_t)nq * H1N * BP;
         float da0 = 0.0f, da1 = 0.0f;
         f32x16 pre;                             // layer-1 pre-activations of this (k-tile, m-tile): the relu mask, in acc's layout
-        if (A.DAP && IN == CIN) pre = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
+        float wa0[16], wa1[16];                 // W1[9 + o][k]: the action rows of the critic's first layer, read in one batch
+        if (A.DAP && IN == CIN) {
+            pre = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = min(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, W1C - 1);
+                wa0[r] = w1[9 * W1C + k]; wa1[r] = w1[10 * W1C + k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -814,8 +847,8 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
                 D1[k * BP + m] = acc[r];
                 if (A.DAP && IN == CIN) {
                     const float v = pre[r] > 0.0f ? acc[r] : 0.0f;
-                    da0 = fmaf(w1[9 * W1C + k], v, da0);       // W1[9 + o][k]: the action rows of the critic's first layer
-                    da1 = fmaf(w1[10 * W1C + k], v, da1);
+                    da0 = fmaf(wa0[r], v, da0);
+                    da1 = fmaf(wa1[r], v, da1);
                 }
             }
         }
