@@ -879,30 +879,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // ---- kernel E: layer-1 gradients, one wave per hidden unit k --------------------------------------------------
 //   D1[k][m] = (h1[k][m] > 0) * sum_q D1part[q][k][m];  gb1[k] = sum_m D1;  gW1[j][k] = sum_m x[j][m] D1[k][m]
 // One wave, xs = the network input [12][BP] in LDS.  gout[j] = gW1[j][k] (j < IN), gout[IN] = gb1[k], valid in every lane.
-// The global operands of a row (its W1 column, b1 and the NQ partial slabs) do not depend on the input block: l1row_load issues
-// them before the block is built and its barrier passed; l1bwd_wave then only touches LDS.
-template <int IN> struct L1Row { float w[IN]; float b; float part[2][NQ]; };
+// Everything a row needs comes straight from global memory in ONE batch of loads per lane -- its W1 column and b1, the NQ partial
+// slabs and the two input columns (lane, lane + 64) of the network input, which for both differentiated networks is plain
+// workspace data (normalised states, stored actions) -- so there is no LDS block, no barrier and one exposed latency.
+template <int IN> struct L1Row { float w[IN]; float b; float part[2][NQ]; float x[2][IN]; };
 template <int IN>
-__device__ __forceinline__ void l1row_load(const float *__restrict__ P, const float *__restrict__ D1P, int k, int lane, L1Row<IN> &R)
+__device__ __forceinline__ void l1row_load(const float *__restrict__ P, const XSrc &xsrc, const float *__restrict__ D1P, int k, int lane,
+                                           L1Row<IN> &R)
 {
 #pragma unroll
     for (int j = 0; j < IN; ++j) R.w[j] = P[j * H1N + k];
     R.b = P[off_b1(IN) + k];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+        const int m = lane + 64 * h;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) R.part[h][q] = D1P[((int64_t)q * H1N + k) * BP + lane + 64 * h];
+        for (int q = 0; q < NQ; ++q) R.part[h][q] = D1P[((int64_t)q * H1N + k) * BP + m];
+#pragma unroll
+        for (int j = 0; j < IN; ++j) R.x[h][j] = j < SIN ? xsrc.X[j * BP + m] : xsrc.A[(j - SIN) * BP + m];
+    }
 }
 template <int IN>
-__device__ __forceinline__ void l1bwd_wave(const L1Row<IN> &R, const float *xs, int lane, float (&gout)[IN + 1])
+__device__ __forceinline__ void l1bwd_wave(const L1Row<IN> &R, float (&gout)[IN + 1])
 {
     float dv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int m = lane + 64 * h;
         float pre = R.b;
 #pragma unroll
-        for (int j = 0; j < IN; ++j) pre = fmaf(R.w[j], xs[j * BP + m], pre);
+        for (int j = 0; j < IN; ++j) pre = fmaf(R.w[j], R.x[h][j], pre);
         float s = 0.0f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s += R.part[h][q];
@@ -910,21 +915,19 @@ __device__ __forceinline__ void l1bwd_wave(const L1Row<IN> &R, const float *xs, 
     }
     gout[IN] = __shfl(wave_sum(dv[0] + dv[1]), 0, 64);
 #pragma unroll
-    for (int j = 0; j < IN; ++j) gout[j] = __shfl(wave_sum(xs[j * BP + lane] * dv[0] + xs[j * BP + 64 + lane] * dv[1]), 0, 64);
+    for (int j = 0; j < IN; ++j) gout[j] = __shfl(wave_sum(R.x[0][j] * dv[0] + R.x[1][j] * dv[1]), 0, 64);
 }
 
 template <int IN>
 __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
-                                           float *__restrict__ grad, float *xs)
+                                           float *__restrict__ grad)
 {
     const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    L1Row<IN> R;
-    l1row_load<IN>(P, D1P, min(k, H1N - 1), lane, R);
-    build_x<IN>(x, xs, false);
-    __syncthreads();
     if (k >= H1N) return;
+    L1Row<IN> R;
+    l1row_load<IN>(P, x, D1P, k, lane, R);
     float gout[IN + 1];
-    l1bwd_wave<IN>(R, xs, lane, gout);
+    l1bwd_wave<IN>(R, gout);
     if (lane == 0) {
         grad[off_b1(IN) + k] = gout[IN];
 #pragma unroll
@@ -934,9 +937,8 @@ __device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XS
 
 __global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad, int64_t gstride)
 {
-    __shared__ float xs[W1K * BP];
     if (gstride) { const int64_t off = blockIdx.z * gstride; P = gsh(P, off); gshift(x, off); D1P = gsh(D1P, off); grad = gsh(grad, off); }
-    if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad, xs); else l1bwd_body<CIN>(P, x, D1P, grad, xs);
+    if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad); else l1bwd_body<CIN>(P, x, D1P, grad);
 }
 
 // ---- kernel G: Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------
@@ -975,16 +977,14 @@ __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
 }
 
 template <int IN>
-__device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1, float *xs)
+__device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1)
 {
     const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    L1Row<IN> R;
-    l1row_load<IN>(l1.P, l1.D1P, min(k, H1N - 1), lane, R);
-    build_x<IN>(l1.x, xs, false);
-    __syncthreads();
     if (k >= H1N) return;
+    L1Row<IN> R;
+    l1row_load<IN>(l1.P, l1.x, l1.D1P, k, lane, R);
     float gout[IN + 1];
-    l1bwd_wave<IN>(R, xs, lane, gout);
+    l1bwd_wave<IN>(R, gout);
     float mine = 0.0f;
 #pragma unroll
     for (int j = 0; j <= IN; ++j) mine = lane == j ? gout[j] : mine;
@@ -997,7 +997,6 @@ __device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1, 
 
 __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t gstride)
 {
-    __shared__ float xs[W1K * BP];
     if (gstride) {
         const int64_t off = blockIdx.z * gstride;
         c.p = gsh(c.p, off); c.g = gsh(c.g, off); c.mt = gsh(c.mt, off); c.vt = gsh(c.vt, off); c.target = gsh(c.target, off);
@@ -1008,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t 
     if (l1.on) {                                  // the first 63 workgroups ONLY produce + apply the layer-1 rows; the sweep follows them
         constexpr int kRowWgs = (H1N + 3) / 4;
         if (blk < kRowWgs) {
-            if (c.in == SIN) adam_l1_rows<SIN>(c, l1, xs); else adam_l1_rows<CIN>(c, l1, xs);
+            if (c.in == SIN) adam_l1_rows<SIN>(c, l1); else adam_l1_rows<CIN>(c, l1);
             return;
         }
         first = (c.in + 1) * H1N;
