@@ -319,6 +319,21 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     constexpr int kMTiles = BP / MT;           // workgroups per n-tile
+    if (PREP && (int)blockIdx.x >= NT * kMTiles) {
+        // The five extra workgroups of an update's first launch: one publishes what the later launches read from the workspace
+        // (the sampled, gathered and normalised minibatch), four pack the layer-1 images of the four networks.  Kept off the tile
+        // workgroups so that none of those runs longer than the others.
+        const int duty = (int)blockIdx.x - NT * kMTiles;
+        if (duty == 0) {
+            if (tid < BP) prep_column(*pa, tid, nullptr, true);
+        } else {
+            const int net = duty - 1;
+            const shems_ddpg &d = pa->d;
+            const float *Pn = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
+            pack_w1m(Pn, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(d.ws, net));
+        }
+        return;
+    }
     const int n0 = ((int)blockIdx.x / kMTiles) * 32;
     const int mt = wave % SH::NMW, kh = wave / SH::NMW, mbase = MT * ((int)blockIdx.x % kMTiles) + 32 * mt;
     const float *__restrict__ P = J.P;
@@ -346,20 +361,13 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
         stage_w1m_load(J.w1t, wr);
     }
     if (PREP) {
-        // First launch of an update (actor_target on s'): no separate sample/gather/pack launch.  Every workgroup samples the
-        // minibatch and gathers + normalises s' straight into its LDS input block; workgroup 0 also publishes what the later
-        // launches read from the workspace, workgroups 1..4 the packed layer-1 images of the four networks; the image this
-        // launch needs itself is packed from the parameter block.
-        if (tid < BP) prep_column(*pa, tid, xs, blockIdx.x == 0);
+        // First launch of an update (actor_target on s'): no separate sample/gather/pack launch.  Every tile workgroup samples the
+        // minibatch and gathers + normalises s' straight into its LDS input block, and packs the layer-1 image it needs from the
+        // parameter block; five extra workgroups (above) publish the workspace copies for the later launches.
+        if (tid < BP) prep_column(*pa, tid, xs, false);
         xs[9 * BP + tid] = 0.0f;                                                    // rows 9, 10 (2 * BP == blockDim)
         if (tid < BP) xs[11 * BP + tid] = 1.0f;                                     // bias row
         pack_w1m(P, IN, w1);
-        if (blockIdx.x >= 1 && blockIdx.x <= 4) {
-            const int net = blockIdx.x - 1;
-            const shems_ddpg &d = pa->d;
-            const float *Pn = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
-            pack_w1m(Pn, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(d.ws, net));
-        }
     } else {
         build_x_store<IN>(J.x, xr, xs, blockIdx.x == 0);
         stage_w1m_store(wr, w1);
@@ -1162,7 +1170,7 @@ static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64
     f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
     f.prep = 1;                                    // sample + gather + normalise + layer-1 image packing ride in this launch
     f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), flds, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx + 5, 1, L), dim3(256), flds, st, f);      // + 5 publishing workgroups (see fwd_body)
     f.prep = 0;
     f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
     f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
