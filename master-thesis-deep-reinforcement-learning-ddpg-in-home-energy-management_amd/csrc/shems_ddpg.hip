@@ -610,7 +610,7 @@ __device__ __forceinline__ void gshift(BwdArgs &B, int64_t off)
     B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.d3 = gsh(B.d3, off);
     B.grad = gsh(B.grad, off); B.D1P = gsh(B.D1P, off); B.DAP = gsh(B.DAP, off); gshift(B.dd, off);
 }
-enum { BWD_NG = 16 };                      // G workgroups: 32 rows of gb2 / gW3 each
+enum { BWD_NG = 16, BWD_GROWS = 512 / BWD_NG, BWD_GU = BWD_GROWS / 4 };   // G workgroups: 32 rows of gb2 / gW3 each, 8 per wave (32 x 16 measured equal)
 
 constexpr int BWD_BT = BP * (NQW + 1);                       // W: [128 m][65] D2^T panel (>= I: [64 n][128 m] D2 panel)
 constexpr int BWD_AT = BP * 33;                              // W: [128 m][33] h1^T panel (>= I: [32 k][65] W2 panel)
@@ -766,20 +766,21 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
             }
         }
     } else if (is_g) {
-        // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: 16 workgroups x 32 rows, one wave per row, 8 rows in flight
+        // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: BWD_NG workgroups x BWD_GROWS rows, one wave per row, all of a
+        // wave's rows in flight
         const int g = blockIdx.x - A.n_w;
         const float e0a = d3[lane], e0b = d3[64 + lane], e1a = d3[BP + lane], e1b = d3[BP + 64 + lane];
         {
-            float h0[8], h1[8];
+            float h0[BWD_GU], h1[BWD_GU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int nc = min(g * 32 + wave + 4 * u, H2N - 1);
+            for (int u = 0; u < BWD_GU; ++u) {
+                const int nc = min(g * BWD_GROWS + wave + 4 * u, H2N - 1);
                 h0[u] = A.H2[nc * BP + lane];
                 h1[u] = A.H2[nc * BP + 64 + lane];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int nn = g * 32 + wave + 4 * u;
+            for (int u = 0; u < BWD_GU; ++u) {
+                const int nn = g * BWD_GROWS + wave + 4 * u;
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * min(nn, H2N - 1));
                 const float s0 = wave_sum(h0[u] * e0a + h1[u] * e0b);
                 const float s1 = wave_sum(h0[u] * e1a + h1[u] * e1b);
