@@ -963,24 +963,54 @@ struct AdamCtx {
 };
 struct L1Src { const float *P; XSrc x; const float *D1P; float *grad; int on; };
 
-__device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
+// One element of ADAM + soft update on values: (m, v, p, target) in, updated in place.
+__device__ __forceinline__ void adam_math(const AdamCtx &c, float graw, float &m, float &v, float &p, float &t)
 {
     // Julia evaluates the broadcast expressions without fusing multiplies into adds; keeping the compiler from contracting also
-    // makes the two inlined copies of this function (layer-1 rows / sweep) round identically.
+    // makes the inlined copies of this function (layer-1 rows / sweep) round identically.
 #pragma clang fp contract(off)
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const float gf = (float)((double)graw * c.gscale);          // averaged gradient, as every replica holds it
-    const float m1 = (float)(b1 * (double)c.mt[i] + (1.0 - b1) * (double)gf);
-    const float v1 = (float)(b2 * (double)c.vt[i] + (1.0 - b2) * ((double)gf * (double)gf));
+    const float m1 = (float)(b1 * (double)m + (1.0 - b1) * (double)gf);
+    const float v1 = (float)(b2 * (double)v + (1.0 - b2) * ((double)gf * (double)gf));
     const float delta = (float)((double)m1 / (1.0 - c.bp1) / (sqrt((double)v1 / (1.0 - c.bp2)) + eps) * c.eta);
-    const float pn = c.p[i] - delta;
-    c.mt[i] = m1; c.vt[i] = v1; c.p[i] = pn;
-    if (c.publish) c.publish[i] = pn;
+    const float pn = p - delta;
     const float one_m_tau = 1.0f - c.tau;
-    c.target[i] = one_m_tau * c.target[i] + c.tau * pn;
+    t = one_m_tau * t + c.tau * pn;
+    m = m1; v = v1; p = pn;
+}
+__device__ __forceinline__ void adam_image(const AdamCtx &c, int i, float pn)
+{
     if (c.w1t_g && i < c.in * H1N + H1N) {   // keep the packed layer-1 image of the updated network current
         const int j = i / H1N, k = i - j * H1N;
         c.w1t_g[(j < c.in ? j : W1K - 1) * W1C + k] = pn;
+    }
+}
+__device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
+{
+    float m = c.mt[i], v = c.vt[i], p = c.p[i], t = c.target[i];
+    adam_math(c, graw, m, v, p, t);
+    c.mt[i] = m; c.vt[i] = v; c.p[i] = p; c.target[i] = t;
+    if (c.publish) c.publish[i] = p;
+    adam_image(c, i, p);
+}
+// Four consecutive elements per thread (16-byte accesses: a quarter of the workgroups, the same bits).  i0 is a multiple of 4.
+__device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
+{
+    if (i0 + 3 < c.n) {
+        const float4 g4 = *reinterpret_cast<const float4 *>(c.g + i0);
+        float4 m4 = *reinterpret_cast<const float4 *>(c.mt + i0), v4 = *reinterpret_cast<const float4 *>(c.vt + i0);
+        float4 p4 = *reinterpret_cast<const float4 *>(c.p + i0), t4 = *reinterpret_cast<const float4 *>(c.target + i0);
+        adam_math(c, g4.x, m4.x, v4.x, p4.x, t4.x);
+        adam_math(c, g4.y, m4.y, v4.y, p4.y, t4.y);
+        adam_math(c, g4.z, m4.z, v4.z, p4.z, t4.z);
+        adam_math(c, g4.w, m4.w, v4.w, p4.w, t4.w);
+        *reinterpret_cast<float4 *>(c.mt + i0) = m4; *reinterpret_cast<float4 *>(c.vt + i0) = v4;
+        *reinterpret_cast<float4 *>(c.p + i0) = p4; *reinterpret_cast<float4 *>(c.target + i0) = t4;
+        if (c.publish) *reinterpret_cast<float4 *>(c.publish + i0) = p4;
+        if (c.w1t_g && i0 < c.in * H1N + H1N) { adam_image(c, i0, p4.x); adam_image(c, i0 + 1, p4.y); adam_image(c, i0 + 2, p4.z); adam_image(c, i0 + 3, p4.w); }
+    } else {
+        for (int i = i0; i < c.n; ++i) adam_elem(c, i, c.g[i]);
     }
 }
 
@@ -1021,8 +1051,8 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t 
         first = (c.in + 1) * H1N;
         blk -= kRowWgs;
     }
-    const int i = first + blk * blockDim.x + threadIdx.x;
-    if (i < c.n) adam_elem(c, i, c.g[i]);
+    const int i0 = first + 4 * (blk * (int)blockDim.x + (int)threadIdx.x);          // first is a multiple of 4, the blocks 16-byte aligned
+    if (i0 < c.n) adam_vec4(c, i0);
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -1211,7 +1241,8 @@ static int adam_launch(float *p, const float *g, float *m, float *v, float *targ
     const AdamCtx c{p, g, m, v, target, w1t_g, publish, n, in, eta, bp1, bp2, gscale, tau};
     const int sweep = l1.on ? n - (in + 1) * H1N : n;             // elements the plain sweep covers
     const int row_wgs = l1.on ? (H1N + 3) / 4 : 0;                // + the workgroups that produce and apply the layer-1 rows
-    hipLaunchKernelGGL(k_adam_soft, dim3(row_wgs + (sweep + 255) / 256, 1, L), dim3(256), 0, st, c, l1, gs);
+    static_assert(((SIN + 1) * H1N) % 4 == 0 && ((CIN + 1) * H1N) % 4 == 0, "the sweep starts on a 16-byte boundary");
+    hipLaunchKernelGGL(k_adam_soft, dim3(row_wgs + (sweep + 1023) / 1024, 1, L), dim3(256), 0, st, c, l1, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
