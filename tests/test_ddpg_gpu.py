@@ -227,3 +227,30 @@ def test_fused_layer1_gradient_is_bit_identical_to_the_separate_launch():
     for k in out[0]:
         assert torch.equal(out[0][k], out[1][k]), k
     assert float(out[0]["grad_critic"][:3000].abs().max()) > 0 and float(out[0]["grad_actor"][:2500].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B", [1, 17, 128])
+def test_other_batch_sizes_match_oracle(B):
+    """BATCH_SIZE other than the tuned 120 (1 <= B <= 128): the unused columns of the 128-wide tiles must stay out of every sum."""
+    torch, S, D, ag, ring, h = _setup(seed=23)
+    ag.batch = B
+    idx = DO.sample_indices(23, 4, B, len(ring))
+    assert (ag.sample_indices(4, len(ring)) == idx).all()
+    L = DO.Learner(h["pa"], h["pc"], h["s_min"], h["s_max"])
+    s, a, r, s2, done = (h[k][idx] for k in ("s", "a", "r", "s2", "done"))
+    y = L.targets(r, s2, done.astype(bool))
+    gc_ref, lc_ref = L.critic_grad(s, a, y)
+    ag.replay(ring, tick=4)
+    torch.cuda.synchronize()
+    gc = ag.grad_critic.cpu().numpy()
+    assert _rel(gc, gc_ref) < 2e-4
+    losses = ag.losses.cpu().numpy()
+    assert abs(losses[0] - lc_ref) < 1e-4 * max(1.0, abs(lc_ref))
+    L.critic = ag.critic.cpu().numpy()
+    ga_ref, la_ref = L.actor_grad(s)
+    ga = ag.grad_actor.cpu().numpy()
+    assert _rel(ga, ga_ref) < 2e-4
+    assert abs(losses[1] - la_ref) < 1e-4 * max(1.0, abs(la_ref))
+    with pytest.raises(S.ShemsError):
+        ag.batch = 129
+        ag.replay(ring, tick=5)
