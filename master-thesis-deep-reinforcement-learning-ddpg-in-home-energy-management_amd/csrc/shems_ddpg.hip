@@ -703,6 +703,9 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
 
     if (is_w) {
         const int nbase = nq * NQW;
+        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
+        // issued first so that it runs under the VALU work of the D2 panel below.
+        const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
         // D2^T panel Bt[m][nl] (row stride 65), nl = 2*u + half: 32 rows per thread from the loads issued above (W3 comes from LDS;
         // rows >= 500 meet the zero rows of its image)
         {
@@ -713,12 +716,8 @@ __device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
                 Bt[mcol * (NQW + 1) + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
             }
         }
-        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe
-        {
-            const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
-        }
+        for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
         __syncthreads();
         BSTAMP(2);
         // wave (nt, mh): the 32 x 32 tile of columns [32 nt, +32) over the batch half [64 mh, +64): 32 MFMA pairs, operand fetch
