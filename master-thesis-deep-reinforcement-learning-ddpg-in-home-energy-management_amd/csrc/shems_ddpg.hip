@@ -8,18 +8,22 @@
 // layout.  At batch 120 one update is 307.8 MFLOP (~2 us at the fp32 MFMA peak): it is bound by
 // dependent-launch boundaries (~1.5 us each) and by L2/Infinity-Cache latency, not by the matrix
 // pipe.  Design rules that follow from the first measured version (profiles/r01_train_v1_*):
-//   * no single-workgroup latency chains: every phase is spread over 16-64 workgroups;
-//   * operands are staged into LDS with wide, independent loads (one latency per phase), never
-//     fetched per MFMA k-step;
+//   * no single-workgroup latency chains: every phase is spread over 64-144 workgroups, shaped so that no workgroup type
+//     is the straggler of its launch (the 8 x 64-row gb2/gW3 workgroups once were: -4 us for halving them);
+//   * operands are staged into LDS with wide, independent loads, ALL of a phase's global loads issued before the first
+//     wait (one exposed latency per phase), never fetched per MFMA k-step; phases that only one wave finishes read
+//     their LDS constants in one batch;
 //   * nothing derivable is stored: layer-1 activations, their relu masks and the back-propagated
 //     layer-2 error D2 = (W3 d3) .* (h2 > 0) are recomputed inside the kernels that consume them;
 //   * cross-workgroup reductions go through partial slabs summed in a fixed order (bitwise
-//     reproducible; no float atomics).
-// 11 launches per update (the loss / actor heads run in the prologue of the bwd workgroups):
-//   prep -> fwd(actor_t) -> fwd(critic_t | critic | actor) -> bwd(critic) -> l1bwd(critic)
-//   [all-reduce] adam+soft(critic)
-//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> bwd(actor) -> l1bwd(actor)
-//   [all-reduce] adam+soft(actor)
+//     reproducible; no float atomics, no device-scope fences -- on this 8-XCD part a release writes the L2 back).
+// 8 launches per update on a single replica (the loss / actor heads run in the prologue of the bwd workgroups, the
+// minibatch sampling / gather and the layer-1 image packing inside the first forward launch, the layer-1 gradient rows
+// inside the ADAM launch):
+//   fwd(actor_t) -> fwd(critic_t | critic | actor) -> bwd(critic) -> adam+soft(critic)
+//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> bwd(actor) -> adam+soft(actor)
+// and 10 when replicas exchange gradients (the all-reduce needs the complete gradient before ADAM):
+//   ... bwd(critic) -> l1bwd(critic) [all-reduce] adam+soft(critic) ... bwd(actor) -> l1bwd(actor) [all-reduce] adam+soft(actor)
 #include <hip/hip_runtime.h>
 
 #include <cstring>

@@ -421,7 +421,7 @@ class Agent:
 
 class TrainWorkload:
     """bench.py's "train" step: the body of the reference's episode! loop for all envs of a rank at once --
-    act + noise + scale_action + step! + remember (one fused launch) and `updates` x replay() (15 launches
+    act + noise + scale_action + step! + remember (one fused launch) and `updates` x replay() (8 launches
     each, 2 gradient all-reduces when several GPUs train one model)."""
 
     name = "train"

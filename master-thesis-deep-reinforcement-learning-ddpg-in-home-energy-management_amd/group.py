@@ -137,7 +137,7 @@ class LearnerGroup:
                 ring.pushed += int(window[1])
 
     def replay(self, tick=None):
-        """replay() (DDPG.jl:121-145) for every learner: 11 launches in total, grid z = learner."""
+        """replay() (DDPG.jl:121-145) for every learner: 8 launches in total, grid z = learner."""
         a0, g, r0 = self.learners[0], self.struct(), self.rings[0].struct()
         d = a0._ddpg_args()
         st = self._stream()
