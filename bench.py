@@ -174,7 +174,16 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
     for t in range(EP_LEN):
         L.orc_batch_step_omp(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, obs.ctypes.data)
     env_all = n * EP_LEN / (time.perf_counter() - t0)
-    out = {"env_only_value": env_one, "env_only_all_cores_value": env_all, "all_cores": os.cpu_count() or 1}
+    # BASELINE config 1 / B1: ONE env, rule-based 72-step episodes (reset!(env; rng=-1), action(env, track), step!), one thread
+    one = oracle_c.Batch(1, EP_LEN, tab, oracle_c.profile(98))
+    nrep, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        one.reset(True)
+        one.rule_episode(0, EP_LEN)
+        nrep += 1
+    rule_us = (time.perf_counter() - t0) / (nrep * EP_LEN) * 1e6
+    out = {"env_only_value": env_one, "env_only_all_cores_value": env_all, "all_cores": os.cpu_count() or 1,
+           "config1_rule_episode_us_per_step": rule_us}
     if mode == "env":
         out.update({"value": env_one, "unit": "env-steps/s", "cores": 1, "kind": "port",
                     "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes, {steps} env-steps in {t_step:.1f} s"})
