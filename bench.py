@@ -169,11 +169,20 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
         t_step += time.perf_counter() - t0
         steps += n * EP_LEN
     env_one = steps / t_step
+    # all host cores: each OpenMP thread carries its envs through whole 72-step episodes inside one parallel region
+    # (orc_batch_episode_omp); one untimed episode warms the thread pool, then whole episodes for >= 3 s
+    sets = np.stack(acts)
     b.reset(False, idx0, soc0)
-    t0 = time.perf_counter()
-    for t in range(EP_LEN):
-        L.orc_batch_step_omp(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, obs.ctypes.data)
-    env_all = n * EP_LEN / (time.perf_counter() - t0)
+    b.episode_omp(sets, EP_LEN)
+    steps_all, t_all = 0, 0.0
+    while t_all < 3.0:
+        b.reset(False, idx0, soc0)
+        t0 = time.perf_counter()
+        rc, _ = b.episode_omp(sets, EP_LEN)
+        t_all += time.perf_counter() - t0
+        steps_all += n * EP_LEN
+        assert rc == 0
+    env_all = steps_all / t_all
     # BASELINE config 1 / B1: ONE env, rule-based 72-step episodes (reset!(env; rng=-1), action(env, track), step!), one thread
     one = oracle_c.Batch(1, EP_LEN, tab, oracle_c.profile(98))
     nrep, t0 = 0, time.perf_counter()
@@ -251,13 +260,53 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: this process becomes the launcher.  It has made NO
+    GPU call (torch is not even imported here) and starts N fresh children of this same script, one rank per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, exactly what `-m torch.distributed.run` would set.
+    Rank 0's single JSON line goes to this process's stdout; the exit code is non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                    for q in pending:                            # a failed rank leaves the others in a collective: stop them
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Rehearsal knobs for a one-GPU box (never set by the driver): every rank on device 0, gloo instead of RCCL.
     if os.environ.get("SHEMS_BENCH_ONE_DEVICE") == "1":
@@ -320,14 +369,17 @@ def main():
     if rank == 0:
         k = wl.kernel_pass(min(args.steps, 500))
         achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes, see profiles/README.md
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(mode, {})
             if rec.get("envs_per_gpu") == args.envs:
                 traffic = rec.get("hbm_bytes_per_launch")
+                # PMC counters cannot be read from inside this process: the figure is the committed result of separate
+                # `rocprofv3 --pmc` passes over this same command, not a measurement of the run that prints it
+                traffic_src = "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, " + str(rec.get("round", "r01")) + ")"
         roof = {"bound": k["bound"], "achieved": achieved, "peak": k["peak"], "unit": k["unit"],
-                "frac": achieved / k["peak"], "traffic": traffic, "kernel": k["kernel"],
+                "frac": achieved / k["peak"], "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
                 "algorithmic_per_launch": k["algorithmic"]}
         if world == 1 and not args.no_cpu_baseline:

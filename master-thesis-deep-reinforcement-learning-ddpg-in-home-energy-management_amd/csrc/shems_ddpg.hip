@@ -975,7 +975,8 @@ __device__ __forceinline__ void adam_math(const AdamCtx &c, float graw, float &m
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const float gf = (float)((double)graw * c.gscale);          // averaged gradient, as every replica holds it
     const float m1 = (float)(b1 * (double)m + (1.0 - b1) * (double)gf);
-    const float v1 = (float)(b2 * (double)v + (1.0 - b2) * ((double)gf * (double)gf));
+    const float g2 = gf * gf;                                    // Flux 0.12.1 `Δ^2` on a Float32 array: literal_pow = Δ*Δ in Float32, then promoted
+    const float v1 = (float)(b2 * (double)v + (1.0 - b2) * (double)g2);
     const float delta = (float)((double)m1 / (1.0 - c.bp1) / (sqrt((double)v1 / (1.0 - c.bp2)) + eps) * c.eta);
     const float pn = p - delta;
     const float one_m_tau = 1.0f - c.tau;

@@ -237,11 +237,12 @@ using namespace shems;
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-static int check_view(const shems_view *v)
+int shems::check_view(const shems_view *v, const char *fn)
 {
-    if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1 ||
-        (v->n_cfg > 1 && !v->cfg_of_env))
-        return set_error(SHEMS_ERR_ARG, "invalid shems_view (NULL buffer or n_envs <= 0)");
+    if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1)
+        return set_error(SHEMS_ERR_ARG, "%s: invalid shems_view (NULL buffer or n_envs <= 0)", fn);
+    if (v->n_cfg > 1 && !v->cfg_of_env)
+        return set_error(SHEMS_ERR_ARG, "%s: shems_view has %d configs but no cfg_of_env map", fn, (int)v->n_cfg);
     return SHEMS_OK;
 }
 
@@ -250,7 +251,7 @@ extern "C" {
 int shems_step_dev(const shems_view *v, const float *d_actions, int track_mode, double *d_rewards,
                    float *d_rewards_f32, double *d_results, double *d_block_reward, void *stream)
 {
-    if (int rc = check_view(v)) return rc;
+    if (int rc = check_view(v, "shems_step_dev")) return rc;
     if (!d_actions) return set_error(SHEMS_ERR_ARG, "shems_step_dev: d_actions is NULL");
     hipLaunchKernelGGL(k_step, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, d_actions,
                        track_mode, d_rewards, d_rewards_f32, d_results, d_block_reward);
@@ -259,7 +260,7 @@ int shems_step_dev(const shems_view *v, const float *d_actions, int track_mode, 
 
 int shems_action_dev(const shems_view *v, const float *d_targets, int rule_based, float *d_out, void *stream)
 {
-    if (int rc = check_view(v)) return rc;
+    if (int rc = check_view(v, "shems_action_dev")) return rc;
     if (!d_out || (!rule_based && !d_targets)) return set_error(SHEMS_ERR_ARG, "shems_action_dev: NULL buffer");
     hipLaunchKernelGGL(k_action, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, d_targets,
                        rule_based, d_out);
@@ -268,7 +269,7 @@ int shems_action_dev(const shems_view *v, const float *d_targets, int rule_based
 
 int shems_reset_dev(const shems_view *v, int rng_minus1, const int32_t *d_idx0, const float *d_soc_b0, void *stream)
 {
-    if (int rc = check_view(v)) return rc;
+    if (int rc = check_view(v, "shems_reset_dev")) return rc;
     if (!rng_minus1 && (!d_idx0 || !d_soc_b0))
         return set_error(SHEMS_ERR_ARG, "shems_reset_dev: idx0/soc_b0 required unless rng == -1");
     hipLaunchKernelGGL(k_reset, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, rng_minus1,
@@ -278,7 +279,7 @@ int shems_reset_dev(const shems_view *v, int rng_minus1, const int32_t *d_idx0, 
 
 int shems_reset_seeded_dev(const shems_view *v, uint64_t seed, uint32_t episode, void *stream)
 {
-    if (int rc = check_view(v)) return rc;
+    if (int rc = check_view(v, "shems_reset_seeded_dev")) return rc;
     hipLaunchKernelGGL(k_reset, dim3(grid_for(v->n_envs)), dim3(kBlock), 0, (hipStream_t)stream, *v, 0,
                        (const int32_t *)nullptr, (const float *)nullptr, 1, seed, episode);
     return hip_ok(hipGetLastError(), "k_reset launch");
@@ -294,7 +295,7 @@ int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stre
 int shems_rollout_dev(const shems_view *v, int policy, int32_t nsteps, uint64_t seed, double *d_returns,
                       const shems_replay *ring, int64_t ring_pos, int64_t ring_envs, void *stream)
 {
-    if (int rc = check_view(v)) return rc;
+    if (int rc = check_view(v, "shems_rollout_dev")) return rc;
     if (nsteps < 0 || (policy != SHEMS_ROLLOUT_RULE && policy != SHEMS_ROLLOUT_RANDOM))
         return set_error(SHEMS_ERR_ARG, "shems_rollout_dev: bad policy or nsteps");
     shems_replay r;

@@ -567,8 +567,7 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
                        const shems_replay *ring, const shems_ring_window *window, void *stream)
 {
     if (int rc = check_act(p, "shems_act_step_dev")) return rc;
-    if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1)
-        return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: invalid view");
+    if (int rc = check_view(v, "shems_act_step_dev")) return rc;
     ActArgs a;
     std::memset(&a, 0, sizeof a);
     a.v = *v; a.p = *p; a.obs = v->obs; a.m = v->n_envs; a.a_out = d_a;
@@ -580,6 +579,9 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
             return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: incomplete replay ring");
         if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0)
             return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: ring window larger than the ring or the batch");
+        if (window->offset < 0 || window->offset >= v->n_envs)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: ring window offset %lld outside the batch of %lld envs",
+                             (long long)window->offset, (long long)v->n_envs);
         a.ring = *ring; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);
@@ -589,8 +591,7 @@ int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, co
                              double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
 {
     if (int rc = check_act(p0, "shems_act_step_group_dev")) return rc;
-    if (!v || v->n_envs <= 0 || !v->obs || !v->idx || !v->step || !v->cfgs || !v->tables || v->n_cfg < 1)
-        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: invalid view");
+    if (int rc = check_view(v, "shems_act_step_group_dev")) return rc;
     if (!g || g->count < 1 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
         return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: shems_group needs count >= 1 and a 16-byte-multiple stride");
     if (g->envs_per_learner < 128 || g->envs_per_learner % 128 != 0 || g->envs_per_learner * g->count != v->n_envs)
@@ -607,6 +608,9 @@ int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, co
             return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: incomplete replay ring");
         if (window->count > ring0->capacity || window->count > g->envs_per_learner || window->pos < 0)
             return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: ring window larger than the ring or a learner's env block");
+        if (window->offset < 0 || window->offset >= g->envs_per_learner)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: ring window offset %lld outside a learner's block of %lld envs",
+                             (long long)window->offset, (long long)g->envs_per_learner);
         a.ring = *ring0; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);

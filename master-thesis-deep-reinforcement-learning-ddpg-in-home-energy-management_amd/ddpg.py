@@ -39,6 +39,14 @@ class ActParams(C.Structure):          # shems_act_params
 
 NOISE_KINDS = {"gn": 0, "ou": 1, "en": 2, "pn": 0}   # noise_type strings of the reference (DDPG.jl:152-161); "pn" runs the perturbed actor with train = 0
 NOISE_ACT = 0.1                                  # noise_act, input.jl:231 (ParamNoise.sigma_target)
+EPS_ZETA, EPS_XI0, EPS_XI_MIN = float(np.float32(0.0005)), 0.5, float(np.float32(0.1))   # input.jl:226-228 (Float32 literals)
+SEED_INI = 123                                   # input.jl:134; evaluation seeds are "123" * test_ep (DDPG.jl:275)
+
+
+def eps_schedule(current_episode, mem_size=24000, ep_length=72, zeta=EPS_ZETA, xi_min=EPS_XI_MIN):
+    """sample_noise(en::EpsNoise) (DDPG.jl:69-72): xi = Float32(max(0.5 - zeta * (current_episode - MEM_SIZE / EP_LENGTH), xi_min)),
+    evaluated in Float64 (0.5 and the quotient are Float64) and rounded once.  No upper clamp: episode 1 gives 0.666."""
+    return float(np.float32(max(0.5 - zeta * (current_episode - mem_size / ep_length), xi_min)))
 
 
 class DdpgArgs(C.Structure):           # shems_ddpg
@@ -193,6 +201,30 @@ class Agent:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
 
+    def _same_device(self, env=None, ring=None):
+        """Every buffer a launch dereferences must live on this learner's GPU (one process per GPU: a ring or env
+        created on another device would be unmapped peer memory inside the kernels)."""
+        if ring is not None and ring.s.device != self.device:
+            raise ValueError(f"replay ring lives on {ring.s.device}, the learner on {self.device}")
+        if env is not None and getattr(env, "device_index", self.device.index) != self.device.index:
+            raise ValueError(f"env batch lives on cuda:{env.device_index}, the learner on {self.device}")
+
+    _LEARNER_TENSORS = ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic", "grad_actor",
+                        "grad_critic", "losses")
+
+    def snapshot(self):
+        """Everything replay() mutates (device clones + the host-side ADAM powers / counters)."""
+        return ({k: getattr(self, k).clone() for k in self._LEARNER_TENSORS},
+                dict(bp_actor=list(self.bp_actor), bp_critic=list(self.bp_critic), updates=self.updates, tick=self.tick,
+                     pn_sigma=self.pn_sigma, fuse_l1=self.fuse_l1))
+
+    def restore(self, snap):
+        tensors, host = snap
+        for k, v in tensors.items():
+            getattr(self, k).copy_(v)
+        for k, v in host.items():
+            setattr(self, k, list(v) if isinstance(v, list) else v)
+
     def set_params(self, actor=None, critic=None, sync_targets=True):
         t = self.torch
         if actor is not None:
@@ -278,6 +310,7 @@ class Agent:
     def act_step(self, env, train=True, tick=None, a_out=None, rewards=None, rewards_f32=None, block_reward=None,
                  returns_acc=None, ring=None, window=None):
         """One fused vector step: s = env.state; a = act(s); step!(env, s, scale_action(a)); remember(...)."""
+        self._same_device(env, ring)
         env.use_torch_stream()
         v = env.view()
         self._ensure_ou(env.n)
@@ -309,6 +342,7 @@ class Agent:
     def replay(self, ring, tick=None, exclude=None, publish=None):
         """replay(; rng_rpl) (DDPG.jl:121-145): one DDPG update from `ring`.  exclude = (pos, count): ring slots another
         stream is writing right now (pipelined mode); publish = tensor that also receives the updated actor."""
+        self._same_device(None, ring)
         d = self._ddpg_args()
         st = self._stream()
         rs = ring.struct()
@@ -339,6 +373,7 @@ class Agent:
         """s_min, s_max = min_max_buffer(MIN_EXP_SIZE) (MPS:50-53, main script :30): extrema of s over a
         bootstrap sample (with replacement) of `count` ring entries; with several replicas the 9-float
         extrema are all-reduced (min / max)."""
+        self._same_device(None, ring)
         rs = ring.struct()
         count = len(ring) if count is None else int(count)
         _capi.check(self.L.shems_minmax_dev(C.byref(rs), len(ring), count, self.rng_seed if seed is None else int(seed),
@@ -357,6 +392,7 @@ class Agent:
         """populate_memory (MPS:9-29): fill the ring to capacity with uniform random actions.  The
         reference runs ceil(MEM/72) sequential 72-step episodes; here that many envs of the batch run
         them in ONE launch (shems_rollout_dev) and push in the reference's episode-major order."""
+        self._same_device(env, ring)
         seed = self.rng_seed if seed is None else int(seed)
         nsteps = env.maxsteps
         n_ep = -(-ring.capacity // nsteps)                    # episodes until length(memory) >= MIN_EXP_SIZE
@@ -366,12 +402,15 @@ class Agent:
         return ring
 
     def episode_(self, env, ring=None, train=True, num_steps=None, rng_ep=0, episode=0, updates_per_step=1,
-                 window_count=None):
+                 window_count=None, current_episode=None):
         """episode!(env; train, rng_ep) (DDPG.jl:186-242) for every env of the batch at once.  Returns the
         per-env episode returns (float64 device tensor).  train=True: exploration noise, replay insert
         of a rotating window of envs and `updates_per_step` x replay() per vector step."""
         t = self.torch
         num_steps = env.maxsteps if num_steps is None else int(num_steps)
+        if train and self.noise_type == "en":                                   # `global current_episode = i` (DDPG.jl:250)
+            self.eps = eps_schedule(episode if current_episode is None else current_episode, ring.capacity if ring is not None
+                                    else MEM_SIZE, EP_LENGTH_TRAIN)
         if rng_ep == -1:
             env.reset_(-1)
         else:
@@ -391,7 +430,7 @@ class Agent:
                 ring.pushed += window_count
                 for _ in range(updates_per_step):
                     self.replay(ring)
-            self.tick += 1
+                self.tick += 1                                                  # rotates the replay window: training steps only
         return returns
 
     def run_episodes(self, env_train, env_eval, ring, num_ep, test_every=100, test_runs=100, seed=None,
@@ -408,8 +447,10 @@ class Agent:
             total_reward[i - 1] = self.sync.mean_scalar(ret.mean().item(), env_train.n)
             if i % test_every == 1:
                 idx = -(-i // test_every)
-                # the eval env has nrow - maxsteps = 1 => every test episode starts at idx 1 and differs in Soc_b only
-                score = self.episode_(env_eval, None, train=False, num_steps=EP_LENGTH_TRAIN, rng_ep=123, episode=idx)
+                # DDPG.jl:273-277: every evaluation sweep runs the SAME test_runs seeds "123" * test_ep, so best-score
+                # snapshots compare like with like -> fixed (seed_ini, episode 0) reset key, env j = test_ep j + 1.  The eval
+                # env has nrow - maxsteps = 1 => every test episode starts at idx 1 and differs in Soc_b only.
+                score = self.episode_(env_eval, None, train=False, num_steps=EP_LENGTH_TRAIN, rng_ep=SEED_INI, episode=0)
                 score_mean[idx - 1] = self.sync.mean_scalar(score.mean().item(), env_eval.n)
                 if score_mean[idx - 1] > best_score:
                     best_score, best_run = score_mean[idx - 1], i
@@ -517,7 +558,11 @@ class TrainWorkload:
         # here (the other ranks are not in this code), so the gradient exchange is switched off for its duration.
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         nup = 50
+        # the learner state is put back afterwards, so rank 0's replica stays identical to the others
+        snap = self.agent.snapshot()
         saved_sync, self.agent.sync = self.agent.sync, GradSync(None)
+        world = saved_sync.world
+        self.agent.fuse_l1 = world == 1                 # time the launch structure the benchmarked world size runs (minus the exchange)
         try:
             torch.cuda.synchronize()
             e0.record()
@@ -527,6 +572,7 @@ class TrainWorkload:
             torch.cuda.synchronize()
         finally:
             self.agent.sync = saved_sync
+            self.agent.restore(snap)
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
         return dict(kernel="shems::k_act<TM>", avg_us=avg_us, median_us=med_us, launches=reps,

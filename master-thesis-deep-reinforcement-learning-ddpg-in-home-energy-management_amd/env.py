@@ -48,6 +48,7 @@ class EnvSlice:
         if start < 0 or count < 1 or start + count > parent.n:
             raise ValueError("slice outside the batch")
         self.parent, self.start, self.n, self.maxsteps = parent, start, count, parent.maxsteps
+        self.device_index = parent.device_index
         self._L = parent._L
 
     def view(self):
@@ -75,11 +76,12 @@ class EnvSlice:
 
 
 def mixed_profile_setup(n_envs, charger_ids=(1, 2, 3, 4, 5, 6, 7, 8, 9, 98), sweep=((0.01, 2.0), (0.04, 2.0), (0.1, 2.0), (0.01, 1.0), (0.04, 1.0), (0.1, 1.0)),
-                        split="train"):
-    """BASELINE config 5: one synthetic table per charger profile and one config per (profile, discomfort weight, power)
-    point of the sweep (values of shems_LU1.jl:20-41 / shems_LU1_input0607.jl); env i uses config i mod n_cfg.
-    Returns (tables, configs, cfg_of_env)."""
-    tabs = [_tables.synthetic_table(split, c) for c in charger_ids]
+                        split="train", prefer_real=True):
+    """BASELINE config 5: one table per charger profile -- the real exogenous series where the reference holds one (train:
+    Chargers 01/03/04/05/08/09, tables.real_series), the seeded synthetic generator for the rest -- and one config per
+    (profile, discomfort weight, power) point of the sweep (values of shems_LU1.jl:20-41 / shems_LU1_input0607.jl); env i uses
+    config i mod n_cfg.  Returns (tables, configs, cfg_of_env)."""
+    tabs = [_tables.profile_table(c, split, prefer_real) for c in charger_ids]
     row0 = np.cumsum([0] + [t.shape[0] for t in tabs])
     cfgs = [make_config(c, row0[p], tabs[p].shape[0], w, pot) for p, c in enumerate(charger_ids) for (w, pot) in sweep]
     return tabs, cfgs, (np.arange(n_envs) % len(cfgs)).astype(np.uint16)
@@ -98,6 +100,7 @@ class ShemsBatch:
         self._h = C.c_void_p()
         self.n = int(n_envs)
         self.maxsteps = int(maxsteps)
+        self.device_index = int(device)
         _capi.check(L.shems_create(self.n, self.maxsteps, int(device), C.byref(self._h)))
         tabs = tables if isinstance(tables, (list, tuple)) else [tables]
         tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in tabs]

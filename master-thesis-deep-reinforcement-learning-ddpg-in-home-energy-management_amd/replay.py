@@ -11,7 +11,7 @@ from . import _capi
 
 
 class ReplayRing:
-    def __init__(self, capacity, device="cuda:0", tensors=None):
+    def __init__(self, capacity, device=None, tensors=None):
         """tensors = (s, a, r, s2, done): views into memory the caller owns (a learner group's slab) instead of new buffers."""
         import torch
         self.capacity = int(capacity)
@@ -20,7 +20,9 @@ class ReplayRing:
             self.device = self.s.device
             assert self.s.shape == (self.capacity, _capi.NSTATE) and self.done.dtype == torch.uint8 and self.done.shape == (self.capacity,)
         else:
-            self.device = torch.device(device)
+            # default = the CURRENT device (one process per GPU: bench.py/run_charger.py call set_device(LOCAL_RANK) first);
+            # a ring on another GPU than the env/agent would make every kernel dereference unmapped peer memory
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
             self.s = torch.zeros((self.capacity, _capi.NSTATE), dtype=torch.float32, device=self.device)
             self.a = torch.zeros((self.capacity, _capi.NACTION), dtype=torch.float32, device=self.device)
             self.r = torch.zeros((self.capacity,), dtype=torch.float32, device=self.device)

@@ -172,6 +172,37 @@ def synthetic_table(split="train", charger_id=98, seed=None, nrow=None):
     return pack_columns(h_cd, soc, d_e, g_e, p_buy, hour_cos, hour_sin, season)
 
 
+_SERIES = None
+
+
+def real_series_keys():
+    """("ChargerNN_split", ...) of the exogenous series shipped in data/mpc_series.npz."""
+    global _SERIES
+    if _SERIES is None:
+        import os
+        with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mpc_series.npz"), allow_pickle=False) as z:
+            _SERIES = {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+    return tuple(sorted(_SERIES))
+
+
+def real_series(charger_id, split="train"):
+    """The real exogenous series of a charger profile, [nrow][8] float32, or None when the reference holds none.
+
+    The per-charger input CSVs are not public (reference README.md:12), but the reference commits the MPC benchmark's result
+    files for Chargers 01/03/04/05/08/09 (train, 4 319 rows), 04/05/09 (eval, 1 439) and 01/03/06/08/09/98 (test, 2 999)
+    under `SHEMS python/single_building/results/`; the 8 columns the env reads are recovered from the LP's balance
+    constraints by tests/golden/make_fixtures.py (data, not source text).  One row shorter than the CSVs (the MPC horizon)."""
+    real_series_keys()
+    t = _SERIES.get(f"Charger{int(charger_id):02d}_{split}")
+    return None if t is None else t.copy()
+
+
+def profile_table(charger_id, split="train", prefer_real=True):
+    """Real series where the reference holds one, the seeded synthetic generator otherwise."""
+    t = real_series(charger_id, split) if prefer_real else None
+    return synthetic_table(split, charger_id) if t is None else t
+
+
 def episode_start_table(table, maxsteps):
     """Resolved episode start for every possible first draw (pure function of the draw:
     shems_LU1.jl:227-246 redraws with the SAME seed, i.e. the same value).  Host-side helper

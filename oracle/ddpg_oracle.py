@@ -72,9 +72,11 @@ def critic_forward(p, s_norm, a, dtype=np.float32):
     return mlp_forward(p, np.concatenate([s_norm, a], 1), STATE + ACTION, 1, False, dtype=dtype)[:, 0]
 
 
-def mlp_backward(p, cache, dy, in_dim, out_dim, final_tanh, y=None):
-    """Gradient of sum(dy * y) wrt the flat parameters and wrt the input x."""
-    W1, b1, W2, b2, W3, b3 = split(p, in_dim, out_dim)
+def mlp_backward(p, cache, dy, in_dim, out_dim, final_tanh, y=None, dtype=np.float32):
+    """Gradient of sum(dy * y) wrt the flat parameters and wrt the input x (arithmetic in `dtype`; float64 = the arbiter
+    the per-block parity tests hold both this restatement and the kernels to)."""
+    W1, b1, W2, b2, W3, b3 = (a.astype(dtype) for a in split(p, in_dim, out_dim))
+    dy = np.asarray(dy, dtype)
     x, z1, h1, z2, h2, z3 = cache
     d3 = dy * (1 - np.tanh(z3) ** 2) if final_tanh else dy
     gW3 = h2.T @ d3
@@ -86,13 +88,19 @@ def mlp_backward(p, cache, dy, in_dim, out_dim, final_tanh, y=None):
     gW1 = x.T @ d1
     gb1 = d1.sum(0)
     dx = d1 @ W1.T
-    g = np.concatenate([gW1.ravel(), gb1, gW2.ravel(), gb2, gW3.ravel(), gb3]).astype(f32)
-    return g, dx.astype(f32)
+    g = np.concatenate([gW1.ravel(), gb1, gW2.ravel(), gb2, gW3.ravel(), gb3]).astype(dtype)
+    return g, dx.astype(dtype)
+
+
+def blocks(in_dim, out_dim):
+    """[(name, lo, hi)] of the six Flux.params blocks in the flat layout."""
+    o = np.cumsum([0] + sizes(in_dim, out_dim))
+    return [(n, int(o[i]), int(o[i + 1])) for i, n in enumerate(("W1", "b1", "W2", "b2", "W3", "b3"))]
 
 
 class Adam:
     """Flux 0.12.1 ADAM(eta, (0.9, 0.999)), eps = 1e-8: scalars in Float64, arrays Float32.
-        mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2
+        mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2   (g^2 = literal_pow -> g*g in Float32, then promoted)
         delta = mt / (1 - bp1) / (sqrt(vt / (1 - bp2)) + eps) * eta ; bp .*= beta ; p .-= delta"""
 
     def __init__(self, n, eta):
@@ -104,7 +112,8 @@ class Adam:
     def step(self, p, g):
         g64 = g.astype(np.float64)
         self.m = (BETA[0] * self.m.astype(np.float64) + (1 - BETA[0]) * g64).astype(f32)
-        self.v = (BETA[1] * self.v.astype(np.float64) + (1 - BETA[1]) * g64 * g64).astype(f32)
+        g2 = (g.astype(f32) * g.astype(f32)).astype(np.float64)          # Float32 square (Flux optimisers.jl ADAM: `Δ^2`)
+        self.v = (BETA[1] * self.v.astype(np.float64) + (1 - BETA[1]) * g2).astype(f32)
         delta = (self.m.astype(np.float64) / (1 - self.bp[0]) /
                  (np.sqrt(self.v.astype(np.float64) / (1 - self.bp[1])) + EPS) * self.eta).astype(f32)
         self.bp = [self.bp[0] * BETA[0], self.bp[1] * BETA[1]]
@@ -243,23 +252,23 @@ class Learner:
         q2 = critic_forward(self.critic_t, s2n, a2)
         return (r + GAMMA * (f32(1) - done.astype(f32)) * q2).astype(f32)          # DDPG.jl:133
 
-    def critic_grad(self, s, a, y):
+    def critic_grad(self, s, a, y, dtype=np.float32):
         sn = normalize(s, self.s_min, self.s_max)
-        q, cache = mlp_forward(self.critic, np.concatenate([sn, a], 1), STATE + ACTION, 1, False, keep=True)
+        q, cache = mlp_forward(self.critic, np.concatenate([sn, a], 1), STATE + ACTION, 1, False, keep=True, dtype=dtype)
         B = len(y)
-        dq = (f32(2) * (q[:, 0] - y) / f32(B)).astype(f32)[:, None]                 # Flux.mse
-        g, _ = mlp_backward(self.critic, cache, dq, STATE + ACTION, 1, False)
+        dq = (dtype(2) * (q[:, 0] - y) / dtype(B)).astype(dtype)[:, None]           # Flux.mse
+        g, _ = mlp_backward(self.critic, cache, dq, STATE + ACTION, 1, False, dtype=dtype)
         loss = float(np.mean((q[:, 0] - y) ** 2))
         return g, loss
 
-    def actor_grad(self, s):
+    def actor_grad(self, s, dtype=np.float32):
         sn = normalize(s, self.s_min, self.s_max)
-        a, ca = mlp_forward(self.actor, sn, STATE, ACTION, True, keep=True)
-        q, cc = mlp_forward(self.critic, np.concatenate([sn, a], 1), STATE + ACTION, 1, False, keep=True)
+        a, ca = mlp_forward(self.actor, sn, STATE, ACTION, True, keep=True, dtype=dtype)
+        q, cc = mlp_forward(self.critic, np.concatenate([sn, a], 1), STATE + ACTION, 1, False, keep=True, dtype=dtype)
         B = len(s)
-        dq = np.full((B, 1), f32(-1.0 / B), f32)                                    # -mean(q)
-        _, dx = mlp_backward(self.critic, cc, dq, STATE + ACTION, 1, False)
-        g, _ = mlp_backward(self.actor, ca, dx[:, STATE:], STATE, ACTION, True)
+        dq = np.full((B, 1), dtype(-1.0 / B), dtype)                                # -mean(q)
+        _, dx = mlp_backward(self.critic, cc, dq, STATE + ACTION, 1, False, dtype=dtype)
+        g, _ = mlp_backward(self.actor, ca, dx[:, STATE:], STATE, ACTION, True, dtype=dtype)
         return g, float(-np.mean(q))
 
     def replay(self, s, a, r, s2, done, allreduce=None):

@@ -53,6 +53,7 @@ def lib():
     L.orc_scale_action.restype = C.c_float
     L.orc_batch_step.argtypes = [vp, i64, vp, C.c_int, vp, vp, vp]
     L.orc_batch_step_omp.argtypes = [vp, i64, vp, C.c_int, vp, vp]
+    L.orc_batch_episode_omp.argtypes = [vp, i64, vp, i64, i64, C.c_int, vp]
     L.orc_rule_episode.argtypes = [vp, i64, vp]
     L.orc_rule_episode.restype = C.c_double
     L.orc_batch_alloc.argtypes = [i64]
@@ -172,6 +173,14 @@ class Batch:
         rc = L.orc_batch_step(self.ptr, self.n, actions.ctypes.data, track_mode, rewards.ctypes.data,
                               obs.ctypes.data, res.ctypes.data if want_results else None)
         return rc, rewards, obs, res
+
+    def episode_omp(self, action_sets, nsteps, track_mode=0):
+        """nsteps x step! for every env inside one OpenMP region (all host cores); action_sets [nsets][n][2], set t % nsets at step t."""
+        a = np.ascontiguousarray(action_sets, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[1:] == (self.n, 2)
+        ret = np.empty(self.n, np.float64)
+        rc = lib().orc_batch_episode_omp(self.ptr, self.n, a.ctypes.data, a.shape[0], int(nsteps), track_mode, ret.ctypes.data)
+        return rc, ret
 
     def rule_episode(self, i, steps, want_results=False):
         L = lib()

@@ -465,6 +465,26 @@ int orc_batch_step_omp(orc_env *envs, int64_t n, const float *actions, int track
     return rc ? -1 : 0;
 }
 
+/* Whole episodes on all host cores: envs are independent, so each thread carries its envs through all `nsteps` steps inside ONE
+ * parallel region (the per-vector-step variant above pays a fork/join per step, which at 256 threads outweighs the work).
+ * actions: [nsets][n][2], step t uses set t % nsets.  returns_out[i] = sum of the env's rewards. */
+int orc_batch_episode_omp(orc_env *envs, int64_t n, const float *actions, int64_t nsets, int64_t nsteps, int track_mode,
+                          double *returns_out)
+{
+    int rc = 0;
+#pragma omp parallel for schedule(static) reduction(|:rc)
+    for (int64_t i = 0; i < n; ++i) {
+        double total = 0.0;
+        for (int64_t t = 0; t < nsteps; ++t) {
+            double r;
+            if (orc_step(&envs[i], actions + ((t % nsets) * n + i) * 2, track_mode, &r, 0) != 0) { rc |= 1; break; }
+            total += r;
+        }
+        if (returns_out) returns_out[i] = total;
+    }
+    return rc ? -1 : 0;
+}
+
 /* Array-of-envs helpers so Python (ctypes) can own a batch without mirroring the struct. */
 #include <stdlib.h>
 orc_env *orc_batch_alloc(int64_t n) { return (orc_env *)calloc((size_t)n, sizeof(orc_env)); }

@@ -109,6 +109,8 @@ double orc_rule_episode(orc_env *e, int64_t steps, double *results /* [steps][23
 
 int  orc_batch_step_omp(orc_env *envs, int64_t n, const float *actions, int track_mode,
                         double *rewards, float *obs_out);
+int  orc_batch_episode_omp(orc_env *envs, int64_t n, const float *actions /* [nsets][n][2] */, int64_t nsets, int64_t nsteps,
+                           int track_mode, double *returns_out /* [n] or NULL */);
 orc_env *orc_batch_alloc(int64_t n);
 void     orc_batch_free(orc_env *p);
 orc_env *orc_batch_at(orc_env *p, int64_t i);

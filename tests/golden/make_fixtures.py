@@ -9,6 +9,11 @@
         h_countdown = C_EV,  soc_ev = Soc_Ev / 35.816 on arrival rows (else 1),
         hour_cos/sin = cos/sin(2*pi*hour/23), season from month, p_buy = 0.4   (SURVEY.md App. C).
     This is input DATA (8 numeric columns), no reference source text.
+(1b) <package>/data/mpc_series.npz (read through tables.real_series; `bench.py --mixed` uses it) -- the same reconstruction for EVERY MPC result file the reference holds that is not an LFS stub
+    (results/260724_results_*_all_{train,eval,test}_fix_ChargerNN.csv: Chargers 01/03/04/05/08/09 train (4 319 rows),
+    04/05/09 eval (1 439), 01/03/06/08/09/98 test (2 999)), one packed [nrow][8] float32 table per key
+    "ChargerNN_split", with each charger's own cap_ev (shems_LU1.jl:47-59) and, for the train split, the linear
+    soc_ev interpolation that Data_preparation_v2.ipynb cell 40 applies to training data only.
 (2) kat_appendix_b.json -- the hand-traced known-answer vectors of SURVEY.md Appendix B.
 (3) oracle_golden.npz -- outputs of the CPU oracle (C restatement) on fixed inputs: a rule-based
     72-step episode (BASELINE config 1) and 64 DRL envs x 72 steps with hashed actions.  These
@@ -36,8 +41,8 @@ def season_of_month(m):
     return 1 if m in (3, 4, 5) else 2 if m in (6, 7, 8) else 3 if m in (9, 10, 11) else 4
 
 
-def reconstruct():
-    rows = list(csv.DictReader(open(REF)))
+def reconstruct(path=REF, cap_ev=35.816, split="test"):
+    rows = list(csv.DictReader(open(path)))
     out = []
     prev_c = -1.0
     for r in rows:
@@ -45,13 +50,50 @@ def reconstruct():
         c = g("C_EV")
         d_e = g("PV_DE") + g("B_DE") + g("GR_DE")
         g_e = g("PV_DE") + g("PV_B") + g("PV_GR") + g("PV_EV")
-        soc = g("Soc_Ev") / 35.816 if (c > -1 and prev_c == -1) else 1.0
+        soc = g("Soc_Ev") / cap_ev if (c > -1 and prev_c == -1) else 1.0
         hour, month = g("hour"), int(g("month"))
         out.append([c, min(soc, 1.0), round(d_e, 3), round(g_e, 3), 0.4,
                     math.cos(2 * math.pi * hour / 23.0), math.sin(2 * math.pi * hour / 23.0),
                     float(season_of_month(month))])
         prev_c = c
-    return np.asarray(out, dtype=np.float64)
+    a = np.asarray(out, dtype=np.float64)
+    if split == "train":
+        interpolate_soc_ev(a)
+    return a
+
+
+def interpolate_soc_ev(a):
+    """Training tables only (Data_preparation_v2.ipynb cells 40, 45): soc_ev rises linearly from its arrival value to 1.0 at the
+    row whose countdown is 0.  A session starts where h_countdown > 0 follows a -1 row (or opens the table)."""
+    h, soc = a[:, 0], a[:, 1]
+    start = None
+    for i in range(len(h)):
+        if h[i] > 0 and (i == 0 or h[i - 1] == -1):
+            start = i
+        if h[i] == 0 and start is not None:
+            s0 = soc[start]
+            for j in range(start, i + 1):
+                soc[j] = s0 + (1.0 - s0) * (j - start) / (i - start)
+            start = None
+
+
+RESULT_DIR = "/root/reference/SHEMS python/single_building/results"
+
+
+def reconstruct_all(T):
+    """Every non-LFS MPC result file -> {"ChargerNN_split": [nrow][8] float32}."""
+    import glob
+    import re
+    out = {}
+    for path in sorted(glob.glob(os.path.join(RESULT_DIR, "260724_results_*_all_*_fix_Charger*.csv"))):
+        m = re.search(r"_all_(train|eval|test)_fix_Charger(\d\d)\.csv$", path)
+        split, cid = m.group(1), int(m.group(2))
+        a = reconstruct(path, T.CHARGER_PROFILES[cid][0], split)
+        h = a[:, 0]
+        assert ((h[1:][h[:-1] == 0]) == -1).all(), "a departure row must be followed by -1 (cell 39)"
+        assert (a[:, 1] >= 0).all() and (a[:, 1] <= 1 + 1e-12).all() and (a[:, 2] >= 0).all() and (a[:, 3] >= -1e-9).all()
+        out[f"Charger{cid:02d}_{split}"] = T.pack_columns(*[a[:, j] for j in range(8)])
+    return out
 
 
 def main():
@@ -62,6 +104,10 @@ def main():
         tab = T.pack_columns(*[a[:, j] for j in range(8)])
         T.save_csv(os.path.join(HERE, "charger98_test_reconstructed.csv"), tab)
         print("reconstructed table", tab.shape)
+        series = reconstruct_all(T)
+        assert np.array_equal(series["Charger98_test"], tab)
+        np.savez_compressed(os.path.join(ROOT, U.PKG_NAME, "data", "mpc_series.npz"), **series)     # shipped as package DATA
+        print("mpc_series.npz:", {k: v.shape[0] for k, v in series.items()})
     else:
         print("reference data file absent: keeping the committed reconstructed table")
 

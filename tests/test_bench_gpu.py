@@ -53,3 +53,22 @@ def test_two_rank_data_parallel_rehearsal():
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "4096"],
              env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["value"] > 0
+
+
+def test_bench_starts_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` (the driver's call: no torchrun, no WORLD_SIZE in the environment) must start two ranks
+    itself and report n_gpus == 2.  Rehearsal form for the one-GPU box: both ranks on device 0, gloo instead of RCCL.
+    BASELINE config 4's call is `python bench.py --gpus 8 --envs 8192`."""
+    env = {"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        assert k not in os.environ or True
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    e.update(env)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "8192"],
+                         cwd=U.ROOT, env=e, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["cpu_baseline"] is None and d["value"] > 0
+    assert d["updates_per_sec"] > 0 and d["roofline"]["frac"] > 0

@@ -274,3 +274,43 @@ def test_full_size_65536_envs_properties_and_sampled_parity():
     assert (st[:, 1] <= 1.0 + 1e-6).all() and np.isfinite(total).all()
     assert (U.bits32(st[sample]) == U.bits32(ref.state())).all()
     env.close()
+
+
+def test_real_series_mixed_profiles_reset_and_steps_bit_exact():
+    """BASELINE config 5 on the REAL exogenous series (tables.real_series: Chargers 01/03/04/05/08/09 train from the reference's MPC
+    result files, synthetic for 02/06/07/98): seeded reset (Philox draws + the LU1:227-246 extension loop on real transaction
+    patterns, every first draw of every real table) and 72 steps of the per-env-config batch, bit for bit against the oracle."""
+    S = _S()
+    T = S.tables
+    tabs, cfgs, co = S.mixed_profile_setup(6000)
+    assert [t.shape[0] for t in tabs] == [4319, 4320, 4319, 4319, 4319, 4320, 4320, 4319, 4319, 4320]
+    sweep = [(0.01, 2.0), (0.04, 2.0), (0.1, 2.0), (0.01, 1.0), (0.04, 1.0), (0.1, 1.0)]
+    profs = [oracle_c.profile(c, w, pot) for c in U.CHARGER_IDS for (w, pot) in sweep]
+    tab_of = np.repeat(np.arange(10), 6)
+    n = 6000
+    env = S.ShemsBatch(n, 72, tabs, cfgs, co)
+    ref = oracle_c.Batch(n, 72, tabs, profs, tab_of[co], co)
+    seed, ep = 1231, 3
+    env.reset_(seed, episode=ep)
+    i0 = np.empty(n, np.int32); s0 = np.empty(n, np.float32)
+    for k, cfg in enumerate(cfgs):
+        a, b = philox_np.reset_draws(seed, ep, n, tabs[tab_of[k]].shape[0], 72, cfg.soc_max)
+        i0[co == k], s0[co == k] = a[co == k], b[co == k]
+    ref.reset(False, i0, s0)
+    assert (env.idx == ref.idx()).all() and (U.bits32(env.state) == U.bits32(ref.state())).all()
+    rng = np.random.default_rng(5)
+    for t in range(72):
+        a = rng.random((n, 2)).astype(np.float32)
+        r, s2 = env.step_(None, a)
+        rc, r_ref, o_ref, _ = ref.step(a, 0)
+        assert rc == 0 and (U.bits64(r) == U.bits64(r_ref)).all() and (U.bits32(s2) == U.bits32(o_ref)).all()
+    assert (env.idx == ref.idx()).all() and (env.step == 72).all()
+    env.close()
+    # every possible first draw of every real train table resolves like the reference loop (device extension loop)
+    for c in (1, 3, 4, 5, 8, 9):
+        tab = T.real_series(c, "train")
+        m = tab.shape[0] - 72
+        e2 = S.ShemsBatch(m, 72, [tab], [S.make_config(c, 0, tab.shape[0])])
+        e2.reset_(0, idx0=np.arange(1, m + 1, dtype=np.int32), soc_b0=np.zeros(m, np.float32))
+        assert (e2.idx == T.episode_start_table(tab, 72)).all(), c
+        e2.close()

@@ -1,0 +1,45 @@
+"""Host-side logic that needs no GPU: the epsilon-noise schedule, bench.py's rank launcher."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import util as U
+
+
+def test_eps_noise_schedule_follows_the_reference_formula():
+    """sample_noise(en::EpsNoise), DDPG.jl:69-72 with input.jl:226-228 (zeta = 0.0005f0, xi_0 = 0.5f0, xi_min = 0.1f0):
+    xi = Float32(max(0.5 - zeta * (current_episode - MEM_SIZE / EP_LENGTH["train"]), xi_min)).  "Parity unpinned": the reference
+    holds no fixture for it; the values below are the formula evaluated by hand in Float64."""
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    z = float(np.float32(0.0005))
+    for ep in (1, 100, 333, 334, 1001, 1133, 1134, 5000):
+        want = np.float32(max(0.5 - z * (ep - 24000 / 72), float(np.float32(0.1))))
+        assert D.eps_schedule(ep) == float(want), ep
+    assert D.eps_schedule(1) > 0.66                      # no upper clamp in the reference: 0.5 + zeta * 332.33
+    assert abs(D.eps_schedule(334) - 0.5) < 1e-3         # reaches xi_0 once the pre-filled memory's worth of episodes has passed
+    assert D.eps_schedule(1134) == float(np.float32(0.1)) and D.eps_schedule(10 ** 6) == float(np.float32(0.1))
+    xs = [D.eps_schedule(e) for e in range(1, 1300)]
+    assert all(a >= b for a, b in zip(xs, xs[1:]))      # monotone decay
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """`python bench.py --gpus 2` with no rendezvous in the environment becomes the launcher (it makes no GPU call itself).
+    In the GPU-less container every rank fails at device selection; the launcher must return non-zero and name the rank
+    rather than hang or print a JSON line.  (The success path runs on the GPU box: tests/test_bench_gpu.py.)"""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    e["HIP_VISIBLE_DEVICES"] = ""                       # no device even if the box has one
+    e["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         cwd=U.ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "rank" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rejects_mismatched_world_size():
+    e = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=U.ROOT, env=e,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr

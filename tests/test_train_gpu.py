@@ -78,6 +78,43 @@ def test_episode_returns_match_stepwise_rewards_and_eval_is_deterministic():
     env.close(); env_eval.close()
 
 
+def test_every_evaluation_sweep_starts_from_the_same_draws():
+    """DDPG.jl:273-277: each evaluation runs the same test_runs seeds "123" * test_ep, so score_mean entries (and the best-actor
+    snapshot chosen from them) compare like with like.  Here: the eval env's start states are identical at every sweep, with a
+    frozen actor two sweeps give identical scores, and evaluation episodes leave the training-side counters alone."""
+    torch, S, D = _mods()
+    tab = S.tables.synthetic_table("train", 98)
+    ev = S.tables.synthetic_table("eval", 98)
+    env = S.ShemsBatch(512, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    env_eval = S.ShemsBatch(100, 1439, [ev], [S.make_config(98, 0, ev.shape[0])]).use_torch_stream()
+    ag = D.Agent(seed=5)
+    ring = D.ReplayRing(D.MEM_SIZE)
+    ag.populate_memory(env, ring)
+    ag.min_max_buffer(ring)
+    starts = []
+    real_episode = ag.episode_
+
+    def spy(e, *a, **kw):
+        if e is env_eval:
+            e.reset_(kw["rng_ep"], episode=kw["episode"])
+            starts.append((np.array(e.state, copy=True), np.array(e.idx, copy=True), ag.tick, ring.pushed))
+        return real_episode(e, *a, **kw)
+
+    ag.episode_ = spy
+    tr, sm, best_run, _ = ag.run_episodes(env, env_eval, ring, num_ep=5, test_every=2, test_runs=100)
+    assert len(starts) == 3                                                # i = 1, 3, 5
+    for st, ix, _, _ in starts[1:]:
+        assert (U.bits32(st) == U.bits32(starts[0][0])).all() and (ix == starts[0][1]).all()
+    assert len(np.unique(starts[0][0][:, 0])) > 50 and (starts[0][1] == 1).all()     # 100 different Soc_b draws, all at idx 1
+    # evaluation does not advance the replay-window rotation or the ring
+    tick0, pushed0 = ag.tick, ring.pushed
+    s1 = real_episode(env_eval, None, train=False, num_steps=72, rng_ep=D.SEED_INI, episode=0).cpu().numpy()
+    s2 = real_episode(env_eval, None, train=False, num_steps=72, rng_ep=D.SEED_INI, episode=0).cpu().numpy()
+    assert (s1 == s2).all() and ag.tick == tick0 and ring.pushed == pushed0
+    assert abs(s1.mean() - sm[2]) < 1e-9                                   # the sweep run_episodes recorded for i = 5 is this one
+    env.close(); env_eval.close()
+
+
 def test_ddpg_actually_learns_the_shems_task():
     """End to end: populate_memory -> min_max_buffer -> 40 training episodes (2 880 updates) on 4 096 households.  The
     deterministic evaluation score and the training return must improve substantially (measured: eval -87 -> about -42,
