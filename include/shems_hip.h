@@ -231,17 +231,23 @@ int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 
 
 /* -------------------------------------------------------- DDPG update -- */
-/* replay() (DDPG.jl:121-145) split at the two points where data-parallel replicas exchange
- * gradients.  Batch <= 128 (BATCH_SIZE = 120 in the tuned config).  All pointers are
- * device memory; `ws` is a scratch block of shems_ddpg_workspace_floats() floats (zero it once).
- *   shems_ddpg_critic_grad : getData (sample WITH replacement, MPS:31-42) -> normalize ->
- *                            a' = actor_target(s'), q' = critic_target([s';a']), y = r + gamma(1-done)q'
- *                            -> d mse(critic([s;a]), y) / d critic  into grad_critic [129001]
+/* replay() (DDPG.jl:121-145).  Batch <= 128 (BATCH_SIZE = 120 in the tuned config).  All pointers are device memory;
+ * `ws` is a scratch block of shems_ddpg_workspace_floats() floats (zero it once).
+ *
+ * Single replica: shems_ddpg_update runs the whole function in five dependent launches (csrc/shems_ddpg.hip):
+ *   getData (sample WITH replacement, MPS:31-42) -> normalize -> a' = actor_target(s'), q' = critic_target([s';a']),
+ *   y = r + gamma(1-done)q' -> update_model!(critic, opt_crit, loss_crit, y, s, a) -> update_model!(actor, opt_act,
+ *   loss_act, s) -> soft_update!(actor_target, actor), soft_update!(critic_target, critic).
+ * ADAM and the soft target update of an element are applied by the workgroup that produced its gradient.
+ *
+ * Data-parallel replicas exchange gradients at two points; for them the same function is split there:
+ *   shems_ddpg_critic_grad : ... -> d mse(critic([s;a]), y) / d critic  into grad_critic [129001]
  *   (all-reduce grad_critic across replicas here)
  *   shems_ddpg_critic_apply: ADAM(eta_crit) on critic, then soft_update!(critic_target, critic; tau)
  *   shems_ddpg_actor_grad  : d(-mean(critic([s; actor(s)]))) / d actor  into grad_actor [129002]
  *   (all-reduce grad_actor here)
  *   shems_ddpg_actor_apply : ADAM(eta_act) on actor, then soft_update!(actor_target, actor; tau)
+ * Both forms run the same gradient kernels and the same ADAM arithmetic: with grad_scale = 1 they produce the same bits.
  * ADAM is Flux 0.12.1's: m,v float32 arrays, scalars in Float64, bias-correction powers beta^t are
  * host state passed by value (bp1 = beta1^t, bp2 = beta2^t for the t-th step, t >= 1). */
 typedef struct shems_ddpg {
@@ -253,13 +259,16 @@ typedef struct shems_ddpg {
     float *losses;                                  /* [2] out: critic mse, actor loss (-mean q)   */
     float gamma, tau;
     int32_t batch;                                  /* BATCH_SIZE (<= 128)                         */
-    int32_t fuse_l1;                                /* single replica only (no all-reduce between *_grad and *_apply): 1 = the
-                                                     * layer-1 rows gW1/gb1 are produced inside the ADAM launch of *_apply instead of
-                                                     * by a launch of *_grad; grad_* is complete only after the matching *_apply.
-                                                     * Same bits either way.  Must be 0 when gradients are exchanged.              */
+    int32_t reserved;                               /* (round 1: fuse_l1) ignored                  */
 } shems_ddpg;
 
 int shems_ddpg_workspace_floats(int64_t *out);
+/* The whole replay() for one replica.  grad_actor / grad_critic still receive the complete gradients.  excl_pos / excl_count:
+ * as shems_ddpg_critic_grad_ex (0, 0 = none).  d_publish: optional second copy [129002] of the updated actor (see
+ * shems_ddpg_actor_apply_pub), or NULL. */
+int shems_ddpg_update(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                      int64_t excl_pos, int64_t excl_count, double eta_crit, double bp1_crit, double bp2_crit,
+                      double eta_act, double bp1_act, double bp2_act, float *d_publish, void *stream);
 int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len,
                            uint64_t seed, uint32_t tick, void *stream);
 /* Pipelined variant for running replay() on a second stream WHILE the fused act/step kernel of the same vector step
@@ -302,6 +311,9 @@ typedef struct shems_group {
 int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,
                              double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window,
                              void *stream);
+int shems_ddpg_group_update(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
+                            uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit,
+                            double eta_act, double bp1_act, double bp2_act, void *stream);
 int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g,
                                  int64_t ring_len, uint64_t seed, uint32_t tick, void *stream);
 int shems_ddpg_group_critic_apply(const shems_ddpg *d0, const shems_group *g, double eta, double bp1, double bp2,

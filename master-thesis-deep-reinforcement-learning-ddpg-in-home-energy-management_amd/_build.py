@@ -44,15 +44,19 @@ def _deps(src):
     return d
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), tag=""):
+    """defines / tag: a diagnostic variant (e.g. defines=("SHEMS_STAMP",), tag="_stamp" -> libshems_hip_stamp.so with in-kernel
+    phase stamps, tools/stamp_update.py); the product library is the default call."""
     hipcc = _hipcc()
     objs = []
     rebuilt = False
+    lib = os.path.join(HERE, f"libshems_hip{tag}.so")
     for name, extra in UNITS:
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             continue
-        obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + ".o")
+        extra = list(extra) + ["-D" + d for d in defines]
+        obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + tag + ".o")
         stale = force or not os.path.exists(obj) or any(os.path.getmtime(p) > os.path.getmtime(obj) for p in _deps(src))
         if stale:
             cmd = [hipcc, *COMMON, *extra, "-c", src, "-o", obj]
@@ -61,14 +65,17 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
             rebuilt = True
         objs.append(obj)
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if rebuilt or not os.path.exists(lib):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamp" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, defines=("SHEMS_STAMP",), tag="_stamp"))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

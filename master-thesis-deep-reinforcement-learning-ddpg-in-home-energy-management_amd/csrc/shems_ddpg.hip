@@ -1,32 +1,41 @@
-// shems_ddpg.hip -- one DDPG update (the reference's replay(), DDPG.jl:121-145) as a short chain of
-// gfx950 kernels: GPU-resident minibatch sampling/gather, target pass, critic forward/backward,
-// actor forward/backward through the critic, Flux-style ADAM and the soft target updates.
+// shems_ddpg.hip -- one DDPG update (the reference's replay(), DDPG.jl:121-145) as FIVE dependent gfx950 launches:
+// GPU-resident minibatch sampling/gather, target pass, critic forward/backward, actor forward/backward through the
+// critic, Flux-style ADAM and the soft target updates.
 //
-// Shapes: BATCH = 120 padded to BP = 128 columns (pad columns carry zero error signals); everything
-// is FEATURE-major "[k][m]" (sample index contiguous) as in shems_policy.hip, so the 250x500 layer
-// runs on v_mfma_f32_32x32x2_f32 with the weights as the A operand straight out of Flux's [in][out]
-// layout.  At batch 120 one update is 307.8 MFLOP (~2 us at the fp32 MFMA peak): it is bound by
-// dependent-launch boundaries (~1.5 us each) and by L2/Infinity-Cache latency, not by the matrix
-// pipe.  Design rules that follow from the first measured version (profiles/r01_train_v1_*):
-//   * no single-workgroup latency chains: every phase is spread over 64-144 workgroups, shaped so that no workgroup type
-//     is the straggler of its launch (the 8 x 64-row gb2/gW3 workgroups once were: -4 us for halving them);
-//   * operands are staged into LDS with wide, independent loads, ALL of a phase's global loads issued before the first
-//     wait (one exposed latency per phase), never fetched per MFMA k-step; phases that only one wave finishes read
-//     their LDS constants in one batch;
-//   * nothing derivable is stored: layer-1 activations, their relu masks and the back-propagated
-//     layer-2 error D2 = (W3 d3) .* (h2 > 0) are recomputed inside the kernels that consume them;
-//   * cross-workgroup reductions go through partial slabs summed in a fixed order (bitwise
-//     reproducible; no float atomics, no device-scope fences -- on this 8-XCD part a release writes the L2 back).
-// 8 launches per update on a single replica (the loss / actor heads run in the prologue of the bwd workgroups, the
-// minibatch sampling / gather and the layer-1 image packing inside the first forward launch, the layer-1 gradient rows
-// inside the ADAM launch):
-//   fwd(actor_t) -> fwd(critic_t | critic | actor) -> bwd(critic) -> adam+soft(critic)
-//   fwd(critic on [s; actor(s)]) -> bwd(input grad) -> bwd(actor) -> adam+soft(actor)
-// and 10 when replicas exchange gradients (the all-reduce needs the complete gradient before ADAM):
-//   ... bwd(critic) -> l1bwd(critic) [all-reduce] adam+soft(critic) ... bwd(actor) -> l1bwd(actor) [all-reduce] adam+soft(actor)
+// Shapes: BATCH = 120 padded to BP = 128 columns (pad columns carry zero error signals); everything is FEATURE-major
+// "[k][m]" (sample index contiguous) as in shems_policy.hip, so the 250x500 layer runs on v_mfma_f32_32x32x2_f32 with the
+// weights as the A operand straight out of Flux's [in][out] layout.  At batch 120 one update is 307.8 MFLOP (~2 us at the
+// fp32 MFMA peak): it is bound by dependent-launch boundaries and by L2/Infinity-Cache latency, not by the matrix pipe, so
+// the design minimises the NUMBER of grid-wide dependencies (round 1 had 8 launches; this has 5):
+//
+//   K1  k_fwd (opens the update: every tile workgroup samples / gathers / normalises the minibatch columns it needs)
+//         actor_target(s') | critic(s, a) | actor(s)                              three independent forward passes
+//   K2  k_mid   critic_target(s', a')  |  E_c = (W3c .* mask2c) W2c^T  |  E_a0, E_a1 = (W3a[.,j] .* mask2a) W2a^T
+//   K3  k_grad  critic: every gradient block from batch contractions only + ADAM + soft update IN THE SAME workgroup
+//   K4  k_fwd<QG> critic(s, actor(s)) with the updated critic: forward AND input gradient fused per n-tile
+//   K5  k_grad  actor: as K3
+//
+// Two identities remove the cross-workgroup reductions that used to force extra launches:
+//   * layer-1 error through a network with output width o:  D1[k][m] = mask1[k][m] * sum_j d3[j][m] * E_j[k][m] with
+//     E_j[k][m] = sum_n W2[k][n] W3[n][j] mask2[n][m], which does NOT depend on the error signal d3 -- it is computed in K2,
+//     next to the target critic's forward pass, as soon as the forward masks exist.  The gradient launches K3 / K5 then
+//     contract over the BATCH only, so each gradient tile is complete inside one workgroup and that workgroup applies ADAM
+//     and the soft target update to exactly the elements it produced (no ADAM launch, no gradient round trip);
+//   * the actor loss -mean(q) has a constant upstream gradient (-1/B), so the critic's backward pass on [s; actor(s)] needs
+//     no finished forward pass: each n-tile workgroup of K4 back-propagates through its own 32 hidden units right after
+//     computing them (same W2 panel, still in LDS) and emits a partial d loss / d a; K5's prologue adds the 16 partials.
+// In place updates are race free because no launch reads a parameter another workgroup of the same launch writes: K3 / K5
+// take W3 / b3 from a frozen copy K1 puts in the workspace, layer 1 from the packed images K1 builds, and nothing else of
+// the network being updated.
+// When replicas exchange gradients (data parallel) K3 / K5 only store the gradient and a k_adam_soft sweep follows the
+// all-reduce: 7 launches.  Both forms give the same bits (same gradient code, same ADAM function).
+// Other rules kept from round 1: operands staged into LDS with wide independent loads, ALL of a phase's global loads issued
+// before the first wait, clamped and never predicated; partial slabs summed in a fixed order (bitwise reproducible; no float
+// atomics, no device-scope fences).
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <type_traits>
 
 #include "philox.h"
 #include "shems_internal.h"
@@ -35,12 +44,22 @@ namespace shems {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Diagnostic build only (-DSHEMS_STAMP, tools/stamp_update.py): thread 0 of every workgroup records (s_memtime, s_memrealtime) at the
+// phase boundaries into a buffer of its own -- no product code reads it, the product library contains none of this.
+#ifdef SHEMS_STAMP
+__device__ unsigned long long *g_stamps = nullptr;             // [5 launches][1024 workgroups][16 stamps][2]
+#define STAMP(region, i) do { if (threadIdx.x == 0 && g_stamps) { unsigned long long *sp_ = g_stamps + ((((size_t)(region) * 1024 + blockIdx.x + 256 * blockIdx.y) * 16 + (i)) * 2); \
+        sp_[0] = __builtin_amdgcn_s_memtime(); sp_[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define STAMP(region, i)
+#endif
+
 constexpr int BP = 128;            // padded batch (columns)
 constexpr int H1N = SHEMS_L1, H2N = SHEMS_L2;
 constexpr int SIN = 9, AIN = 2, CIN = 11;
 constexpr int NT = 16;             // n-tiles of 32 over the 500 (512) layer-2 outputs
 constexpr int KT = 8;              // k-tiles of 32 over the 250 (256) layer-1 outputs
-constexpr int NQ = 8;              // blocks of the n range for the backward tiles
+constexpr int NQ = 8;              // blocks of the n range for the E / gradient tiles
 constexpr int NQW = 64;            // n per block (the last block holds the 52 columns 448..499)
 
 __host__ __device__ constexpr int off_b1(int in) { return in * H1N; }
@@ -62,24 +81,42 @@ constexpr int64_t WS_D3C = WS_API + AIN * BP;         // [1][BP]  dq of the crit
 constexpr int64_t WS_D3Q = WS_D3C + BP;               // [1][BP]  -1/B (actor loss through the critic)
 constexpr int64_t WS_D3A = WS_D3Q + BP;               // [2][BP]  error at the actor's pre-tanh output
 constexpr int64_t WS_IDX = WS_D3A + AIN * BP;         // [BP]     sampled ring slots (int32)
-constexpr int64_t WS_DAP = WS_IDX + BP;               // [KT][NQ][2][BP]  partial d loss / d a_pi
-constexpr int64_t WS_W1T = WS_DAP + KT * NQ * AIN * BP;   // [4 nets][12][256] packed layer-1 images (see w1m below)
-constexpr int64_t WS_SLOT0 = WS_W1T + 4 * 12 * 256;
+constexpr int64_t WS_DAP = WS_IDX + BP;               // [NT][2][BP]  per-n-tile partial d loss / d a_pi (K4)
+constexpr int64_t WS_FW3C = WS_DAP + NT * AIN * BP;   // [512]     frozen critic W3 (rows >= 500 zero)
+constexpr int64_t WS_FW3A = WS_FW3C + 512;            // [512][2]  frozen actor W3
+constexpr int64_t WS_FB3 = WS_FW3A + 1024;            // [8]       frozen b3: critic, critic_target, actor[0], actor[1]
+constexpr int64_t WS_W1T = WS_FB3 + 8;                // [4 nets][12][256] packed layer-1 images (see w1m below)
+constexpr int64_t WS_EA1 = WS_W1T + 4 * 12 * 256;     // [NQ][250][BP]  partial E of the actor's second output
+constexpr int64_t WS_SLOT0 = WS_EA1 + NQ * H1N * BP;
 constexpr int64_t SL_H2 = 0;                          // [500][BP]          relu(W2' h1 + b2)
 constexpr int64_t SL_P3 = SL_H2 + H2N * BP;           // [NT][2][BP]        per-n-tile partial sums of layer 3
-constexpr int64_t SL_D1P = SL_P3 + NT * 2 * BP;       // [NQ][250][BP]      partial (unmasked) error at layer 1
-constexpr int64_t SL_SIZE = SL_D1P + NQ * H1N * BP;
+constexpr int64_t SL_EP = SL_P3 + NT * 2 * BP;        // [NQ][250][BP]      partial E (first output) over the n blocks
+constexpr int64_t SL_SIZE = SL_EP + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
+static_assert(WS_W1T % 4 == 0 && WS_SLOT0 % 4 == 0 && SL_SIZE % 4 == 0, "16-byte aligned blocks");
 __host__ __device__ inline float *w1t_of(float *ws, int net) { return ws + WS_W1T + (int64_t)net * 12 * 256; }   // net = SLOT_* < 4
 constexpr int64_t WS_FLOATS = WS_SLOT0 + N_SLOTS * SL_SIZE;
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
 
+// Sum over the 64 lanes, returned in EVERY lane.  Data-parallel-primitive adds on the VALU (quad swaps, row mirrors, the two row
+// broadcasts), no ds_bpermute round trips through the LDS crossbar: six dependent v_add_f32 instead of six ~100-cycle shuffles.
+// Fixed association: ((pairs) quads) half rows) rows), then (row0 + row1) + (row2 + row3).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float x)
+{
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false);   // masked rows read 0.0f
+    return x + __builtin_bit_cast(float, y);
+}
 __device__ __forceinline__ float wave_sum(float x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
+    x = dpp_add<0xB1, 0xF>(x);         // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E, 0xF>(x);         // quad_perm [2,3,0,1]
+    x = dpp_add<0x141, 0xF>(x);        // row_half_mirror
+    x = dpp_add<0x140, 0xF>(x);        // row_mirror: every lane of a row of 16 now holds the row's sum
+    x = dpp_add<0x142, 0xA>(x);        // row_bcast15 into rows 1, 3
+    x = dpp_add<0x143, 0xC>(x);        // row_bcast31 into rows 2, 3: lane 63 = total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
 // Where a network input [in][BP] comes from: rows 0..8 = a normalised-state block, rows 9..10 (critics) either the
@@ -94,7 +131,13 @@ struct XSrc {
 
 // Learner groups (shems_group): learner l's copy of every device buffer is learner 0's pointer + l * stride bytes.
 template <class T>
-__device__ __forceinline__ T *gsh(T *p, int64_t off) { return p ? reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off) : p; }
+__device__ __forceinline__ T *gsh(T *p, int64_t off)
+{
+    // byte arithmetic on the pointer itself (no round trip through an integer): the compiler keeps the global address space of the
+    // kernel argument it came from and emits global_load / global_store instead of flat accesses
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return p ? reinterpret_cast<T *>(reinterpret_cast<B *>(p) + off) : p;
+}
 __device__ __forceinline__ void gshift(XSrc &x, int64_t off)
 {
     x.X = gsh(x.X, off); x.A = gsh(x.A, off); x.P3 = gsh(x.P3, off); x.b3 = gsh(x.b3, off); x.publish = gsh(x.publish, off);
@@ -113,19 +156,20 @@ __device__ __forceinline__ void gshift(shems_replay &r, int64_t off)
 
 // Split in two so that a kernel can issue these loads together with everything else it fetches and only then start consuming
 // (one exposed global latency per kernel phase instead of one per helper).  blockDim = 256: one action element per thread.
-template <int IN> struct XRegs { float v[5]; float a; float b3v; float p[NT]; };
+template <int IN> struct XRegs { float v[5]; float ab[2]; float p[NT]; };      // ab = {stored action | actor b3}: an array member, like the others (scalar members of this by-reference aggregate were left in scratch)
 template <int IN>
 __device__ __forceinline__ void build_x_load(const XSrc &s, XRegs<IN> &R)
 {
 #pragma unroll
     for (int it = 0; it < 5; ++it) { const int e = it * 256 + threadIdx.x; R.v[it] = s.X[min(e, SIN * BP - 1)]; }   // clamped, never predicated:
     // a guarded load becomes a branch + its own s_waitcnt, which serialises the batch
+    R.ab[0] = 0.0f; R.ab[1] = 0.0f;
     if (IN == CIN) {
         const int e = threadIdx.x, o = e / BP, m = e - o * BP;
         if (s.A) {
-            R.a = s.A[e];
+            R.ab[0] = s.A[e];
         } else {
-            R.b3v = s.b3[o];
+            R.ab[1] = s.b3[o];
 #pragma unroll
             for (int t = 0; t < NT; ++t) R.p[t] = s.P3[(t * 2 + o) * BP + m];
         }
@@ -144,9 +188,9 @@ __device__ __forceinline__ void build_x_store(const XSrc &s, const XRegs<IN> &R,
         const int e = threadIdx.x;                                                // AIN * BP == blockDim
         float a;
         if (s.A) {
-            a = R.a;
+            a = R.ab[0];
         } else {
-            float acc = R.b3v;
+            float acc = R.ab[1];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc += R.p[t];
             a = tanhf(acc);                                       // Dense(500, 2, tanh)
@@ -155,48 +199,48 @@ __device__ __forceinline__ void build_x_store(const XSrc &s, const XRegs<IN> &R,
         xs[SIN * BP + e] = a;
     }
 }
-template <int IN>
-__device__ __forceinline__ void build_x(const XSrc &s, float *xs /*LDS [IN][BP]*/, bool publisher)
-{
-    XRegs<IN> R;
-    build_x_load<IN>(s, R);
-    build_x_store<IN>(s, R, xs, publisher);
-}
 
 // Layer 1 also runs on the matrix pipe: pre[k][m] = sum_j w1m[j][k] * xs[j][m] with K = 12 = 6 MFMA k-steps, where
 //   w1m [12][256] = rows 0..in-1: W1[j][k]; row 11: b1[k]; everything else (rows in..10, columns 250..255) zero
 //   xs  [12][BP]  = rows 0..in-1: the network input; row 11: 1.0 (bias); rows in..10 zero.
-// The packed image w1m lives in the workspace (the update's first launch builds it for all four networks, the
-// critic's ADAM launch refreshes the critic's); staging it is a straight 12 KB float4 copy, three loads per thread.
+// K1 builds the packed images of the four networks in the workspace (from the weights as they stand when the update starts);
+// staging one is a straight 12 KB float4 copy, three loads per thread.  Workgroups that need the image of weights changed
+// earlier in the same update (K4) pack it themselves from the parameter block.
 constexpr int W1K = 12, W1C = 256;
-struct W1mRegs { float4 v[3]; };
+// (a native vector type, not HIP's float4 struct: copies of that struct from global memory into a by-reference aggregate become
+// memcpy intrinsics into a private alloca that is never promoted -- 64 B of scratch per lane and a scratch round trip per launch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct W1mRegs { f32x4 v0, v1, v2; };
 __device__ __forceinline__ void stage_w1m_load(const float *__restrict__ g, W1mRegs &R)
 {
-#pragma unroll
-    for (int it = 0; it < 3; ++it) R.v[it] = reinterpret_cast<const float4 *>(g)[it * 256 + threadIdx.x];
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g) + threadIdx.x;
+    R.v0 = g4[0]; R.v1 = g4[256]; R.v2 = g4[512];
 }
 __device__ __forceinline__ void stage_w1m_store(const W1mRegs &R, float *l)
 {
-#pragma unroll
-    for (int it = 0; it < 3; ++it) reinterpret_cast<float4 *>(l)[it * 256 + threadIdx.x] = R.v[it];
+    f32x4 *l4 = reinterpret_cast<f32x4 *>(l) + threadIdx.x;
+    l4[0] = R.v0; l4[256] = R.v1; l4[512] = R.v2;
 }
-__device__ __forceinline__ void stage_w1m(const float *__restrict__ g, float *l)
+struct PackRegs { float v[12]; };
+__device__ __forceinline__ void pack_w1m_load(const float *__restrict__ P, int in, PackRegs &R)
 {
-    W1mRegs R;
-    stage_w1m_load(g, R);
-    stage_w1m_store(R, l);
-}
-__device__ __forceinline__ void pack_w1m(const float *__restrict__ P, int in, float *__restrict__ g)
-{
-    float v[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) {                       // thread = column k (blockDim 256), unconditional clamped loads
         const int k = min((int)threadIdx.x, H1N - 1);
-        v[j] = P[(j == W1K - 1 ? in : min(j, in - 1)) * H1N + k];          // row `in` of the block is b1
+        R.v[j] = P[(j == W1K - 1 ? in : min(j, in - 1)) * H1N + k];        // row `in` of the block is b1
     }
+}
+__device__ __forceinline__ void pack_w1m_store(const PackRegs &R, int in, float *__restrict__ g)
+{
 #pragma unroll
     for (int j = 0; j < 12; ++j)
-        g[j * W1C + threadIdx.x] = ((j < in || j == W1K - 1) && (int)threadIdx.x < H1N) ? v[j] : 0.0f;
+        g[j * W1C + threadIdx.x] = ((j < in || j == W1K - 1) && (int)threadIdx.x < H1N) ? R.v[j] : 0.0f;
+}
+__device__ __forceinline__ void pack_w1m(const float *__restrict__ P, int in, float *__restrict__ g)
+{
+    PackRegs R;
+    pack_w1m_load(P, in, R);
+    pack_w1m_store(R, in, g);
 }
 // One 32(k) x 32(m) tile of layer-1 pre-activations, D layout (row k = (r&3)+8(r>>2)+4*lh, column m = lane&31).
 __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int kbase, int mbase, int li, int lh)
@@ -227,128 +271,160 @@ struct PrepArgs {
     int64_t excl_pos, excl_count;
 };
 // Thread m < BP: minibatch column m.  Samples the ring slot (StatsBase.sample with replacement, MPS:33), gathers the transition and
-// normalises.  xs2 (LDS [.][BP], may be null) receives normalize(s'); when `publish`, everything later launches read goes to the
-// workspace: normalize(s), normalize(s'), a, r, done, d(-mean q)/dq and the sampled slots.
-__device__ __forceinline__ void prep_column(const PrepArgs &A, int m, float *xs2, bool publish)
+// normalises.  `which` says what the calling tile workgroup needs in its LDS input block xs [.][BP]: 0 = normalize(s') (target
+// actor), 1 = normalize(s) + the stored action (critic), 2 = normalize(s) (actor); xs == null with `publish`: the publishing
+// workgroup, which writes everything later launches read to the workspace: normalize(s), normalize(s'), a, r, done,
+// d(-mean q)/dq and the sampled slots.  Split in a load and a store half so that the gather (whose addresses need no memory: the
+// slot comes from the counter RNG) is in flight together with every other load of the workgroup's first phase.
+struct PrepRegs { float s[SIN], s2[SIN], lo[SIN], hi[SIN], a[2], r, dn; int64_t j; };
+__device__ __forceinline__ void prep_load(const PrepArgs &A, int m, int which, bool publish, PrepRegs &R)
 {
     const shems_ddpg &d = A.d;
     const shems_replay &ring = A.ring;
-    float *ws = d.ws;
-    float s[SIN], s2[SIN], a0 = 0.f, a1 = 0.f, r = 0.f, dn = 0.f;
-    int64_t j = -1;
-    const bool live = m < d.batch;
-    if (live) {
-        const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, A.tick, kStreamSample, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
-        j = (int64_t)(w % (uint32_t)(A.ring_len - A.excl_count));
-        if (A.excl_count > 0) j = (A.excl_pos + A.excl_count + j) % ring.capacity;     // skip the window another stream is writing
-#pragma unroll
-        for (int k = 0; k < SIN; ++k) s2[k] = ring.s2[j * SIN + k];
-        if (publish) {
-#pragma unroll
-            for (int k = 0; k < SIN; ++k) s[k] = ring.s[j * SIN + k];
-            a0 = ring.a[j * 2]; a1 = ring.a[j * 2 + 1];
-            r = ring.r[j];
-            dn = ring.done[j] ? 1.0f : 0.0f;
-        }
-    }
+    const bool want_s2 = publish || which == 0, want_s = publish || which != 0, want_a = publish || which == 1;
+    const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, A.tick, kStreamSample, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+    const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
+    int64_t j = (int64_t)(w % (uint32_t)(A.ring_len - A.excl_count));
+    if (A.excl_count > 0) j = (A.excl_pos + A.excl_count + j) % ring.capacity;         // skip the window another stream is writing
+    R.j = j;                                                                            // (pad columns m >= batch gather a valid slot too and discard it)
 #pragma unroll
     for (int k = 0; k < SIN; ++k) {
-        const float lo = d.s_min[k], den = (d.s_max[k] - lo) + 1e-8f;                 // MPS:56
-        const float x2 = live ? (s2[k] - lo) / den : 0.0f;
-        if (xs2) xs2[k * BP + m] = x2;
+        R.s2[k] = want_s2 ? ring.s2[j * SIN + k] : 0.0f;
+        R.s[k] = want_s ? ring.s[j * SIN + k] : 0.0f;
+        R.lo[k] = d.s_min[k]; R.hi[k] = d.s_max[k];
+    }
+    R.a[0] = want_a ? ring.a[j * 2] : 0.0f;
+    R.a[1] = want_a ? ring.a[j * 2 + 1] : 0.0f;
+    R.r = publish ? ring.r[j] : 0.0f;
+    R.dn = publish ? (ring.done[j] ? 1.0f : 0.0f) : 0.0f;
+}
+__device__ __forceinline__ void prep_store(const PrepArgs &A, int m, float *xs, int which, bool publish, const PrepRegs &R)
+{
+    const shems_ddpg &d = A.d;
+    float *ws = d.ws;
+    const bool live = m < d.batch;
+#pragma unroll
+    for (int k = 0; k < SIN; ++k) {
+        const float lo = R.lo[k], den = (R.hi[k] - lo) + 1e-8f;                       // MPS:56
+        const float x2 = live ? (R.s2[k] - lo) / den : 0.0f;
+        const float x1 = live ? (R.s[k] - lo) / den : 0.0f;
+        if (xs) xs[k * BP + m] = which == 0 ? x2 : x1;
         if (publish) {
-            ws[WS_XT + k * BP + m] = live ? (s[k] - lo) / den : 0.0f;
+            ws[WS_XT + k * BP + m] = x1;
             ws[WS_X2T + k * BP + m] = x2;
         }
     }
+    const float a0 = live ? R.a[0] : 0.0f, a1 = live ? R.a[1] : 0.0f;
+    if (xs) {
+        xs[9 * BP + m] = which == 1 ? a0 : 0.0f;
+        xs[10 * BP + m] = which == 1 ? a1 : 0.0f;
+        xs[11 * BP + m] = 1.0f;                                                        // bias row
+    }
     if (publish) {
         ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
-        ws[WS_R + m] = r; ws[WS_DONE + m] = dn;
+        ws[WS_R + m] = live ? R.r : 0.0f; ws[WS_DONE + m] = live ? R.dn : 0.0f;
         ws[WS_D3Q + m] = live ? -1.0f / (float)d.batch : 0.0f;                        // d(-mean q)/dq
-        reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = (int32_t)j;
+        reinterpret_cast<int32_t *>(ws + WS_IDX)[m] = live ? (int32_t)R.j : -1;
     }
 }
 
-// ---- kernel B: layers 1+2 forward for one 32-wide n-tile and all 128 columns --------------------------
+// ---- layers 1+2 forward for one 32-wide n-tile -------------------------------------------------------------------------
 struct FwdJob {
-    const float *w1t;      // packed layer-1 image [250][12] of this network
+    const float *w1t;      // packed layer-1 image [12][256] of this network (PREP == 0)
     const float *P;        // parameter block
     int in;                // 9 (actor nets) or 11 (critic nets)
     int out;               // 2 or 1
+    int which;             // K1: what prep_column gathers for this job (0 s', 1 s + a, 2 s)
     XSrc x;
     float *H2;             // [500][BP] or null (target nets: nothing downstream needs it)
     float *P3;             // [NT][2][BP] layer-3 partials of this n-tile
+    const float *d3q;      // QG: [BP] upstream gradient of q (-1/B, 0 in the pad columns)
+    float *DAP;            // QG: [NT][2][BP] partial d loss / d a_pi
 };
-struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; int mt; PrepArgs pa; };    // prep: this launch opens the update (see fwd_body)
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; };    // prep: 1 = this launch opens the update (K1), 2 = K4
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
     J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
+    J.d3q = gsh(J.d3q, off); J.DAP = gsh(J.DAP, off);
 }
 
-// Workgroup = one 32-wide n-tile x MT columns of the batch.  K is always cut into four quarters of 64 hidden units (rows 250..255 are
-// zero), each accumulated as its own 32-MFMA chain and added in the fixed order ((q0 + q1) + q2) + q3, so both shapes give the
-// same bits:
-//   MT = 32 (a single learner: 64 workgroups per network, latency): the 4 waves take one K quarter each;
-//   MT = 64 (learner groups of >= 8: 32 workgroups per network, half the redundant panel loads): wave w takes the column tile
-//            w & 1 and the K half w >> 1, i.e. two quarters with an accumulator each.
-// Waves with a K part other than the first hand their accumulators to the first through LDS at the end.
-constexpr int FWD_KQ = 64;                                    // k rows per K-quarter (32 MFMA pairs)
-template <int MT> struct FwdShape {
-    static constexpr int NMW = MT / 32;                       // column tiles (waves) per workgroup
-    static constexpr int NKW = 4 / NMW;                       // K parts (waves) per column tile
-    static constexpr int KPW = 256 / NKW;                     // k rows per wave
-    static constexpr int QPW = KPW / FWD_KQ;                  // K quarters per wave
-    static constexpr int LDS = (4 * KPW * 32 + 256 * 32 + W1K * BP + W1K * W1C + 96) * 4;
+// Workgroup = one 32-wide n-tile x 32 columns of the batch (64 workgroups per network).  K is cut into four quarters of 64 hidden
+// units (rows 250..255 are zero), one per wave, each accumulated as its own 32-MFMA chain; the quarters are added in the fixed
+// order ((q0 + q1) + q2) + q3.
+//   * Layer 1 (K = 12, matrix pipe) leaves wave w with the pre-activations of ITS 64 hidden units x its 32 columns in registers, in
+//     the MFMA D layout: lane (column, half) holds rows (r & 3) + 8 (r >> 2) + 4 half of each 32-row tile.  Layer 2 contracts over
+//     those 64 units in any order, so its k-step r simply takes relu(t[r]) as the B operand -- straight from the registers -- and
+//     fetches the matching W2 rows (r & 3) + 8 (r >> 2) + 4 half as the A operand: no LDS round trip for the activations.
+//   * Every wave hands its partial tile to the others through LDS and finishes four of the sixteen accumulator rows (bias, relu,
+//     store, layer-3 partial), so the epilogue is spread over the four SIMDs.
+// QG (K4, the updated critic on [s; actor(s)]): after the forward tile the workgroup back-propagates the constant upstream gradient
+// through its own 32 hidden units -- M[n][m] = d3q[m] W3[n] (h2 > 0), D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m] (the W2 panel is
+// still in LDS; wave w produces the k rows of its quarter, whose layer-1 tiles it still holds in registers for the relu mask) --
+// and emits the tile's share of d loss / d a = W1[9.., k] (mask1 .* D1part).
+template <bool QG> struct FwdShape {
+    static constexpr int WST = QG ? 36 : 32;                  // row stride of the W2 panel (QG also reads it along n: 36 keeps the
+                                                              // float4 staging stores aligned and that second read 2-way at worst)
+    static constexpr int LDS = (256 * WST + W1K * BP + W1K * W1C + 96 + 4 * 16 * 64 + 4 * 2 * 32 + (QG ? 32 * 32 + 4 * 2 * 32 : 0)) * 4;
 };
-constexpr int FWD_LDS = FwdShape<64>::LDS;                    // the larger of the two
 
-#ifdef ABL_STAMP
-#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { stamps[2*(i)] = __builtin_amdgcn_s_memtime(); stamps[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define STAMP(i)
-#endif
-template <int IN, bool PREP, int MT>
+template <int IN, int PREP, bool QG>
 __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const PrepArgs *pa)
 {
-    typedef FwdShape<MT> SH;
-#ifdef ABL_STAMP
-    unsigned long long *stamps = reinterpret_cast<unsigned long long *>(const_cast<float *>(J.P3) + 100000);   // unused part of the slot
-#endif
-    STAMP(0);
-    float *Hc = smem;                          // [4 waves][KPW][32]  relu(layer 1): this wave's K part x its 32 columns
-    float *Wc = Hc + 4 * SH::KPW * 32;         // [256][32]  W2 panel (rows >= 250: zero)
-    float *xs = Wc + 256 * 32;                 // [12][BP]
+    typedef FwdShape<QG> SH;
+    constexpr int WST = SH::WST;
+    float *Wc = smem;                          // [256][WST]  W2 panel (rows >= 250: zero)
+    float *xs = Wc + 256 * WST;                // [12][BP]
     float *w1 = xs + W1K * BP;                 // w1m [12][256]
     float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
+    float *xch = ep + 96;                      // [4 quarters][16 rows][64 lanes]
+    float *pp = xch + 4 * 16 * 64;             // [4 row groups][2][32] layer-3 partials
+    float *Mt = pp + 4 * 2 * 32;               // QG: [32 n][32 m]
+    float *red = Mt + 32 * 32;                 // QG: [4 quarters][2][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    constexpr int kMTiles = BP / MT;           // workgroups per n-tile
-    if (PREP && (int)blockIdx.x >= NT * kMTiles) {
-        // The five extra workgroups of an update's first launch: one publishes what the later launches read from the workspace
-        // (the sampled, gathered and normalised minibatch), four pack the layer-1 images of the four networks.  Kept off the tile
+    constexpr int kMTiles = BP / 32;           // workgroups per n-tile
+    constexpr int kRegion = PREP == 1 ? 0 : PREP == 0 ? 1 : 3;
+    (void)kRegion;
+    STAMP(kRegion, 0);
+    if (PREP == 1 && (int)blockIdx.x >= NT * kMTiles) {
+        // The six extra workgroups of an update's first launch (job 0 only): one publishes what the later launches read from the
+        // workspace (the sampled, gathered and normalised minibatch), four pack the layer-1 images of the four networks, one
+        // freezes the output layers the gradient launches must read while their owners are updated in place.  Kept off the tile
         // workgroups so that none of those runs longer than the others.
+        if (blockIdx.y != 0) return;
         const int duty = (int)blockIdx.x - NT * kMTiles;
+        const shems_ddpg &d = pa->d;
         if (duty == 0) {
-            if (tid < BP) prep_column(*pa, tid, nullptr, true);
-        } else {
+            if (tid < BP) {
+                PrepRegs pr;
+                prep_load(*pa, tid, 0, true, pr);
+                prep_store(*pa, tid, nullptr, 0, true, pr);
+            }
+        } else if (duty <= 4) {
             const int net = duty - 1;
-            const shems_ddpg &d = pa->d;
             const float *Pn = net == SLOT_ACTOR_T ? d.actor_t : net == SLOT_CRITIC_T ? d.critic_t : net == SLOT_CRITIC ? d.critic : d.actor;
             pack_w1m(Pn, (net == SLOT_CRITIC_T || net == SLOT_CRITIC) ? CIN : SIN, w1t_of(d.ws, net));
+        } else {
+            float *ws = d.ws;
+            for (int e = tid; e < 512; e += 256) ws[WS_FW3C + e] = e < H2N ? d.critic[off_w3(CIN) + e] : 0.0f;
+            for (int e = tid; e < 1024; e += 256) ws[WS_FW3A + e] = e < 2 * H2N ? d.actor[off_w3(SIN) + e] : 0.0f;
+            if (tid < 8)
+                ws[WS_FB3 + tid] = tid == 0 ? d.critic[off_b3(CIN, 1)] : tid == 1 ? d.critic_t[off_b3(CIN, 1)]
+                                 : tid == 2 ? d.actor[off_b3(SIN, 2)] : tid == 3 ? d.actor[off_b3(SIN, 2) + 1] : 0.0f;
         }
         return;
     }
-    const int n0 = ((int)blockIdx.x / kMTiles) * 32;
-    const int mt = wave % SH::NMW, kh = wave / SH::NMW, mbase = MT * ((int)blockIdx.x % kMTiles) + 32 * mt;
+    const int ntile = (int)blockIdx.x / kMTiles, n0 = ntile * 32;
+    const int mbase = 32 * ((int)blockIdx.x % kMTiles);
     const float *__restrict__ P = J.P;
 
+    // ---- every global load of the workgroup goes out before the first one is consumed (one exposed latency) ----
     float epv = 0.0f;
-    if (tid < 96) {                            // epilogue constants: in flight while the inputs are staged
+    if (tid < 96) {                            // epilogue constants
         const int nl = tid / 3, c = tid - nl * 3, nc = min(n0 + nl, H2N - 1);
         epv = c == 0 ? P[off_b2(IN) + nc] : P[off_w3(IN) + nc * J.out + min(c - 1, J.out - 1)];
         if (n0 + nl >= H2N || c - 1 >= J.out) epv = 0.0f;
     }
-    // W2[0..255][n0..n0+31] (rows of 128 B, 8 float4 each): 2048 float4, 8 per thread, all issued before the first store.
+    // W2[0..255][n0..n0+31] (rows of 128 B, 8 float4 each): 2048 float4, 8 per thread.
     // Columns >= 500 of the last tile read the next row / b2 (in bounds) and only feed output rows that are discarded.
     const float *__restrict__ W2 = P + off_w2(IN);
     float4 wv[8];
@@ -360,635 +436,324 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     }
     XRegs<IN> xr;
     W1mRegs wr;
-    if (!PREP) {                                   // every global load of the stage goes out before the first one is consumed
-        build_x_load<IN>(J.x, xr);
-        stage_w1m_load(J.w1t, wr);
-    }
-    if (PREP) {
-        // First launch of an update (actor_target on s'): no separate sample/gather/pack launch.  Every tile workgroup samples the
-        // minibatch and gathers + normalises s' straight into its LDS input block, and packs the layer-1 image it needs from the
-        // parameter block; five extra workgroups (above) publish the workspace copies for the later launches.
-        if (tid < BP) prep_column(*pa, tid, xs, false);
-        xs[9 * BP + tid] = 0.0f;                                                    // rows 9, 10 (2 * BP == blockDim)
-        if (tid < BP) xs[11 * BP + tid] = 1.0f;                                     // bias row
-        pack_w1m(P, IN, w1);
+    PackRegs pk;
+    PrepRegs pr;
+    float d3q = 0.0f;
+    if (QG) d3q = J.d3q[mbase + li];
+    if (PREP != 1) build_x_load<IN>(J.x, xr);
+    if (PREP == 0) stage_w1m_load(J.w1t, wr); else pack_w1m_load(P, IN, pk);
+    // First launch of an update: no separate sample/gather/pack launch.  Every tile workgroup samples the minibatch and gathers +
+    // normalises what its network reads straight into its LDS input block, and packs the layer-1 image it needs from the
+    // parameter block; the extra workgroups (above) publish the workspace copies for the later launches.
+    if (PREP == 1 && tid < BP) prep_load(*pa, tid, J.which, false, pr);
+    // ---- consume ----
+    if (PREP == 1) {
+        if (tid < BP) prep_store(*pa, tid, xs, J.which, false, pr);
     } else {
         build_x_store<IN>(J.x, xr, xs, blockIdx.x == 0);
-        stage_w1m_store(wr, w1);
     }
+    if (PREP == 0) stage_w1m_store(wr, w1); else pack_w1m_store(pk, IN, w1);
     if (tid < 96) ep[tid] = epv;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) reinterpret_cast<float4 *>(Wc)[it * 256 + tid] = wv[it];
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid, k = e >> 3, c = e & 7;
+        *reinterpret_cast<float4 *>(Wc + k * WST + 4 * c) = wv[it];
+    }
+    STAMP(kRegion, 1);
     __syncthreads();
-    STAMP(1);
+    STAMP(kRegion, 2);
 
-    // layer 1 on the matrix pipe: KPW / 32 tiles (the rows of this wave's K part) x its 32 columns; the accumulator chains are
-    // independent, so their MFMAs interleave
-    float *Hw = Hc + wave * (SH::KPW * 32);
+    // layer 1 on the matrix pipe: the two 32-row tiles of this wave's K quarter x the workgroup's 32 columns; the accumulator chains
+    // are independent, so their MFMAs interleave
+    f32x16 t[2];
     {
-        constexpr int NT1 = SH::KPW / 32;
-        f32x16 t[NT1];
 #pragma unroll
-        for (int q = 0; q < NT1; ++q)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[q][r] = 0.0f;
-        float xb[W1K / 2], wa[W1K / 2][NT1];      // operand reads in one batch (see l1_tile)
+        float xb[W1K / 2], wa[W1K / 2][2];        // operand reads in one batch (see l1_tile)
 #pragma unroll
         for (int sidx = 0; sidx < W1K / 2; ++sidx) {
             const int j = 2 * sidx + lh;
             xb[sidx] = xs[j * BP + mbase + li];
 #pragma unroll
-            for (int q = 0; q < NT1; ++q) wa[sidx][q] = w1[j * W1C + SH::KPW * kh + 32 * q + li];
+            for (int q = 0; q < 2; ++q) wa[sidx][q] = w1[j * W1C + 64 * wave + 32 * q + li];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sidx = 0; sidx < W1K / 2; ++sidx)
 #pragma unroll
-            for (int q = 0; q < NT1; ++q)
+            for (int q = 0; q < 2; ++q)
                 t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[sidx][q], xb[sidx], t[q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < NT1; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Hw[(32 * q + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = fmaxf(t[q][r], 0.0f);
     }
-    STAMP(2);
-    // this wave reads only its own Hw columns: no barrier needed between the layer-1 writes and the main loop
-    f32x16 accq[SH::QPW];
+    STAMP(kRegion, 3);
+    // layer 2 over this wave's K quarter: 32 MFMA pairs, B operand = relu of the layer-1 registers, A operand = the W2 rows those
+    // registers stand for
+    f32x16 acc;
 #pragma unroll
-    for (int qq = 0; qq < SH::QPW; ++qq) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    {
+        const float *pa_ = Wc + (64 * wave + 4 * lh) * WST + li;
+        float av[32];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accq[qq][r] = 0.0f;
-        // 32 MFMA pairs over one K quarter, operand fetch software-pipelined one group (8 pairs) ahead
-        const float *pa = Wc + (SH::KPW * kh + FWD_KQ * qq) * 32 + li, *pb = Hw + FWD_KQ * qq * 32 + li;
-        float ac[8], bc[8], an[8], bn[8];
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 32]; bc[u] = pb[(2 * u + lh) * 32]; }
+            for (int r = 0; r < 16; ++r) av[q * 16 + r] = pa_[(32 * q + (r & 3) + 8 * (r >> 2)) * WST];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) {
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int kk = 2 * ((g + 1) * 8 + u) + lh;
-                    an[u] = pa[kk * 32]; bn[u] = pb[kk * 32];
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q * 16 + r], fmaxf(t[q][r], 0.0f), acc, 0, 0, 0);
+    }
+    STAMP(kRegion, 4);
+    // hand the partial tile over: xch[quarter = wave][row][lane]
 #pragma unroll
-            for (int u = 0; u < 8; ++u) accq[qq] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], accq[qq], 0, 0, 0);
+    for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    STAMP(kRegion, 5);
+    // this wave finishes rows 4 wave .. 4 wave + 3 of the tile, i.e. hidden units n0 + r + 8 wave + 4 lh, column mbase + li
+    {
+        float xv[4][4], eb[4], e0[4], e1[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[q][r] = xch[(q * 16 + 4 * wave + r) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nl = r + 8 * wave + 4 * lh;
+            eb[r] = ep[nl * 3]; e0[r] = ep[nl * 3 + 1]; e1[r] = ep[nl * 3 + 2];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = mbase + li;
+        float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nl = r + 8 * wave + 4 * lh, n = n0 + nl;
+            const float sum = ((xv[0][r] + xv[1][r]) + xv[2][r]) + xv[3][r];
+            const float h = n < H2N ? fmaxf(sum + eb[r], 0.0f) : 0.0f;
+            if (J.H2 && n < H2N) J.H2[n * BP + m] = h;
+            p0 = fmaf(h, e0[r], p0);
+            p1 = fmaf(h, e1[r], p1);
+            if (QG) Mt[nl * 32 + li] = h > 0.0f ? e0[r] * d3q : 0.0f;           // rows >= 500: h == 0
+        }
+        p0 += __shfl_xor(p0, 32, 64);
+        p1 += __shfl_xor(p1, 32, 64);
+        if (lh == 0) { pp[(wave * 2 + 0) * 32 + li] = p0; pp[(wave * 2 + 1) * 32 + li] = p1; }
     }
-    STAMP(3);
-    // add the four K quarters in the fixed order ((q0 + q1) + q2) + q3: the waves of the later K parts hand their accumulators to the
-    // first one of their column tile through LDS (Hc is free once everybody is here)
     __syncthreads();
-    float *xch = Hc + mt * (3 * 16 * 64);                     // [quarter 1..3][16][64] of this column tile
-    if (kh != 0) {
-#pragma unroll
-        for (int qq = 0; qq < SH::QPW; ++qq)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[((SH::QPW * kh + qq - 1) * 16 + r) * 64 + lane] = accq[qq][r];
+    STAMP(kRegion, 6);
+    if (tid < 64) {                                            // layer-3 partial of the tile: the four row groups in a fixed order
+        const int o = tid >> 5, c = tid & 31;
+        const float s = ((pp[(0 * 2 + o) * 32 + c] + pp[(1 * 2 + o) * 32 + c]) + pp[(2 * 2 + o) * 32 + c]) + pp[(3 * 2 + o) * 32 + c];
+        J.P3[(ntile * 2 + o) * BP + mbase + c] = s;
     }
+    if (!QG) return;
+    STAMP(kRegion, 7);
+    // backward through this n-tile: wave w -> rows k of its quarter (two tiles of 32), K = the tile's 32 hidden units.  The action
+    // gradient of the quarters is added in the fixed order ((q0 + q1) + q2) + q3 by the threads that store it.
+    {
+        float bq[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bq[u] = Mt[(2 * u + lh) * 32 + li];
+        float da0 = 0.0f, da1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kb = 64 * wave + 32 * q;
+            float aq[16], wa0[16], wa1[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) aq[u] = Wc[(kb + li) * WST + 2 * u + lh];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                wa0[r] = w1[9 * W1C + k]; wa1[r] = w1[10 * W1C + k];               // W1[9 + o][k]: the action rows (columns >= 250 zero)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) g = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u], bq[u], g, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = t[q][r] > 0.0f ? g[r] : 0.0f;                       // layer-1 relu mask (pre-activations still in registers)
+                da0 = fmaf(wa0[r], v, da0);
+                da1 = fmaf(wa1[r], v, da1);
+            }
+        }
+        da0 += __shfl_xor(da0, 32, 64);
+        da1 += __shfl_xor(da1, 32, 64);
+        if (lh == 0) { red[(wave * 2 + 0) * 32 + li] = da0; red[(wave * 2 + 1) * 32 + li] = da1; }
+    }
+    STAMP(kRegion, 8);
     __syncthreads();
-    if (kh != 0) return;
-    f32x16 acc = accq[0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += (q < SH::QPW) ? accq[q < SH::QPW ? q : 0][r] : xch[((q - 1) * 16 + r) * 64 + lane];
+    if (tid < 64) {                                            // (o, column) of this workgroup
+        const int o = tid >> 5, c = tid & 31;
+        const float s = ((red[(0 * 2 + o) * 32 + c] + red[(1 * 2 + o) * 32 + c]) + red[(2 * 2 + o) * 32 + c]) + red[(3 * 2 + o) * 32 + c];
+        J.DAP[(ntile * 2 + o) * BP + mbase + c] = s;
     }
-    // epilogue: h2 = relu(acc + b2); store; layer-3 partial over this tile's 32 rows
-    const int m = mbase + li;
-    float p0 = 0.0f, p1 = 0.0f;
-    // only this wave is still running: nothing hides an LDS latency, so all 48 epilogue constants are read in one batch (left to
-    // the compiler each row's three reads sit right in front of their use: 16 exposed round trips)
-    float eb[16], e0[16], e1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        eb[r] = ep[nl * 3]; e0[r] = ep[nl * 3 + 1]; e1[r] = ep[nl * 3 + 2];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nl;
-        const float h = n < H2N ? fmaxf(acc[r] + eb[r], 0.0f) : 0.0f;
-        if (J.H2 && n < H2N) J.H2[n * BP + m] = h;
-        p0 = fmaf(h, e0[r], p0);
-        p1 = fmaf(h, e1[r], p1);
-    }
-    p0 += __shfl_xor(p0, 32, 64);
-    p1 += __shfl_xor(p1, 32, 64);
-    if (lh == 0) {
-        J.P3[(((int)blockIdx.x / kMTiles) * 2 + 0) * BP + m] = p0;
-        J.P3[(((int)blockIdx.x / kMTiles) * 2 + 1) * BP + m] = p1;
-    }
-    STAMP(12);
+    STAMP(kRegion, 9);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    FwdJob J = A.job[blockIdx.y];
-    if (A.gstride) gshift(J, blockIdx.z * A.gstride);
-    if (A.prep) {                                  // one job, an actor network
+    FwdJob J = blockIdx.y == 0 ? A.job[0] : blockIdx.y == 1 ? A.job[1] : A.job[2];      // (no dynamic indexing of the kernarg block: that goes through scratch)
+    gshift(J, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
+    if (A.prep == 1) {                             // K1: three jobs, each workgroup gathers its own input block
         PrepArgs pa = A.pa;
-        if (A.gstride) { gshift(pa.d, blockIdx.z * A.gstride); gshift(pa.ring, blockIdx.z * A.gstride); pa.seed += blockIdx.z; }   // learner blockIdx.z
-        if (A.mt == 64) fwd_body<SIN, true, 64>(J, smem, &pa); else fwd_body<SIN, true, 32>(J, smem, &pa);
+        gshift(pa.d, blockIdx.z * A.gstride); gshift(pa.ring, blockIdx.z * A.gstride); pa.seed += blockIdx.z;
+        if (J.in == SIN) fwd_body<SIN, 1, false>(J, smem, &pa); else fwd_body<CIN, 1, false>(J, smem, &pa);
         return;
     }
-    if (A.mt == 64) {
-        if (J.in == SIN) fwd_body<SIN, false, 64>(J, smem, nullptr); else fwd_body<CIN, false, 64>(J, smem, nullptr);
-    } else {
-        if (J.in == SIN) fwd_body<SIN, false, 32>(J, smem, nullptr); else fwd_body<CIN, false, 32>(J, smem, nullptr);
-    }
+    fwd_body<CIN, 2, true>(J, smem, nullptr);      // K4: the updated critic on [s; actor(s)], forward + input gradient
 }
 
-// ---- critic loss head, evaluated in the prologue of every bwd(critic) workgroup (cheaper than a launch boundary) --------
-// d3[0][m] = dq[m] = 2 (q - y) / B into LDS; workgroup 0 also publishes y, q, the loss and gb3.
-// The global operands of the two heads, fetched with the rest of a backward workgroup's first batch of loads (all threads load;
-// the critic head uses the values of threads < BP only).
-struct HeadRegs { float v[KT * NQ]; float a, b, c, e; };
-static_assert(KT * NQ >= 2 * NT, "HeadRegs.v holds the 2 x NT layer-3 partials of the critic head");
-__device__ __forceinline__ void head_loss_load(const shems_ddpg &d, HeadRegs &R)
-{
-    const float *ws = d.ws;
-    const int m = threadIdx.x & 127;
-    const float *Pt = slot(d.ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(d.ws, SLOT_CRITIC) + SL_P3;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) { R.v[i] = Pt[(i * 2) * BP + m]; R.v[NT + i] = Pc[(i * 2) * BP + m]; }
-    R.a = d.critic_t[off_b3(CIN, 1)];
-    R.b = d.critic[off_b3(CIN, 1)];
-    R.c = ws[WS_R + m];
-    R.e = ws[WS_DONE + m];
-}
-__device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R)
-{
-    const float *ws = d.ws;
-    const int t = threadIdx.x, o = t >> 7, m = t & 127;
-#pragma unroll
-    for (int p = 0; p < KT * NQ; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
-    R.a = ws[WS_API + t];
-}
-
-__device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
-{
-    float *ws = d.ws;
-    const int t = threadIdx.x, m = t & 127;
-    float dq = 0.0f, diff = 0.0f;
-    if (t < BP) {
-        float q2 = R.a, q = R.b;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) { q2 += R.v[i]; q += R.v[NT + i]; }
-        const float y = R.c + d.gamma * (1.0f - R.e) * q2;                                  // DDPG.jl:133
-        diff = m < d.batch ? q - y : 0.0f;
-        dq = 2.0f * diff / (float)d.batch;                                                  // d mse / d q
-        if (publisher) { ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq; }
-    }
-    d3[t] = t < BP ? dq : 0.0f;
-    if (publisher) {
-        const float s1 = wave_sum(diff * diff), s2 = wave_sum(dq);
-        if ((t & 63) == 0) { red[t >> 6] = s1; red[4 + (t >> 6)] = s2; }
-        __syncthreads();
-        if (t == 0) {
-            d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
-            d.grad_critic[off_b3(CIN, 1)] = red[4] + red[5];
-        }
-    }
-}
-
-// ---- actor head backward, evaluated in the prologue of every bwd(actor) workgroup ------------------------------------
-// d3[o][m] = (sum of the 32 partial d loss / d a_pi) * (1 - a_pi^2); workgroup 0 publishes d3, the actor loss and gb3.
-__device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher)
-{
-    float *ws = d.ws;
-    const int t = threadIdx.x, o = t >> 7, m = t & 127;
-    const float a = R.a;
-    float da = 0.0f;
-#pragma unroll
-    for (int p = 0; p < KT * NQ; ++p) da += R.v[p];
-    const float g = da * (1.0f - a * a);                       // through tanh
-    d3[t] = g;
-    if (publisher) {
-        ws[WS_D3A + t] = g;
-        float q = 0.0f;
-        if (o == 0 && m < d.batch) {
-            const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
-            q = d.critic[off_b3(CIN, 1)];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) q += Pq[(i * 2) * BP + m];
-        }
-        const float sg = wave_sum(g), sq = wave_sum(q);
-        if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
-        __syncthreads();
-        if (t == 0) {
-            d.grad_actor[off_b3(SIN, 2) + 0] = red[0] + red[1];
-            d.grad_actor[off_b3(SIN, 2) + 1] = red[2] + red[3];
-            d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
-        }
-    }
-}
-
-// ---- kernel D: layer-2 backward ---------------------------------------------------------------------------
-// D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (h2[n][m] > 0) is generated while staging, never stored.
-//   W workgroups (kt, nq): gW2[32 k][128 n] = sum_m h1[k][m] D2[n][m]; kt == 0 also emits gb2 and gW3.
-//   I workgroups (kt, nq): D1part[nq][32 k][128 m] = sum_{n in quarter} W2[k][n] D2[n][m]; for the critic inside the
-//                          actor loss they also emit the partial action gradient (through the layer-1 relu mask).
-struct BwdArgs {
-    const float *w1t;      // packed layer-1 image of that network
-    const float *P;        // parameter block of the network being differentiated
-    int in, out;
-    XSrc x;                // its input (for the layer-1 recompute)
+// ---- K2: critic_target forward | the three E products ---------------------------------------------------------------------
+// E workgroup (kt, nq) of set j: Epart[nq][32 k][128 m] = sum_{n in block nq} W2[k][n] * (W3[n][j] * (h2[n][m] > 0)).
+struct EJob {
+    const float *P;        // parameter block of the network
+    int in, out, col;      // col = j
     const float *H2;       // [500][BP]
-    const float *d3;       // [out][BP] error at the layer-3 pre-activation
-    float *grad;           // gradient block (W part) or null
-    float *D1P;            // [NQ][250][BP]
-    float *DAP;            // [KT][NQ][2][BP] or null
-    int n_w;               // number of W workgroups (32 or 0); when > 0, 8 more "G" workgroups emit gb2 and gW3
-    int head;              // how d3 is obtained: 0 = read A.d3, 1 = critic loss head, 2 = actor head
-    shems_ddpg dd;         // for the heads
-    int64_t gstride;       // learner groups: byte stride between learners (0 = single learner)
+    float *EP;             // [NQ][250][BP]
 };
-__device__ __forceinline__ void gshift(BwdArgs &B, int64_t off)
-{
-    B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.d3 = gsh(B.d3, off);
-    B.grad = gsh(B.grad, off); B.D1P = gsh(B.D1P, off); B.DAP = gsh(B.DAP, off); gshift(B.dd, off);
-}
-enum { BWD_NG = 16, BWD_GROWS = 512 / BWD_NG, BWD_GU = BWD_GROWS / 4 };   // G workgroups: 32 rows of gb2 / gW3 each, 8 per wave (32 x 16 measured equal)
+struct MidArgs { FwdJob fwd; EJob e[3]; int64_t gstride; int nfwd; };
+constexpr int E_LDS = (NQW * BP + 32 * (NQW + 1) + NQW) * 4;
 
-constexpr int BWD_BT = BP * (NQW + 1);                       // W: [128 m][65] D2^T panel (>= I: [64 n][128 m] D2 panel)
-constexpr int BWD_AT = BP * 33;                              // W: [128 m][33] h1^T panel (>= I: [32 k][65] W2 panel)
-constexpr int BWD_LDS = (BWD_BT + BWD_AT + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8) * 4;
-
-// D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
-__device__ __forceinline__ float d2_val(float h2, int out, float w3a, float w3b, float d3a, float d3b)
+__device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 {
-    const float g = out == 2 ? fmaf(w3b, d3b, w3a * d3a) : w3a * d3a;
-    return h2 > 0.0f ? g : 0.0f;
-}
-
-template <int IN>
-__device__ __forceinline__ void bwd_body(const BwdArgs &A, float *smem)
-{
-#ifdef ABL_STAMP
-    unsigned long long *bst = reinterpret_cast<unsigned long long *>(A.D1P + NQ * H1N * BP - 4096) + (((int)blockIdx.x == 0) ? 0 : 32);
-    const bool bst_on = threadIdx.x == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == A.n_w + (A.n_w > 0 ? (int)BWD_NG : 0));
-#define BSTAMP(i) do { if (bst_on) { bst[2*(i)] = __builtin_amdgcn_s_memtime(); bst[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define BSTAMP(i)
-#endif
-    BSTAMP(0);
-    float *Bt = smem;                          // W: [128 m][65] D2^T panel;  I: [64 n][128 m] D2 panel
-    float *At = Bt + BWD_BT;                   // W: [128 m][33] h1^T panel; I: [32 k][65] W2 panel
-    float *xs = At + BWD_AT;                   // [12][BP]
-    float *w1 = xs + W1K * BP;                 // w1m [12][256]
-    float *d3 = w1 + W1K * W1C;                // [2][BP]
-    float *w3s = d3 + AIN * BP;                // W3 [512][2] (out == 1: [.][0] only), zero beyond row 499
-    float *red = w3s + 2 * 512;                // [8]
+    float *Bt = smem;                          // [64 n][128 m]  M panel
+    float *At = Bt + NQW * BP;                 // [32 k][65]     W2 panel
+    float *w3s = At + 32 * (NQW + 1);          // [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const float *__restrict__ P = A.P;
-    const float *__restrict__ W3 = P + off_w3(IN);
-    const int n_g = A.n_w > 0 ? (int)BWD_NG : 0;
-    const bool is_w = (int)blockIdx.x < A.n_w, is_g = !is_w && (int)blockIdx.x < A.n_w + n_g;
-    const int b = is_w ? blockIdx.x : blockIdx.x - A.n_w - n_g;
-    const int kt = b >> 3, nq = b & 7;                           // (k-tile of 32, n-block of 64)
+    const int kt = b >> 3, nq = b & 7, nb = nq * NQW;
     const int mcol = tid & 127, half = tid >> 7;
-
-    // The H2 panel (and, for the input-gradient tiles, the W2 panel) does not depend on the error signal: its loads go out before
-    // the head is evaluated, so the two global latencies overlap instead of following each other.
-    float hv[32], wvp[8];
-    const float *__restrict__ W2p = P + off_w2(IN);
-    if (!is_g) {                                  // W and I tiles of a block read the same 64 rows of H2
+    const float *__restrict__ P = E.P;
+    const float *__restrict__ W2p = P + off_w2(E.in);
+    STAMP(1, 0);
+    float hv[32], wvp[8], w3v = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) hv[u] = A.H2[min(nq * NQW + 2 * u + half, H2N - 1) * BP + mcol];
-        if (!is_w) {
+    for (int u = 0; u < 32; ++u) hv[u] = E.H2[min(nb + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = u * 256 + tid, kl = e >> 6, nl = e & 63, k = kt * 32 + kl, n = nq * NQW + nl;
-                const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + min(n, H2N - 1)];
-                wvp[u] = (k < H1N && n < H2N) ? t : 0.0f;
-            }
-        }
+    for (int u = 0; u < 8; ++u) {
+        const int e = u * 256 + tid, kl = e >> 6, nl = e & 63, k = kt * 32 + kl, n = nb + nl;
+        const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + min(n, H2N - 1)];
+        wvp[u] = (k < H1N && n < H2N) ? t : 0.0f;
     }
-    XRegs<IN> xr;
-    W1mRegs wr;
-    float w3v[4];
-    build_x_load<IN>(A.x, xr);
-    stage_w1m_load(A.w1t, wr);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = it * 256 + tid, n = e >> 1, o = e & 1;
-        w3v[it] = W3[min(n, H2N - 1) * A.out + min(o, A.out - 1)];
+    if (tid < NQW) {
+        w3v = P[off_w3(E.in) + min(nb + tid, H2N - 1) * E.out + E.col];
+        if (nb + tid >= H2N) w3v = 0.0f;
+        w3s[tid] = w3v;
     }
-    HeadRegs hr;
-    float d3v = 0.0f;
-    if (A.head == 1) head_loss_load(A.dd, hr);
-    else if (A.head == 2) head_actor_load(A.dd, hr);
-    else d3v = A.d3[min(tid, A.out * BP - 1)];
-    build_x_store<IN>(A.x, xr, xs, false);
-    stage_w1m_store(wr, w1);
-    if (A.head == 1) head_loss(A.dd, hr, d3, red, blockIdx.x == 0);
-    else if (A.head == 2) head_actor(A.dd, hr, d3, red, blockIdx.x == 0);
-    else d3[tid] = tid < A.out * BP ? d3v : 0.0f;                                           // AIN * BP == 256 == blockDim
-    {   // W3 -> LDS as [n][2] (second column 0 for the critic), from the loads issued above
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = it * 256 + tid, n = e >> 1, o = e & 1;
-            w3s[e] = (n < H2N && o < A.out) ? w3v[it] : 0.0f;
-        }
-    }
+    STAMP(1, 1);
     __syncthreads();
-    BSTAMP(1);
-    const float d3a = d3[mcol], d3b = d3[BP + mcol];
-
+    STAMP(1, 2);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int nl = 2 * u + half;
+        Bt[nl * BP + mcol] = hv[u] > 0.0f ? w3s[nl] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = u * 256 + tid, kl = e >> 6, nl = e & 63;
+        At[kl * (NQW + 1) + nl] = wvp[u];
+    }
+    STAMP(1, 3);
+    __syncthreads();
+    STAMP(1, 4);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-    if (is_w) {
-        const int nbase = nq * NQW;
-        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
-        // issued first so that it runs under the VALU work of the D2 panel below.
-        const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
-        // D2^T panel Bt[m][nl] (row stride 65), nl = 2*u + half: 32 rows per thread from the loads issued above (W3 comes from LDS;
-        // rows >= 500 meet the zero rows of its image)
-        {
+    const float *pa = At + li * (NQW + 1), *pb = Bt + wave * 32 + li;
+    {   // 32 MFMA pairs (4 groups of 8), operand fetch one group ahead
+        float ac[8], bc[8], an[8], bn[8];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int nl = 2 * u + half, n = nbase + nl;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
-                Bt[mcol * (NQW + 1) + nl] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
-            }
-        }
+        for (int u = 0; u < 8; ++u) { ac[u] = pa[2 * u + lh]; bc[u] = pb[(2 * u + lh) * BP]; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
-        __syncthreads();
-        BSTAMP(2);
-        // wave (nt, mh): the 32 x 32 tile of columns [32 nt, +32) over the batch half [64 mh, +64): 32 MFMA pairs, operand fetch
-        // one group (8 pairs) ahead; the two halves are added through LDS
-        const int nt = wave & 1, mh = wave >> 1;
-        const float *pa = At + (64 * mh) * 33 + li, *pb = Bt + (64 * mh) * (NQW + 1) + nt * 32 + li;
-        {
-            float ac[8], bc[8], an[8], bn[8];
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * (NQW + 1)]; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int mm = 2 * ((g + 1) * 8 + u) + lh;
-                        an[u] = pa[mm * 33]; bn[u] = pb[mm * (NQW + 1)];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
-            }
-        }
-        BSTAMP(3);
-        __syncthreads();                            // everybody is done with the panels: Bt doubles as the exchange buffer
-        float *xch = Bt + nt * (16 * 64);
-        if (mh == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        if (mh == 0) {
-            float *gW2 = A.grad + off_w2(IN);
-            const int n = nbase + nt * 32 + li;
-            float xv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xv[r] = xch[r * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (k < H1N && n < H2N) gW2[k * H2N + n] = acc[r] + xv[r];
-            }
-        }
-    } else if (is_g) {
-        // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: BWD_NG workgroups x BWD_GROWS rows, one wave per row, all of a
-        // wave's rows in flight
-        const int g = blockIdx.x - A.n_w;
-        const float e0a = d3[lane], e0b = d3[64 + lane], e1a = d3[BP + lane], e1b = d3[BP + 64 + lane];
-        {
-            float h0[BWD_GU], h1[BWD_GU];
-#pragma unroll
-            for (int u = 0; u < BWD_GU; ++u) {
-                const int nc = min(g * BWD_GROWS + wave + 4 * u, H2N - 1);
-                h0[u] = A.H2[nc * BP + lane];
-                h1[u] = A.H2[nc * BP + 64 + lane];
-            }
-#pragma unroll
-            for (int u = 0; u < BWD_GU; ++u) {
-                const int nn = g * BWD_GROWS + wave + 4 * u;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * min(nn, H2N - 1));
-                const float s0 = wave_sum(h0[u] * e0a + h1[u] * e0b);
-                const float s1 = wave_sum(h0[u] * e1a + h1[u] * e1b);
-                const float sb = wave_sum(d2_val(h0[u], 2, w.x, w.y, e0a, e1a) + d2_val(h1[u], 2, w.x, w.y, e0b, e1b));
-                if (lane == 0 && nn < H2N) {
-                    A.grad[off_w3(IN) + nn * A.out] = s0;
-                    if (A.out == 2) A.grad[off_w3(IN) + nn * 2 + 1] = s1;
-                    A.grad[off_b2(IN) + nn] = sb;
+                for (int u = 0; u < 8; ++u) {
+                    const int nn = 2 * ((g + 1) * 8 + u) + lh;
+                    an[u] = pa[nn]; bn[u] = pb[nn * BP];
                 }
             }
-        }
-    } else {
-        const int nb = nq * NQW;
-        // D2 panel Bt[nl][m], nl = 2*u + half < 64 (rows >= 500: zero through the W3 image)
-        {
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int nl = 2 * u + half;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * (nb + nl));
-                Bt[nl * BP + mcol] = d2_val(hv[u], 2, w.x, w.y, d3a, d3b);
-            }
-        }
-        // W2 panel At[kl][nl] (row stride 65): 32 x 64 elements from the loads issued above
-        {
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = u * 256 + tid, kl = e >> 6, nl = e & 63;
-                At[kl * (NQW + 1) + nl] = wvp[u];
-            }
-        }
-        __syncthreads();
-        BSTAMP(2);
-        const float *pa = At + li * (NQW + 1), *pb = Bt + wave * 32 + li;
-        {   // 32 MFMA pairs (4 groups of 8), operand fetch one group ahead
-            float ac[8], bc[8], an[8], bn[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { ac[u] = pa[2 * u + lh]; bc[u] = pb[(2 * u + lh) * BP]; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int nn = 2 * ((g + 1) * 8 + u) + lh;
-                        an[u] = pa[nn]; bn[u] = pb[nn * BP];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
-            }
-        }
-        BSTAMP(3);
-        const int m = wave * 32 + li;
-        float *D1 = A.D1P + (int64_t)nq * H1N * BP;
-        float da0 = 0.0f, da1 = 0.0f;
-        f32x16 pre;                             // layer-1 pre-activations of this (k-tile, m-tile): the relu mask, in acc's layout
-        float wa0[16], wa1[16];                 // W1[9 + o][k]: the action rows of the critic's first layer, read in one batch
-        if (A.DAP && IN == CIN) {
-            pre = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = min(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, W1C - 1);
-                wa0[r] = w1[9 * W1C + k]; wa1[r] = w1[10 * W1C + k];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (k < H1N) {
-                D1[k * BP + m] = acc[r];
-                if (A.DAP && IN == CIN) {
-                    const float v = pre[r] > 0.0f ? acc[r] : 0.0f;
-                    da0 = fmaf(wa0[r], v, da0);
-                    da1 = fmaf(wa1[r], v, da1);
-                }
-            }
-        }
-        if (A.DAP && IN == CIN) {
-            da0 += __shfl_xor(da0, 32, 64);
-            da1 += __shfl_xor(da1, 32, 64);
-            if (lh == 0) {
-                float *o = A.DAP + (int64_t)((kt * NQ + nq) * 2) * BP;
-                o[m] = da0; o[BP + m] = da1;
-            }
+            for (int u = 0; u < 8; ++u) { ac[u] = an[u]; bc[u] = bn[u]; }
         }
     }
-    BSTAMP(4);
+    STAMP(1, 5);
+    const int m = wave * 32 + li;
+    float *D = E.EP + (int64_t)nq * H1N * BP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (k < H1N) D[k * BP + m] = acc[r];
+    }
+    STAMP(1, 6);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_bwd(BwdArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_mid(MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (A.gstride) {
-        BwdArgs B = A;
-        gshift(B, blockIdx.z * A.gstride);
-        if (B.in == SIN) bwd_body<SIN>(B, smem); else bwd_body<CIN>(B, smem);
+    const int64_t off = blockIdx.z * A.gstride;
+    if ((int)blockIdx.x < A.nfwd) {
+        FwdJob J = A.fwd;
+        gshift(J, off);
+        fwd_body<CIN, 0, false>(J, smem, nullptr);
         return;
     }
-    if (A.in == SIN) bwd_body<SIN>(A, smem); else bwd_body<CIN>(A, smem);
+    const int e = (int)blockIdx.x - A.nfwd;
+    const int set = e / (KT * NQ);
+    EJob E = set == 0 ? A.e[0] : set == 1 ? A.e[1] : A.e[2];
+    E.P = gsh(E.P, off); E.H2 = gsh(E.H2, off); E.EP = gsh(E.EP, off);
+    e_body(E, e % (KT * NQ), smem);
 }
 
-// ---- kernel E: layer-1 gradients, one wave per hidden unit k --------------------------------------------------
-//   D1[k][m] = (h1[k][m] > 0) * sum_q D1part[q][k][m];  gb1[k] = sum_m D1;  gW1[j][k] = sum_m x[j][m] D1[k][m]
-// One wave, xs = the network input [12][BP] in LDS.  gout[j] = gW1[j][k] (j < IN), gout[IN] = gb1[k], valid in every lane.
-// Everything a row needs comes straight from global memory in ONE batch of loads per lane -- its W1 column and b1, the NQ partial
-// slabs and the two input columns (lane, lane + 64) of the network input, which for both differentiated networks is plain
-// workspace data (normalised states, stored actions) -- so there is no LDS block, no barrier and one exposed latency.
-template <int IN> struct L1Row { float w[IN]; float b; float part[2][NQ]; float x[2][IN]; };
-template <int IN>
-__device__ __forceinline__ void l1row_load(const float *__restrict__ P, const XSrc &xsrc, const float *__restrict__ D1P, int k, int lane,
-                                           L1Row<IN> &R)
-{
-#pragma unroll
-    for (int j = 0; j < IN; ++j) R.w[j] = P[j * H1N + k];
-    R.b = P[off_b1(IN) + k];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m = lane + 64 * h;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) R.part[h][q] = D1P[((int64_t)q * H1N + k) * BP + m];
-#pragma unroll
-        for (int j = 0; j < IN; ++j) R.x[h][j] = j < SIN ? xsrc.X[j * BP + m] : xsrc.A[(j - SIN) * BP + m];
-    }
-}
-template <int IN>
-__device__ __forceinline__ void l1bwd_wave(const L1Row<IN> &R, float (&gout)[IN + 1])
-{
-    float dv[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float pre = R.b;
-#pragma unroll
-        for (int j = 0; j < IN; ++j) pre = fmaf(R.w[j], R.x[h][j], pre);
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) s += R.part[h][q];
-        dv[h] = pre > 0.0f ? s : 0.0f;
-    }
-    gout[IN] = __shfl(wave_sum(dv[0] + dv[1]), 0, 64);
-#pragma unroll
-    for (int j = 0; j < IN; ++j) gout[j] = __shfl(wave_sum(R.x[0][j] * dv[0] + R.x[1][j] * dv[1]), 0, 64);
-}
-
-template <int IN>
-__device__ __forceinline__ void l1bwd_body(const float *__restrict__ P, const XSrc &x, const float *__restrict__ D1P,
-                                           float *__restrict__ grad)
-{
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= H1N) return;
-    L1Row<IN> R;
-    l1row_load<IN>(P, x, D1P, k, lane, R);
-    float gout[IN + 1];
-    l1bwd_wave<IN>(R, gout);
-    if (lane == 0) {
-        grad[off_b1(IN) + k] = gout[IN];
-#pragma unroll
-        for (int j = 0; j < IN; ++j) grad[j * H1N + k] = gout[j];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_l1bwd(const float *P, int in, XSrc x, const float *D1P, float *grad, int64_t gstride)
-{
-    if (gstride) { const int64_t off = blockIdx.z * gstride; P = gsh(P, off); gshift(x, off); D1P = gsh(D1P, off); grad = gsh(grad, off); }
-    if (in == SIN) l1bwd_body<SIN>(P, x, D1P, grad); else l1bwd_body<CIN>(P, x, D1P, grad);
-}
-
-// ---- kernel G: Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------
+// ---- Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------------------------
 //   mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2 ; delta = mt/(1-bp1) / (sqrt(vt/(1-bp2)) + eps) * eta ; p -= delta
-//   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32)
+//   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32; g^2 is the Float32 square)
 //   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
-// Single-replica form (shems_ddpg.fuse_l1): no gradient exchange sits between backward and ADAM, so the layer-1 gradient rows are
-// produced HERE instead of by a k_l1bwd launch of their own: workgroup b < 63 computes the rows of hidden units 4b..4b+3 (one wave
-// each, same arithmetic as k_l1bwd), stores them to the gradient block and applies ADAM to exactly those (in + 1) * 4 elements; the
-// other workgroups sweep the elements from b1's end onwards.  No element is read by one workgroup and written by another.
 struct AdamCtx {
-    float *p; const float *g; float *mt, *vt, *target; float *w1t_g; float *publish;
-    int n, in; double eta, bp1, bp2, gscale; float tau;
+    float *p; const float *g; float *mt, *vt, *target; float *publish;
+    int n, in; double eta, bp1, bp2, gscale;
+    double k1, ic2;        // eta / (1 - bp1), 1 / (1 - bp2): host-side Float64 quotients
+    float tau;
 };
-struct L1Src { const float *P; XSrc x; const float *D1P; float *grad; int on; };
+__device__ __forceinline__ void gshift(AdamCtx &c, int64_t off)
+{
+    c.p = gsh(c.p, off); c.g = gsh(c.g, off); c.mt = gsh(c.mt, off); c.vt = gsh(c.vt, off); c.target = gsh(c.target, off);
+    c.publish = gsh(c.publish, off);
+}
 
 // One element of ADAM + soft update on values: (m, v, p, target) in, updated in place.
 __device__ __forceinline__ void adam_math(const AdamCtx &c, float graw, float &m, float &v, float &p, float &t)
 {
     // Julia evaluates the broadcast expressions without fusing multiplies into adds; keeping the compiler from contracting also
-    // makes the inlined copies of this function (layer-1 rows / sweep) round identically.
+    // makes the inlined copies of this function (gradient tiles / sweep) round identically.
 #pragma clang fp contract(off)
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
     const float gf = (float)((double)graw * c.gscale);          // averaged gradient, as every replica holds it
     const float m1 = (float)(b1 * (double)m + (1.0 - b1) * (double)gf);
     const float g2 = gf * gf;                                    // Flux 0.12.1 `Δ^2` on a Float32 array: literal_pow = Δ*Δ in Float32, then promoted
     const float v1 = (float)(b2 * (double)v + (1.0 - b2) * (double)g2);
-    const float delta = (float)((double)m1 / (1.0 - c.bp1) / (sqrt((double)v1 / (1.0 - c.bp2)) + eps) * c.eta);
+    // delta = Float32(mt / (1 - bp1) / (sqrt(vt / (1 - bp2)) + eps) * eta), every operation in Float64 (Flux's scalars are Float64).
+    // Evaluated as (mt * k1) / s with s = sqrt(vt * ic2) + eps, k1 = eta / (1 - bp1), ic2 = 1 / (1 - bp2), the quotient by a
+    // reciprocal refined to <= 1 ulp (two Newton steps + a residual correction): three Float64 divisions become none.  The Float64
+    // value differs from the reference's left-to-right evaluation by a few ulp(Float64) at most, i.e. the Float32 it rounds to
+    // differs only when it falls within ~1e-15 of a Float32 rounding boundary (about one element in 1e7, by one Float32 ulp of delta).
+    const double sq = sqrt((double)v1 * c.ic2) + eps;
+    double y = __builtin_amdgcn_rcp(sq);
+    y = __builtin_fma(__builtin_fma(-sq, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-sq, y, 1.0), y, y);
+    const double tnum = (double)m1 * c.k1;
+    double qd = tnum * y;
+    qd = __builtin_fma(__builtin_fma(-sq, qd, tnum), y, qd);
+    const float delta = (float)qd;
     const float pn = p - delta;
     const float one_m_tau = 1.0f - c.tau;
     t = one_m_tau * t + c.tau * pn;
     m = m1; v = v1; p = pn;
-}
-__device__ __forceinline__ void adam_image(const AdamCtx &c, int i, float pn)
-{
-    if (c.w1t_g && i < c.in * H1N + H1N) {   // keep the packed layer-1 image of the updated network current
-        const int j = i / H1N, k = i - j * H1N;
-        c.w1t_g[(j < c.in ? j : W1K - 1) * W1C + k] = pn;
-    }
 }
 __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
 {
@@ -996,7 +761,27 @@ __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
     adam_math(c, graw, m, v, p, t);
     c.mt[i] = m; c.vt[i] = v; c.p[i] = p; c.target[i] = t;
     if (c.publish) c.publish[i] = p;
-    adam_image(c, i, p);
+}
+// N independent elements of one lane: all loads first (one exposed latency), then the arithmetic, then the stores.  idx < 0: skip.
+template <int N>
+__device__ __forceinline__ void adam_batch(const AdamCtx &c, const int (&idx)[N], const float (&g)[N])
+{
+    float m[N], v[N], p[N], t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int e = max(idx[i], 0);
+        m[i] = c.mt[e]; v[i] = c.vt[e]; p[i] = c.p[e]; t[i] = c.target[e];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) adam_math(c, g[i], m[i], v[i], p[i], t[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (idx[i] >= 0) {
+            const int e = idx[i];
+            c.mt[e] = m[i]; c.vt[e] = v[i]; c.p[e] = p[i]; c.target[e] = t[i];
+            if (c.publish) c.publish[e] = p[i];
+        }
+    }
 }
 // Four consecutive elements per thread (16-byte accesses: a quarter of the workgroups, the same bits).  i0 is a multiple of 4.
 __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
@@ -1012,51 +797,390 @@ __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
         *reinterpret_cast<float4 *>(c.mt + i0) = m4; *reinterpret_cast<float4 *>(c.vt + i0) = v4;
         *reinterpret_cast<float4 *>(c.p + i0) = p4; *reinterpret_cast<float4 *>(c.target + i0) = t4;
         if (c.publish) *reinterpret_cast<float4 *>(c.publish + i0) = p4;
-        if (c.w1t_g && i0 < c.in * H1N + H1N) { adam_image(c, i0, p4.x); adam_image(c, i0 + 1, p4.y); adam_image(c, i0 + 2, p4.z); adam_image(c, i0 + 3, p4.w); }
     } else {
         for (int i = i0; i < c.n; ++i) adam_elem(c, i, c.g[i]);
     }
 }
 
-template <int IN>
-__device__ __forceinline__ void adam_l1_rows(const AdamCtx &c, const L1Src &l1)
+// Data-parallel form only (a gradient all-reduce sits between the gradient launch and this sweep).
+__global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
 {
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= H1N) return;
-    L1Row<IN> R;
-    l1row_load<IN>(l1.P, l1.x, l1.D1P, k, lane, R);
-    float gout[IN + 1];
-    l1bwd_wave<IN>(R, gout);
-    float mine = 0.0f;
+    gshift(c, blockIdx.z * gstride);
+    const int i0 = 4 * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
+    if (i0 < c.n) adam_vec4(c, i0);
+}
+
+// ---- critic loss head, evaluated in the prologue of every K3 workgroup (cheaper than a launch boundary) --------
+// d3[0][m] = dq[m] = 2 (q - y) / B into LDS; workgroup 0 also publishes y, q, the loss and gb3 (+ its ADAM step when fused).
+// The global operands of the two heads, fetched with the rest of a workgroup's first batch of loads (all threads load;
+// the critic head uses the values of threads < BP only).  b3 of both critics comes from the copy K1 froze: the owner of that
+// element updates it (and the target's) in place during this launch.
+struct HeadRegs { float v[2 * NT]; float s[4]; };       // s = {a, b, c, e} scalars of the heads
+__device__ __forceinline__ void head_loss_load(const shems_ddpg &d, HeadRegs &R)
+{
+    const float *ws = d.ws;
+    const int m = threadIdx.x & 127;
+    const float *Pt = slot(d.ws, SLOT_CRITIC_T) + SL_P3, *Pc = slot(d.ws, SLOT_CRITIC) + SL_P3;
 #pragma unroll
-    for (int j = 0; j <= IN; ++j) mine = lane == j ? gout[j] : mine;
-    if (lane <= IN) {
-        const int e = lane < IN ? lane * H1N + k : off_b1(IN) + k;
-        l1.grad[e] = mine;                   // the gradient block stays complete for callers that read it after the update
-        adam_elem(c, e, mine);
+    for (int i = 0; i < NT; ++i) { R.v[i] = Pt[(i * 2) * BP + m]; R.v[NT + i] = Pc[(i * 2) * BP + m]; }
+    R.s[0] = ws[WS_FB3 + 1];
+    R.s[1] = ws[WS_FB3 + 0];
+    R.s[2] = ws[WS_R + m];
+    R.s[3] = ws[WS_DONE + m];
+}
+__device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R)
+{
+    const float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
+    R.s[0] = ws[WS_API + t];
+    R.s[1] = R.s[2] = R.s[3] = 0.0f;
+}
+
+__device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher,
+                                          const AdamCtx *fuse)
+{
+    float *ws = d.ws;
+    const int t = threadIdx.x, m = t & 127;
+    float dq = 0.0f, diff = 0.0f;
+    if (t < BP) {
+        float q2 = R.s[0], q = R.s[1];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { q2 += R.v[i]; q += R.v[NT + i]; }
+        const float y = R.s[2] + d.gamma * (1.0f - R.s[3]) * q2;                                  // DDPG.jl:133
+        diff = m < d.batch ? q - y : 0.0f;
+        dq = 2.0f * diff / (float)d.batch;                                                  // d mse / d q
+        if (publisher) { ws[WS_Y + m] = y; ws[WS_Q + m] = q; ws[WS_D3C + m] = dq; }
+    }
+    d3[t] = t < BP ? dq : 0.0f;
+    if (publisher) {
+        const float s1 = wave_sum(diff * diff), s2 = wave_sum(dq);
+        if ((t & 63) == 0) { red[t >> 6] = s1; red[4 + (t >> 6)] = s2; }
+        __syncthreads();
+        if (t == 0) {
+            d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
+            const float g = red[4] + red[5];
+            d.grad_critic[off_b3(CIN, 1)] = g;
+            if (fuse) adam_elem(*fuse, off_b3(CIN, 1), g);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, L1Src l1, int64_t gstride)
+// ---- actor head backward, evaluated in the prologue of every K5 workgroup ------------------------------------
+// d3[o][m] = (sum of the NT partial d loss / d a_pi) * (1 - a_pi^2); workgroup 0 publishes d3, the actor loss and gb3.
+__device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher,
+                                           const AdamCtx *fuse)
 {
-    if (gstride) {
-        const int64_t off = blockIdx.z * gstride;
-        c.p = gsh(c.p, off); c.g = gsh(c.g, off); c.mt = gsh(c.mt, off); c.vt = gsh(c.vt, off); c.target = gsh(c.target, off);
-        c.w1t_g = gsh(c.w1t_g, off);
-        l1.P = gsh(l1.P, off); gshift(l1.x, off); l1.D1P = gsh(l1.D1P, off); l1.grad = gsh(l1.grad, off);
-    }
-    int first = 0, blk = blockIdx.x;
-    if (l1.on) {                                  // the first 63 workgroups ONLY produce + apply the layer-1 rows; the sweep follows them
-        constexpr int kRowWgs = (H1N + 3) / 4;
-        if (blk < kRowWgs) {
-            if (c.in == SIN) adam_l1_rows<SIN>(c, l1); else adam_l1_rows<CIN>(c, l1);
-            return;
+    float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+    const float a = R.s[0];
+    float da = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) da += R.v[p];
+    const float g = da * (1.0f - a * a);                       // through tanh
+    d3[t] = g;
+    if (publisher) {
+        ws[WS_D3A + t] = g;
+        float q = 0.0f;
+        if (o == 0 && m < d.batch) {
+            const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
+            q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) q += Pq[(i * 2) * BP + m];
         }
-        first = (c.in + 1) * H1N;
-        blk -= kRowWgs;
+        const float sg = wave_sum(g), sq = wave_sum(q);
+        if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
+        __syncthreads();
+        if (t == 0) {
+            const float g0 = red[0] + red[1], g1 = red[2] + red[3];
+            d.grad_actor[off_b3(SIN, 2) + 0] = g0;
+            d.grad_actor[off_b3(SIN, 2) + 1] = g1;
+            d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
+            if (fuse) { adam_elem(*fuse, off_b3(SIN, 2), g0); adam_elem(*fuse, off_b3(SIN, 2) + 1, g1); }
+        }
     }
-    const int i0 = first + 4 * (blk * (int)blockDim.x + (int)threadIdx.x);          // first is a multiple of 4, the blocks 16-byte aligned
-    if (i0 < c.n) adam_vec4(c, i0);
+}
+
+// ---- K3 / K5: every gradient block of one network, by batch contractions only -------------------------------------------
+// D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (h2[n][m] > 0) is generated while staging, never stored.
+//   W workgroups (kt, nt): gW2[32 k][32 n] = sum_m h1[k][m] D2[n][m], one batch quarter per wave (16 MFMA pairs), the four
+//                 partial tiles added in the fixed order ((q0 + q1) + q2) + q3, each wave finishing (and owning) four rows;
+//   G workgroups: gb2[n] = sum_m D2[n][m], gW3[n][o] = sum_m h2[n][m] d3[o][m], 32 rows each;
+//   R workgroups: one wave per hidden unit k: D1[k][m] = mask1 * sum_j d3[j][m] * (sum_q Epart_j[q][k][m]); gb1[k] = sum_m D1;
+//                 gW1[j][k] = sum_m x[j][m] D1[k][m].
+// With A.fuse every workgroup then applies ADAM + the soft target update to exactly the elements it produced.
+struct GradArgs {
+    const float *w1t;      // packed layer-1 image of that network (as K1 built it)
+    const float *P;        // parameter block of the network being differentiated (read only by the owner of each element)
+    int in, out;
+    XSrc x;                // its input (workspace data)
+    const float *H2;       // [500][BP]
+    const float *w3f;      // frozen W3 [512][out]
+    float *grad;           // gradient block
+    const float *E0, *E1;  // [NQ][250][BP] partial E of output 0 / 1 (E1 null for the critic)
+    int head;              // 1 = critic loss head, 2 = actor head
+    int fuse;              // apply ADAM + soft update here
+    shems_ddpg dd;         // for the heads
+    AdamCtx c;
+    int64_t gstride;       // learner groups: byte stride between learners (0 = single learner)
+};
+__device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
+{
+    B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.w3f = gsh(B.w3f, off);
+    B.grad = gsh(B.grad, off); B.E0 = gsh(B.E0, off); B.E1 = gsh(B.E1, off); gshift(B.dd, off); gshift(B.c, off);
+}
+enum { GR_NW = KT * NT, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };   // G: 32 rows of gb2 / gW3 each, 8 per wave
+
+constexpr int GR_BT = BP * 33;                               // W: [128 m][33] D2^T panel (doubles as the [4][4][4][64] exchange block)
+constexpr int GR_AT = BP * 33;                               // W: [128 m][33] h1^T panel
+constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8 + GR_GROWS * 3) * 4;
+
+// D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
+__device__ __forceinline__ float d2_val(float h2, float w3a, float w3b, float d3a, float d3b)
+{
+    const float g = fmaf(w3b, d3b, w3a * d3a);
+    return h2 > 0.0f ? g : 0.0f;
+}
+
+// One wave, one hidden unit k.  Everything a row needs comes straight from global memory in ONE batch of loads per lane -- its W1
+// column and b1 (owned by this wave: nobody else touches them), the NQ partial slabs of each E and the two input columns (lane,
+// lane + 64) of the network input, which for both differentiated networks is plain workspace data -- so there is no LDS block
+// beyond the error signal and one exposed latency.
+template <int IN, int OUT> struct L1Row { float w[IN]; float b; float e[OUT][2][NQ]; float x[2][IN]; };
+template <int IN, int OUT>
+__device__ __forceinline__ void l1row_load(const GradArgs &A, int k, int lane, L1Row<IN, OUT> &R)
+{
+#pragma unroll
+    for (int j = 0; j < IN; ++j) R.w[j] = A.P[j * H1N + k];
+    R.b = A.P[off_b1(IN) + k];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = lane + 64 * h;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            R.e[0][h][q] = A.E0[((int64_t)q * H1N + k) * BP + m];
+            if constexpr (OUT == 2) R.e[1][h][q] = A.E1[((int64_t)q * H1N + k) * BP + m];
+        }
+#pragma unroll
+        for (int j = 0; j < IN; ++j) R.x[h][j] = j < SIN ? A.x.X[j * BP + m] : A.x.A[(j - SIN) * BP + m];
+    }
+}
+template <int IN, int OUT>
+__device__ __forceinline__ void l1row_wave(const L1Row<IN, OUT> &R, const float *d3 /*LDS [2][BP]*/, int lane, float (&gout)[IN + 1])
+{
+    float dv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = lane + 64 * h;
+        float pre = R.b;
+#pragma unroll
+        for (int j = 0; j < IN; ++j) pre = fmaf(R.w[j], R.x[h][j], pre);
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { s0 += R.e[0][h][q]; if constexpr (OUT == 2) s1 += R.e[1][h][q]; }
+        float g = d3[m] * s0;
+        if (OUT == 2) g = fmaf(d3[BP + m], s1, g);
+        dv[h] = pre > 0.0f ? g : 0.0f;
+    }
+    gout[IN] = wave_sum(dv[0] + dv[1]);
+#pragma unroll
+    for (int j = 0; j < IN; ++j) gout[j] = wave_sum(R.x[0][j] * dv[0] + R.x[1][j] * dv[1]);
+}
+
+template <int IN, int OUT>
+__device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
+{
+    float *Bt = smem;                          // W: [128 m][65] D2^T panel
+    float *At = Bt + GR_BT;                    // W: [128 m][33] h1^T panel
+    float *xs = At + GR_AT;                    // [12][BP]
+    float *w1 = xs + W1K * BP;                 // w1m [12][256]
+    float *d3 = w1 + W1K * W1C;                // [2][BP]
+    float *w3s = d3 + AIN * BP;                // W3 [512][2] (out == 1: [.][0] only), zero beyond row 499
+    float *red = w3s + 2 * 512;                // [8]
+    float *gbuf = red + 8;                     // G: [32 rows][3] sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const bool is_w = (int)blockIdx.x < GR_NW, is_g = !is_w && (int)blockIdx.x < GR_NW + GR_NG;
+    const int kt = (int)blockIdx.x >> 4, nt = (int)blockIdx.x & 15;                          // W: (k-tile of 32, n-tile of 32)
+    const int mcol = tid & 127, half = tid >> 7;
+    const AdamCtx *fz = A.fuse ? &A.c : nullptr;
+    const bool publisher = blockIdx.x == 0;
+    constexpr int kRegion = OUT == 1 ? 2 : 4;
+    (void)kRegion;
+    STAMP(kRegion, 0);
+
+    if (!is_w && !is_g) {
+        // ---- R: layer-1 rows ----
+        const int k = ((int)blockIdx.x - GR_NW - GR_NG) * 4 + wave;
+        HeadRegs hr;
+        L1Row<IN, OUT> R;
+        l1row_load<IN, OUT>(A, min(k, H1N - 1), lane, R);
+        if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
+        STAMP(kRegion, 1);
+        if (A.head == 1) head_loss(A.dd, hr, d3, red, false, nullptr); else head_actor(A.dd, hr, d3, red, false, nullptr);
+        __syncthreads();
+        STAMP(kRegion, 2);
+        if (k >= H1N) return;
+        float gout[IN + 1];
+        l1row_wave<IN, OUT>(R, d3, lane, gout);
+        STAMP(kRegion, 3);
+        float mine = 0.0f;
+#pragma unroll
+        for (int j = 0; j <= IN; ++j) mine = lane == j ? gout[j] : mine;
+        if (lane <= IN) {
+            const int e = lane < IN ? lane * H1N + k : off_b1(IN) + k;
+            A.grad[e] = mine;
+            if (fz) adam_elem(*fz, e, mine);
+        }
+        STAMP(kRegion, 4);
+        return;
+    }
+
+    // The H2 panel does not depend on the error signal: its loads go out before the head is evaluated, so the two global latencies
+    // overlap instead of following each other.
+    float hv[16];
+    if (is_w) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) hv[u] = A.H2[min(nt * 32 + 2 * u + half, H2N - 1) * BP + mcol];
+    }
+    XRegs<IN> xr;
+    W1mRegs wr;
+    float w3v[4];
+    if (is_w) {
+        build_x_load<IN>(A.x, xr);
+        stage_w1m_load(A.w1t, wr);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, n = e >> 1, o = e & 1;
+        w3v[it] = A.w3f[n * OUT + min(o, OUT - 1)];                                          // frozen copy: 512 rows, zero padded
+    }
+    HeadRegs hr;
+    if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
+    if (is_w) {
+        build_x_store<IN>(A.x, xr, xs, false);
+        stage_w1m_store(wr, w1);
+    }
+    if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
+    {   // W3 -> LDS as [n][2] (second column 0 for the critic), from the loads issued above
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = it * 256 + tid, o = e & 1;
+            w3s[e] = o < OUT ? w3v[it] : 0.0f;
+        }
+    }
+    STAMP(kRegion, 1);
+    __syncthreads();
+    STAMP(kRegion, 2);
+    const float d3a = d3[mcol], d3b = d3[BP + mcol];
+
+    if (is_w) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int nbase = nt * 32;
+        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
+        // issued first so that it runs under the VALU work of the D2 panel below.
+        const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
+        // D2^T panel Bt[m][nl] (row stride 33), nl = 2*u + half: 16 rows per thread from the loads issued above (W3 comes from LDS;
+        // rows >= 500 meet the zero rows of its image)
+        {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int nl = 2 * u + half, n = nbase + nl;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
+                Bt[mcol * 33 + nl] = d2_val(hv[u], w.x, w.y, d3a, d3b);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
+        STAMP(kRegion, 3);
+        __syncthreads();
+        STAMP(kRegion, 4);
+        // wave w: the whole 32 x 32 tile over the batch quarter [32 w, +32): 16 MFMA pairs, all operands fetched up front
+        {
+            const float *pa = At + (32 * wave) * 33 + li, *pb = Bt + (32 * wave) * 33 + li;
+            float ac[16], bc[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * 33]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+        }
+        STAMP(kRegion, 5);
+        __syncthreads();                            // everybody is done with the panels: Bt doubles as the exchange buffer
+        // Exchange [owner wave = r >> 2][source wave][r & 3][lane]: every wave hands each row group to the wave that finishes it
+        // (its own group included, so that nothing is indexed dynamically) and then adds the four batch quarters of ITS four rows
+        // in the fixed order ((q0 + q1) + q2) + q3; it owns those elements for ADAM.
+        float *xch = Bt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(((r >> 2) * 4 + wave) * 4 + (r & 3)) * 64 + lane] = acc[r];
+        __syncthreads();
+        {
+            float *gW2 = A.grad + off_w2(IN);
+            const int n = nbase + li;
+            float xv[4][4];
+#pragma unroll
+            for (int sw = 0; sw < 4; ++sw)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[sw][r] = xch[((wave * 4 + sw) * 4 + r) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            int idx[4];
+            float val[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kt * 32 + r + 8 * wave + 4 * lh;                               // row (4 wave + r) of the tile
+                val[r] = ((xv[0][r] + xv[1][r]) + xv[2][r]) + xv[3][r];
+                idx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
+                if (idx[r] >= 0) gW2[k * H2N + n] = val[r];
+            }
+            STAMP(kRegion, 6);
+            if (fz) adam_batch<4>(*fz, idx, val);
+            STAMP(kRegion, 7);
+        }
+    } else {
+        // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: GR_NG workgroups x GR_GROWS rows, one wave per row, all of a
+        // wave's rows in flight
+        const int g = blockIdx.x - GR_NW;
+        const float e0a = d3[lane], e0b = d3[64 + lane], e1a = d3[BP + lane], e1b = d3[BP + 64 + lane];
+        {
+            float h0[GR_GU], h1[GR_GU];
+#pragma unroll
+            for (int u = 0; u < GR_GU; ++u) {
+                const int nc = min(g * GR_GROWS + wave + 4 * u, H2N - 1);
+                h0[u] = A.H2[nc * BP + lane];
+                h1[u] = A.H2[nc * BP + 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < GR_GU; ++u) {
+                const int rl = wave + 4 * u, nn = g * GR_GROWS + rl;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * min(nn, H2N - 1));
+                const float s0 = wave_sum(h0[u] * e0a + h1[u] * e0b);
+                const float s1 = wave_sum(h0[u] * e1a + h1[u] * e1b);
+                const float sb = wave_sum(d2_val(h0[u], w.x, w.y, e0a, e1a) + d2_val(h1[u], w.x, w.y, e0b, e1b));
+                if (lane == 0) { gbuf[rl * 3 + 0] = sb; gbuf[rl * 3 + 1] = s0; gbuf[rl * 3 + 2] = s1; }
+            }
+        }
+        STAMP(kRegion, 5);
+        __syncthreads();
+        if (tid < GR_GROWS * 3) {                   // one element per thread: (row, b2 | W3[.][0] | W3[.][1])
+            const int rl = tid / 3, c = tid - rl * 3, nn = g * GR_GROWS + rl;
+            if (nn < H2N && c - 1 < OUT) {
+                const int e = c == 0 ? off_b2(IN) + nn : off_w3(IN) + nn * OUT + (c - 1);
+                const float v = gbuf[tid];
+                A.grad[e] = v;
+                if (fz) adam_elem(*fz, e, v);
+            }
+        }
+        STAMP(kRegion, 7);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_grad(GradArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
+    if (A.in == SIN) grad_body<SIN, 2>(A, smem); else grad_body<CIN, 1>(A, smem);
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -1106,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_perturb(const float *__restrict__ src, 
     if (i < n) dst[i] = src[i] + shift;
 }
 
-// s of the minibatch the last shems_ddpg_critic_grad sampled (ring slots kept in the workspace) -> obs [batch][9]
+// s of the minibatch the last update sampled (ring slots kept in the workspace) -> obs [batch][9]
 __global__ __launch_bounds__(256) void k_batch_obs(shems_replay ring, const float *__restrict__ ws, int batch, float *__restrict__ obs)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1129,12 +1253,17 @@ __global__ __launch_bounds__(256) void k_action_distance(const float *__restrict
     if (threadIdx.x == 0) out[0] = sqrtf(((part[0] + part[1]) + (part[2] + part[3])) / (float)count);
 }
 
+constexpr int FWD_LDS = FwdShape<false>::LDS, QG_LDS = FwdShape<true>::LDS;
+constexpr int MID_LDS = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
+static_assert(QG_LDS <= 160 * 1024, "one workgroup's LDS");
+
 static int set_lds_attrs()
 {
     static bool done = false;
     if (done) return SHEMS_OK;
-    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS), "attr k_fwd")) return rc;
-    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS), "attr k_bwd")) return rc;
+    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, QG_LDS), "attr k_fwd")) return rc;
+    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mid), hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS), "attr k_mid")) return rc;
+    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad), hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS), "attr k_grad")) return rc;
     done = true;
     return SHEMS_OK;
 }
@@ -1154,7 +1283,120 @@ static int check_ddpg(const shems_ddpg *d, const char *fn)
     return set_lds_attrs();
 }
 
+static int check_group(const shems_group *g, const char *fn)
+{
+    if (!g || g->count < 1 || g->count > 65535 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
+        return set_error(SHEMS_ERR_ARG, "%s: shems_group needs 1 <= count <= 65535 and a 16-byte-multiple stride", fn);
+    return SHEMS_OK;
+}
+
+static int check_adam(double bp1, double bp2, const char *fn)
+{
+    if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "%s: beta powers must be in (0,1)", fn);
+    return SHEMS_OK;
+}
+
+struct AdamScalars { double eta, bp1, bp2, gscale; float *publish; };
+
+static AdamCtx adam_ctx(const shems_ddpg *d, bool critic, const AdamScalars &s)
+{
+    const double k1 = s.eta / (1.0 - s.bp1), ic2 = 1.0 / (1.0 - s.bp2);
+    return critic ? AdamCtx{d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, nullptr, SHEMS_CRITIC_PARAMS, (int)CIN,
+                            s.eta, s.bp1, s.bp2, s.gscale, k1, ic2, d->tau}
+                  : AdamCtx{d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, s.publish, SHEMS_ACTOR_PARAMS, (int)SIN,
+                            s.eta, s.bp1, s.bp2, s.gscale, k1, ic2, d->tau};
+}
+
+// K1 + K2 + K3: the critic side of replay() (DDPG.jl:123-135).  fuse: K3 applies ADAM + the soft target update itself.
+static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                       int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
+    if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
+        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad: bad replay ring / length");
+    if (excl_count < 0 || excl_pos < 0 || (excl_count > 0 && (ring_len != ring->capacity || excl_count >= ring_len)))
+        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad_ex: an exclusion window needs a full ring and 0 <= count < capacity");
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = d->ws;
+    const XSrc none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
+    const XSrc x_sa{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr};
+    float *SC = slot(ws, SLOT_CRITIC), *SA = slot(ws, SLOT_ACTOR);
+    FwdArgs f;
+    std::memset(&f, 0, sizeof f);
+    f.gstride = gs;
+    const unsigned fgx = NT * (BP / 32);
+    const int flds = FWD_LDS;
+    // K1: three independent forward passes; sample + gather + normalise + image packing + head freezing ride in this launch
+    f.job[0] = FwdJob{nullptr, d->actor_t, SIN, 2, 0, none, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, nullptr, nullptr};
+    f.job[1] = FwdJob{nullptr, d->critic, CIN, 1, 1, none, SC + SL_H2, SC + SL_P3, nullptr, nullptr};
+    f.job[2] = FwdJob{nullptr, d->actor, SIN, 2, 2, none, SA + SL_H2, SA + SL_P3, nullptr, nullptr};
+    f.prep = 1;
+    f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
+    hipLaunchKernelGGL(k_fwd, dim3(fgx + 6, 3, L), dim3(256), flds, st, f);      // + 6 publishing workgroups (see fwd_body)
+    // K2: critic_target on [s'; actor_target(s')] | E of the critic | E of the actor's two outputs
+    MidArgs m;
+    std::memset(&m, 0, sizeof m);
+    m.gstride = gs; m.nfwd = (int)fgx;
+    m.fwd = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, 0, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3, nullptr, nullptr};
+    m.e[0] = EJob{d->critic, CIN, 1, 0, SC + SL_H2, SC + SL_EP};
+    m.e[1] = EJob{d->actor, SIN, 2, 0, SA + SL_H2, SA + SL_EP};
+    m.e[2] = EJob{d->actor, SIN, 2, 1, SA + SL_H2, ws + WS_EA1};
+    hipLaunchKernelGGL(k_mid, dim3(fgx + 3 * KT * NQ, 1, L), dim3(256), MID_LDS, st, m);
+    // K3: critic gradient (+ ADAM + soft update)
+    GradArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.w1t = w1t_of(ws, SLOT_CRITIC); g.P = d->critic; g.in = CIN; g.out = 1; g.x = x_sa; g.H2 = SC + SL_H2; g.w3f = ws + WS_FW3C;
+    g.grad = d->grad_critic; g.E0 = SC + SL_EP; g.E1 = nullptr; g.head = 1; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
+    g.c = adam_ctx(d, true, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
+    return hip_ok(hipGetLastError(), "ddpg critic-side launches");
+}
+
+// K4 + K5: the actor side (DDPG.jl:137-140), through the critic as it stands now (already updated)
+static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = d->ws;
+    // critic on [s; a_pi], a_pi = tanh(b3 + partials of the actor pass); workgroup 0 publishes a_pi for K5's head
+    const XSrc x_spi{ws + WS_XT, nullptr, slot(ws, SLOT_ACTOR) + SL_P3, d->actor + off_b3(SIN, 2), ws + WS_API};
+    const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
+    float *C2 = slot(ws, SLOT_CRITIC2), *SA = slot(ws, SLOT_ACTOR);
+    FwdArgs f;
+    std::memset(&f, 0, sizeof f);
+    f.gstride = gs;
+    const unsigned fgx = NT * (BP / 32);
+    f.prep = 2;
+    f.job[0] = FwdJob{nullptr, d->critic, CIN, 1, 0, x_spi, nullptr, C2 + SL_P3, ws + WS_D3Q, ws + WS_DAP};
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG_LDS, st, f);
+    GradArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.w1t = w1t_of(ws, SLOT_ACTOR); g.P = d->actor; g.in = SIN; g.out = 2; g.x = x_s; g.H2 = SA + SL_H2; g.w3f = ws + WS_FW3A;
+    g.grad = d->grad_actor; g.E0 = SA + SL_EP; g.E1 = ws + WS_EA1; g.head = 2; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
+    g.c = adam_ctx(d, false, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
+    return hip_ok(hipGetLastError(), "ddpg actor-side launches");
+}
+
+static int adam_launch(const shems_ddpg *d, bool critic, const AdamScalars &s, hipStream_t st, unsigned L, int64_t gs)
+{
+    if (int rc = check_adam(s.bp1, s.bp2, "adam")) return rc;
+    const AdamCtx c = adam_ctx(d, critic, s);
+    hipLaunchKernelGGL(k_adam_soft, dim3((c.n + 1023) / 1024, 1, L), dim3(256), 0, st, c, gs);
+    return hip_ok(hipGetLastError(), "k_adam_soft launch");
+}
+
 extern "C" {
+
+#ifdef SHEMS_STAMP
+/* diagnostic build only: d_buf = device buffer of 5 * 1024 * 16 * 2 uint64 (or NULL to switch the stamps off) */
+int shems_debug_set_stamps(void *d_buf)
+{
+    unsigned long long *p = (unsigned long long *)d_buf;
+    return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p), "set stamps");
+}
+#endif
 
 int shems_ddpg_workspace_floats(int64_t *out)
 {
@@ -1174,166 +1416,85 @@ int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64
     return SHEMS_OK;
 }
 
-static int check_group(const shems_group *g, const char *fn)
+/* replay() in one call, single replica: K1..K5 with ADAM + soft updates inside the gradient launches. */
+int shems_ddpg_update(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
+                      int64_t excl_pos, int64_t excl_count, double eta_crit, double bp1_crit, double bp2_crit,
+                      double eta_act, double bp1_act, double bp2_act, float *d_publish, void *stream)
 {
-    if (!g || g->count < 1 || g->count > 65535 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
-        return set_error(SHEMS_ERR_ARG, "%s: shems_group needs 1 <= count <= 65535 and a 16-byte-multiple stride", fn);
-    return SHEMS_OK;
+    if (int rc = check_adam(bp1_crit, bp2_crit, "shems_ddpg_update")) return rc;
+    if (int rc = check_adam(bp1_act, bp2_act, "shems_ddpg_update")) return rc;
+    const AdamScalars sc{eta_crit, bp1_crit, bp2_crit, 1.0, nullptr}, sa{eta_act, bp1_act, bp2_act, 1.0, d_publish};
+    if (int rc = critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, &sc, stream)) return rc;
+    return actor_side(d, 1, 0, &sa, stream);
 }
 
-static int critic_grad_impl(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                            int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, void *stream)
+int shems_ddpg_group_update(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len, uint64_t seed,
+                            uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,
+                            double bp2_act, void *stream)
 {
-    if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
-    if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
-        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad: bad replay ring / length");
-    if (excl_count < 0 || excl_pos < 0 || (excl_count > 0 && (ring_len != ring->capacity || excl_count >= ring_len)))
-        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_grad_ex: an exclusion window needs a full ring and 0 <= count < capacity");
-    hipStream_t st = (hipStream_t)stream;
-    float *ws = d->ws;
-    const XSrc x_s2{ws + WS_X2T, nullptr, nullptr, nullptr, nullptr};
-    const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
-    const XSrc x_s2a{ws + WS_X2T, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3, d->actor_t + off_b3(SIN, 2), nullptr};
-    const XSrc x_sa{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr};
-    FwdArgs f;
-    std::memset(&f, 0, sizeof f);
-    f.gstride = gs;
-    f.mt = L >= 8 ? 64 : 32;                       // column-tile width (same bits either way, see FwdShape)
-    const unsigned fgx = NT * (BP / f.mt);
-    const int flds = f.mt == 64 ? FwdShape<64>::LDS : FwdShape<32>::LDS;
-    f.job[0] = FwdJob{w1t_of(ws, SLOT_ACTOR_T), d->actor_t, SIN, 2, x_s2, nullptr, slot(ws, SLOT_ACTOR_T) + SL_P3};
-    f.prep = 1;                                    // sample + gather + normalise + layer-1 image packing ride in this launch
-    f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx + 5, 1, L), dim3(256), flds, st, f);      // + 5 publishing workgroups (see fwd_body)
-    f.prep = 0;
-    f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC_T), d->critic_t, CIN, 1, x_s2a, nullptr, slot(ws, SLOT_CRITIC_T) + SL_P3};
-    f.job[1] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, slot(ws, SLOT_CRITIC) + SL_H2, slot(ws, SLOT_CRITIC) + SL_P3};
-    f.job[2] = FwdJob{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, slot(ws, SLOT_ACTOR) + SL_H2, slot(ws, SLOT_ACTOR) + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 3, L), dim3(256), flds, st, f);
-    float *S = slot(ws, SLOT_CRITIC);
-    const BwdArgs b{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_sa, S + SL_H2, ws + WS_D3C, d->grad_critic, S + SL_D1P, nullptr, KT * NQ, 1, *d, gs};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
-    if (!d->fuse_l1)
-        hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->critic, (int)CIN, x_sa,
-                           (const float *)(S + SL_D1P), d->grad_critic, gs);
-    return hip_ok(hipGetLastError(), "ddpg critic_grad launches");
+    if (int rc = check_group(g, "shems_ddpg_group_update")) return rc;
+    if (int rc = check_adam(bp1_crit, bp2_crit, "shems_ddpg_group_update")) return rc;
+    if (int rc = check_adam(bp1_act, bp2_act, "shems_ddpg_group_update")) return rc;
+    const AdamScalars sc{eta_crit, bp1_crit, bp2_crit, 1.0, nullptr}, sa{eta_act, bp1_act, bp2_act, 1.0, nullptr};
+    const int64_t gs = g->count > 1 ? g->stride_bytes : 0;
+    if (int rc = critic_side(d0, ring0, ring_len, seed, tick, 0, 0, (unsigned)g->count, gs, &sc, stream)) return rc;
+    return actor_side(d0, (unsigned)g->count, gs, &sa, stream);
 }
 
 int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
                            void *stream)
 {
-    return critic_grad_impl(d, ring, ring_len, seed, tick, 0, 0, 1, 0, stream);
+    return critic_side(d, ring, ring_len, seed, tick, 0, 0, 1, 0, nullptr, stream);
 }
 
 int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
                               int64_t excl_pos, int64_t excl_count, void *stream)
 {
-    return critic_grad_impl(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, stream);
+    return critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, nullptr, stream);
 }
 
 int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
                                  uint64_t seed, uint32_t tick, void *stream)
 {
     if (int rc = check_group(g, "shems_ddpg_group_critic_grad")) return rc;
-    return critic_grad_impl(d0, ring0, ring_len, seed, tick, 0, 0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, stream);
-}
-
-static int adam_launch(float *p, const float *g, float *m, float *v, float *target, int n, double eta, double bp1, double bp2,
-                       double gscale, float tau, float *w1t_g, int in, float *publish, hipStream_t st, unsigned L, int64_t gs, const L1Src &l1)
-{
-    if (!(bp1 > 0.0 && bp1 < 1.0 && bp2 > 0.0 && bp2 < 1.0)) return set_error(SHEMS_ERR_ARG, "adam: beta powers must be in (0,1)");
-    const AdamCtx c{p, g, m, v, target, w1t_g, publish, n, in, eta, bp1, bp2, gscale, tau};
-    const int sweep = l1.on ? n - (in + 1) * H1N : n;             // elements the plain sweep covers
-    const int row_wgs = l1.on ? (H1N + 3) / 4 : 0;                // + the workgroups that produce and apply the layer-1 rows
-    static_assert(((SIN + 1) * H1N) % 4 == 0 && ((CIN + 1) * H1N) % 4 == 0, "the sweep starts on a 16-byte boundary");
-    hipLaunchKernelGGL(k_adam_soft, dim3(row_wgs + (sweep + 1023) / 1024, 1, L), dim3(256), 0, st, c, l1, gs);
-    return hip_ok(hipGetLastError(), "k_adam_soft launch");
-}
-
-// the layer-1 sources of the two differentiated networks (must match what *_grad_impl hands to k_bwd / k_l1bwd)
-static L1Src l1_critic(const shems_ddpg *d, bool on)
-{
-    float *ws = d->ws;
-    return L1Src{d->critic, XSrc{ws + WS_XT, ws + WS_AT, nullptr, nullptr, nullptr}, slot(ws, SLOT_CRITIC) + SL_D1P, d->grad_critic, on ? 1 : 0};
-}
-static L1Src l1_actor(const shems_ddpg *d, bool on)
-{
-    float *ws = d->ws;
-    return L1Src{d->actor, XSrc{ws + WS_XT, nullptr, nullptr, nullptr, nullptr}, slot(ws, SLOT_ACTOR) + SL_D1P, d->grad_actor, on ? 1 : 0};
+    return critic_side(d0, ring0, ring_len, seed, tick, 0, 0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, nullptr, stream);
 }
 
 int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_apply")) return rc;
-    if (d->fuse_l1 && grad_scale != 1.0)
-        return set_error(SHEMS_ERR_ARG, "shems_ddpg_critic_apply: fuse_l1 is the single-replica form (grad_scale must be 1)");
-    return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2,
-                       grad_scale, d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream, 1, 0, l1_critic(d, d->fuse_l1 != 0));
+    return adam_launch(d, true, AdamScalars{eta, bp1, bp2, grad_scale, nullptr}, (hipStream_t)stream, 1, 0);
 }
 
 int shems_ddpg_group_critic_apply(const shems_ddpg *d, const shems_group *g, double eta, double bp1, double bp2, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_group_critic_apply")) return rc;
     if (int rc = check_group(g, "shems_ddpg_group_critic_apply")) return rc;
-    return adam_launch(d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, SHEMS_CRITIC_PARAMS, eta, bp1, bp2, 1.0,
-                       d->tau, w1t_of(d->ws, SLOT_CRITIC), (int)CIN, nullptr, (hipStream_t)stream, (unsigned)g->count,
-                       g->count > 1 ? g->stride_bytes : 0, l1_critic(d, d->fuse_l1 != 0));
+    return adam_launch(d, true, AdamScalars{eta, bp1, bp2, 1.0, nullptr}, (hipStream_t)stream, (unsigned)g->count,
+                       g->count > 1 ? g->stride_bytes : 0);
 }
 
-static int actor_grad_impl(const shems_ddpg *d, unsigned L, int64_t gs, void *stream)
-{
-    if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    float *ws = d->ws;
-    // critic (already updated, DDPG.jl:137-140) on [s; a_pi], a_pi = tanh(b3 + partials of the actor pass)
-    const XSrc x_spi{ws + WS_XT, nullptr, slot(ws, SLOT_ACTOR) + SL_P3, d->actor + off_b3(SIN, 2), ws + WS_API};
-    const XSrc x_spi_ro{ws + WS_XT, ws + WS_API, nullptr, nullptr, nullptr};
-    const XSrc x_s{ws + WS_XT, nullptr, nullptr, nullptr, nullptr};
-    float *C2 = slot(ws, SLOT_CRITIC2);
-    FwdArgs f;
-    std::memset(&f, 0, sizeof f);
-    f.gstride = gs;
-    f.mt = L >= 8 ? 64 : 32;                       // column-tile width (same bits either way, see FwdShape)
-    const unsigned fgx = NT * (BP / f.mt);
-    const int flds = f.mt == 64 ? FwdShape<64>::LDS : FwdShape<32>::LDS;
-    f.job[0] = FwdJob{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi, C2 + SL_H2, C2 + SL_P3};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), flds, st, f);
-    const BwdArgs bi{w1t_of(ws, SLOT_CRITIC), d->critic, CIN, 1, x_spi_ro, C2 + SL_H2, ws + WS_D3Q, nullptr, C2 + SL_D1P, ws + WS_DAP, 0, 0, *d, gs};
-    hipLaunchKernelGGL(k_bwd, dim3(KT * NQ, 1, L), dim3(256), BWD_LDS, st, bi);
-    float *S = slot(ws, SLOT_ACTOR);
-    const BwdArgs b{w1t_of(ws, SLOT_ACTOR), d->actor, SIN, 2, x_s, S + SL_H2, ws + WS_D3A, d->grad_actor, S + SL_D1P, nullptr, KT * NQ, 2, *d, gs};
-    hipLaunchKernelGGL(k_bwd, dim3(2 * KT * NQ + BWD_NG, 1, L), dim3(256), BWD_LDS, st, b);
-    if (!d->fuse_l1)
-        hipLaunchKernelGGL(k_l1bwd, dim3((H1N + 3) / 4, 1, L), dim3(256), 0, st, (const float *)d->actor, (int)SIN, x_s,
-                           (const float *)(S + SL_D1P), d->grad_actor, gs);
-    return hip_ok(hipGetLastError(), "ddpg actor_grad launches");
-}
-
-int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream) { return actor_grad_impl(d, 1, 0, stream); }
+int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream) { return actor_side(d, 1, 0, nullptr, stream); }
 
 int shems_ddpg_group_actor_grad(const shems_ddpg *d0, const shems_group *g, void *stream)
 {
     if (int rc = check_group(g, "shems_ddpg_group_actor_grad")) return rc;
-    return actor_grad_impl(d0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, stream);
+    return actor_side(d0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, nullptr, stream);
 }
 
 int shems_ddpg_group_actor_apply(const shems_ddpg *d, const shems_group *g, double eta, double bp1, double bp2, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_group_actor_apply")) return rc;
     if (int rc = check_group(g, "shems_ddpg_group_actor_apply")) return rc;
-    return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, 1.0,
-                       d->tau, nullptr, (int)SIN, nullptr, (hipStream_t)stream, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0,
-                       l1_actor(d, d->fuse_l1 != 0));
+    return adam_launch(d, false, AdamScalars{eta, bp1, bp2, 1.0, nullptr}, (hipStream_t)stream, (unsigned)g->count,
+                       g->count > 1 ? g->stride_bytes : 0);
 }
 
 int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, float *d_publish,
                                void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_apply")) return rc;
-    if (d->fuse_l1 && grad_scale != 1.0)
-        return set_error(SHEMS_ERR_ARG, "shems_ddpg_actor_apply: fuse_l1 is the single-replica form (grad_scale must be 1)");
-    return adam_launch(d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, SHEMS_ACTOR_PARAMS, eta, bp1, bp2, grad_scale,
-                       d->tau, nullptr, (int)SIN, d_publish, (hipStream_t)stream, 1, 0, l1_actor(d, d->fuse_l1 != 0));
+    return adam_launch(d, false, AdamScalars{eta, bp1, bp2, grad_scale, d_publish}, (hipStream_t)stream, 1, 0);
 }
 
 int shems_ddpg_actor_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)

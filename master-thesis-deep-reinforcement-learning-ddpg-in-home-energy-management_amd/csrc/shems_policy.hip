@@ -33,6 +33,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "shems_env_dev.h"
 #include "shems_internal.h"
@@ -79,7 +80,13 @@ struct ActArgs {
 };
 
 template <class T>
-__device__ __forceinline__ T *gsh(T *p, int64_t off) { return p ? reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off) : p; }
+__device__ __forceinline__ T *gsh(T *p, int64_t off)
+{
+    // byte arithmetic on the pointer itself (no round trip through an integer): the compiler keeps the global address space of the
+    // kernel argument and emits global_load / global_store instead of flat accesses
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return p ? reinterpret_cast<T *>(reinterpret_cast<B *>(p) + off) : p;
+}
 
 template <int TM, int NW>
 constexpr size_t act_lds_bytes()

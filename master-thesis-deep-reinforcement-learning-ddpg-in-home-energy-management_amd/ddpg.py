@@ -52,7 +52,7 @@ def eps_schedule(current_episode, mem_size=24000, ep_length=72, zeta=EPS_ZETA, x
 class DdpgArgs(C.Structure):           # shems_ddpg
     _fields_ = [(n, C.c_void_p) for n in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic",
                                           "v_critic", "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")] + \
-               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("fuse_l1", C.c_int32)]
+               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class RingWindow(C.Structure):         # shems_ring_window
@@ -73,6 +73,9 @@ def _declare():
     L.shems_act_step_grid.restype = C.c_int
     PD = C.POINTER(DdpgArgs)
     L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
+    dbl = C.c_double
+    L.shems_ddpg_update.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, dbl, dbl, dbl, dbl, dbl, dbl, vp, vp]
+    L.shems_ddpg_update.restype = C.c_int
     L.shems_ddpg_critic_grad.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, vp]
     L.shems_ddpg_critic_grad_ex.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, vp]
     L.shems_ddpg_critic_grad_ex.restype = C.c_int
@@ -195,7 +198,8 @@ class Agent:
         self.bp_critic = [0.9, 0.999]
         self.updates = 0
         self.sync = GradSync(None)                 # replicas exchange gradients through this (RCCL)
-        self.fuse_l1 = True                        # used only while world == 1 (see shems_ddpg.fuse_l1)
+        self.fused = True                          # single replica: replay() = ONE call, shems_ddpg_update (5 launches, ADAM inside the
+                                                   # gradient launches); False = the split calls the data-parallel path uses (same bits)
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -216,7 +220,7 @@ class Agent:
         """Everything replay() mutates (device clones + the host-side ADAM powers / counters)."""
         return ({k: getattr(self, k).clone() for k in self._LEARNER_TENSORS},
                 dict(bp_actor=list(self.bp_actor), bp_critic=list(self.bp_critic), updates=self.updates, tick=self.tick,
-                     pn_sigma=self.pn_sigma, fuse_l1=self.fuse_l1))
+                     pn_sigma=self.pn_sigma, fused=self.fused))
 
     def restore(self, snap):
         tensors, host = snap
@@ -328,8 +332,7 @@ class Agent:
         return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
                         self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
                         self.grad_actor.data_ptr(), self.grad_critic.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
-                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch,
-                        1 if (self.fuse_l1 and self.sync.world == 1) else 0)     # single replica: gW1/gb1 inside the ADAM launch
+                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch, 0)
 
     def enable_data_parallel(self, dist):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
@@ -348,6 +351,16 @@ class Agent:
         rs = ring.struct()
         tick = self.updates if tick is None else tick
         ex_pos, ex_cnt = (0, 0) if exclude is None else (int(exclude[0]) % ring.capacity, int(exclude[1]))
+        if self.fused and self.sync.world == 1 and self.noise_type != "pn":
+            # one replica, nothing to exchange and no parameter-noise adaptation between getData and the updates: the whole
+            # replay() is one call (K1..K5, csrc/shems_ddpg.hip)
+            _capi.check(self.L.shems_ddpg_update(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF, ex_pos, ex_cnt,
+                                                 self.eta_crit, self.bp_critic[0], self.bp_critic[1], self.eta_act, self.bp_actor[0],
+                                                 self.bp_actor[1], C.c_void_p(publish.data_ptr()) if publish is not None else None, st))
+            self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
+            self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
+            self.updates += 1
+            return
         _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF,
                                                      ex_pos, ex_cnt, st))
         if self.noise_type == "pn":                # DDPG.jl:126-128 (the actor is still the pre-update one here)
@@ -462,8 +475,8 @@ class Agent:
 
 class TrainWorkload:
     """bench.py's "train" step: the body of the reference's episode! loop for all envs of a rank at once --
-    act + noise + scale_action + step! + remember (one fused launch) and `updates` x replay() (8 launches
-    each, 2 gradient all-reduces when several GPUs train one model)."""
+    act + noise + scale_action + step! + remember (one fused launch) and `updates` x replay() (5 launches
+    each; 7 and 2 gradient all-reduces when several GPUs train one model)."""
 
     name = "train"
     dtype = "f32"
@@ -562,7 +575,7 @@ class TrainWorkload:
         snap = self.agent.snapshot()
         saved_sync, self.agent.sync = self.agent.sync, GradSync(None)
         world = saved_sync.world
-        self.agent.fuse_l1 = world == 1                 # time the launch structure the benchmarked world size runs (minus the exchange)
+        self.agent.fused = world == 1                   # time the launch structure the benchmarked world size runs (minus the exchange)
         try:
             torch.cuda.synchronize()
             e0.record()

@@ -33,6 +33,9 @@ def _declare_group():
     from .ddpg import ActParams, DdpgArgs
     PD, PG, PR = C.POINTER(DdpgArgs), C.POINTER(Group), C.POINTER(_capi.Replay)
     L.shems_act_step_group_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), PG, vp, vp, PR, C.POINTER(RingWindow), vp]
+    dbl = C.c_double
+    L.shems_ddpg_group_update.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, vp]
+    L.shems_ddpg_group_update.restype = C.c_int
     L.shems_ddpg_group_critic_grad.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, vp]
     L.shems_ddpg_group_critic_apply.argtypes = [PD, PG, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_group_actor_grad.argtypes = [PD, PG, vp]
@@ -137,16 +140,21 @@ class LearnerGroup:
                 ring.pushed += int(window[1])
 
     def replay(self, tick=None):
-        """replay() (DDPG.jl:121-145) for every learner: 8 launches in total, grid z = learner."""
+        """replay() (DDPG.jl:121-145) for every learner: 5 launches in total, grid z = learner (fused = False: the split calls,
+        7 launches -- the same bits)."""
         a0, g, r0 = self.learners[0], self.struct(), self.rings[0].struct()
         d = a0._ddpg_args()
         st = self._stream()
         tick = self.updates if tick is None else tick
-        _capi.check(self.L.shems_ddpg_group_critic_grad(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed,
-                                                        int(tick) & 0xFFFFFFFF, st))
-        _capi.check(self.L.shems_ddpg_group_critic_apply(C.byref(d), C.byref(g), a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], st))
-        _capi.check(self.L.shems_ddpg_group_actor_grad(C.byref(d), C.byref(g), st))
-        _capi.check(self.L.shems_ddpg_group_actor_apply(C.byref(d), C.byref(g), a0.eta_act, a0.bp_actor[0], a0.bp_actor[1], st))
+        if getattr(self, "fused", True):
+            _capi.check(self.L.shems_ddpg_group_update(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed, int(tick) & 0xFFFFFFFF,
+                                                       a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], a0.eta_act, a0.bp_actor[0], a0.bp_actor[1], st))
+        else:
+            _capi.check(self.L.shems_ddpg_group_critic_grad(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed,
+                                                            int(tick) & 0xFFFFFFFF, st))
+            _capi.check(self.L.shems_ddpg_group_critic_apply(C.byref(d), C.byref(g), a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], st))
+            _capi.check(self.L.shems_ddpg_group_actor_grad(C.byref(d), C.byref(g), st))
+            _capi.check(self.L.shems_ddpg_group_actor_apply(C.byref(d), C.byref(g), a0.eta_act, a0.bp_actor[0], a0.bp_actor[1], st))
         for ag in self.learners:                   # the learners advance in lockstep: shared beta powers / update count
             ag.bp_critic = [ag.bp_critic[0] * 0.9, ag.bp_critic[1] * 0.999]
             ag.bp_actor = [ag.bp_actor[0] * 0.9, ag.bp_actor[1] * 0.999]

@@ -191,6 +191,7 @@ def test_pipelined_replay_excludes_the_window_being_written_and_publishes_the_ac
     pos, cnt = 23900, 333                         # wraps around the end of the ring
     seen = set()
     for t in range(40):
+        ag.fused = bool(t & 1)                    # both forms take the exclusion window and publish the actor
         ag.replay(ring, tick=t, exclude=(pos, cnt), publish=pub)
         idx = ag.ws[30 * 128:31 * 128].cpu().numpy().view(np.int32)[:120]      # WS_IDX
         assert ((idx >= 0) & (idx < 24000)).all()
@@ -239,14 +240,14 @@ def test_parameter_noise_act_and_adaptation():
     torch.cuda.synchronize()
 
 
-def test_fused_layer1_gradient_is_bit_identical_to_the_separate_launch():
-    """shems_ddpg.fuse_l1 (single replica): gW1/gb1 produced inside the ADAM launch.  Same bytes as the k_l1bwd launch that the
-    data-parallel path keeps (the all-reduce needs the complete gradient before ADAM)."""
+def test_fused_update_is_bit_identical_to_the_split_calls():
+    """shems_ddpg_update (single replica: ADAM + soft update applied inside the gradient launches, 5 launches) against the split
+    calls the data-parallel path uses (critic_grad -> critic_apply -> actor_grad -> actor_apply, 7 launches): the same gradient
+    kernels and the same ADAM function, so every buffer must agree bit for bit after several updates."""
     out = []
-    for fuse in (True, False):
+    for fused in (True, False):
         torch, S, D, ag, ring, h = _setup(seed=17)
-        ag.fuse_l1 = fuse
-        assert ag._ddpg_args().fuse_l1 == (1 if fuse else 0)
+        ag.fused = fused
         for t in range(3):
             ag.replay(ring, tick=t)
         torch.cuda.synchronize()
