@@ -48,7 +48,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // phase boundaries into a buffer of its own -- no product code reads it, the product library contains none of this.
 #ifdef SHEMS_STAMP
 __device__ unsigned long long *g_stamps = nullptr;             // [5 launches][1024 workgroups][16 stamps][2]
-#define STAMP(region, i) do { if (threadIdx.x == 0 && g_stamps) { unsigned long long *sp_ = g_stamps + ((((size_t)(region) * 1024 + blockIdx.x + 256 * blockIdx.y) * 16 + (i)) * 2); \
+#define STAMP(region, i) do { if (threadIdx.x == 0 && g_stamps) { unsigned long long *sp_ = g_stamps + ((((size_t)(region) * 1024 + blockIdx.x) * 16 + (i)) * 2); \
         sp_[0] = __builtin_amdgcn_s_memtime(); sp_[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(region, i)
@@ -200,6 +200,46 @@ __device__ __forceinline__ void build_x_store(const XSrc &s, const XRegs<IN> &R,
     }
 }
 
+// The same for ONE 32-column tile [mbase, mbase + 32) (forward workgroups): xs is [12][32].  Threads < 64 own one action element
+// (o = tid >> 5, column tid & 31) each; the state rows are 288 elements, two per thread at most.
+template <int IN> struct XTRegs { float v[2]; float ab[2]; float p[NT]; };
+template <int IN>
+__device__ __forceinline__ void xt_load(const XSrc &s, int mbase, XTRegs<IN> &R)
+{
+    // rows 0..7: one element per thread; row 8: every thread loads (and later stores) the element of column tid & 31 -- eight threads
+    // write the same value to the same LDS word.  Nothing is predicated: a store under `e < 288` pulls its load into that branch,
+    // behind a full `s_waitcnt vmcnt(0)`.
+    R.v[0] = s.X[((int)threadIdx.x >> 5) * BP + mbase + ((int)threadIdx.x & 31)];
+    R.v[1] = s.X[8 * BP + mbase + ((int)threadIdx.x & 31)];
+    R.ab[0] = 0.0f; R.ab[1] = 0.0f;
+    if (IN == CIN) {                           // the critic's action rows: always an actor pass here (stored actions only enter through
+                                               // K1's gather) -- one straight path, no second branch whose registers the loads must respect
+        const int t = min((int)threadIdx.x, 63), o = t >> 5, m = mbase + (t & 31);
+        R.ab[1] = s.b3[o];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) R.p[q] = s.P3[(q * 2 + o) * BP + m];
+    }
+}
+template <int IN>
+__device__ __forceinline__ void xt_store(const XSrc &s, const XTRegs<IN> &R, int mbase, float *xs /*LDS [12][32]*/, bool publisher)
+{
+    const int tid = threadIdx.x;
+    xs[tid] = R.v[0];
+    xs[256 + (tid & 31)] = R.v[1];
+    if (tid < 32) xs[11 * 32 + tid] = 1.0f;                                       // bias row
+    if (tid < 64) {
+        float a = 0.0f;                                                           // rows 9, 10: zero for the actor nets
+        if (IN == CIN) {
+            float acc = R.ab[1];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc += R.p[q];
+            a = tanhf(acc);                                                       // Dense(500, 2, tanh)
+            if (publisher && s.publish) s.publish[(tid >> 5) * BP + mbase + (tid & 31)] = a;
+        }
+        xs[SIN * 32 + tid] = a;
+    }
+}
+
 // Layer 1 also runs on the matrix pipe: pre[k][m] = sum_j w1m[j][k] * xs[j][m] with K = 12 = 6 MFMA k-steps, where
 //   w1m [12][256] = rows 0..in-1: W1[j][k]; row 11: b1[k]; everything else (rows in..10, columns 250..255) zero
 //   xs  [12][BP]  = rows 0..in-1: the network input; row 11: 1.0 (bias); rows in..10 zero.
@@ -243,6 +283,7 @@ __device__ __forceinline__ void pack_w1m(const float *__restrict__ P, int in, fl
     pack_w1m_store(R, in, g);
 }
 // One 32(k) x 32(m) tile of layer-1 pre-activations, D layout (row k = (r&3)+8(r>>2)+4*lh, column m = lane&31).
+template <int WSTRIDE>
 __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int kbase, int mbase, int li, int lh)
 {
     f32x16 t;
@@ -252,7 +293,7 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1m, const float *xs, int
 #pragma unroll
     for (int s = 0; s < W1K / 2; ++s) {
         const int j = 2 * s + lh;
-        a[s] = w1m[j * W1C + kbase + li];
+        a[s] = w1m[j * WSTRIDE + kbase + li];
         b[s] = xs[j * BP + mbase + li];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -298,7 +339,8 @@ __device__ __forceinline__ void prep_load(const PrepArgs &A, int m, int which, b
     R.r = publish ? ring.r[j] : 0.0f;
     R.dn = publish ? (ring.done[j] ? 1.0f : 0.0f) : 0.0f;
 }
-__device__ __forceinline__ void prep_store(const PrepArgs &A, int m, float *xs, int which, bool publish, const PrepRegs &R)
+// xs (LDS input block, or null) has `xstride` columns; this thread's column goes to slot `xcol`.
+__device__ __forceinline__ void prep_store(const PrepArgs &A, int m, float *xs, int xcol, int xstride, int which, bool publish, const PrepRegs &R)
 {
     const shems_ddpg &d = A.d;
     float *ws = d.ws;
@@ -308,7 +350,7 @@ __device__ __forceinline__ void prep_store(const PrepArgs &A, int m, float *xs, 
         const float lo = R.lo[k], den = (R.hi[k] - lo) + 1e-8f;                       // MPS:56
         const float x2 = live ? (R.s2[k] - lo) / den : 0.0f;
         const float x1 = live ? (R.s[k] - lo) / den : 0.0f;
-        if (xs) xs[k * BP + m] = which == 0 ? x2 : x1;
+        if (xs) xs[k * xstride + xcol] = which == 0 ? x2 : x1;
         if (publish) {
             ws[WS_XT + k * BP + m] = x1;
             ws[WS_X2T + k * BP + m] = x2;
@@ -316,9 +358,9 @@ __device__ __forceinline__ void prep_store(const PrepArgs &A, int m, float *xs, 
     }
     const float a0 = live ? R.a[0] : 0.0f, a1 = live ? R.a[1] : 0.0f;
     if (xs) {
-        xs[9 * BP + m] = which == 1 ? a0 : 0.0f;
-        xs[10 * BP + m] = which == 1 ? a1 : 0.0f;
-        xs[11 * BP + m] = 1.0f;                                                        // bias row
+        xs[9 * xstride + xcol] = which == 1 ? a0 : 0.0f;
+        xs[10 * xstride + xcol] = which == 1 ? a1 : 0.0f;
+        xs[11 * xstride + xcol] = 1.0f;                                                // bias row
     }
     if (publish) {
         ws[WS_AT + m] = a0; ws[WS_AT + BP + m] = a1;
@@ -364,19 +406,19 @@ __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 template <bool QG> struct FwdShape {
     static constexpr int WST = QG ? 36 : 32;                  // row stride of the W2 panel (QG also reads it along n: 36 keeps the
                                                               // float4 staging stores aligned and that second read 2-way at worst)
-    static constexpr int LDS = (256 * WST + W1K * BP + W1K * W1C + 96 + 4 * 16 * 64 + 4 * 2 * 32 + (QG ? 32 * 32 + 4 * 2 * 32 : 0)) * 4;
+    static constexpr int LDS = (256 * WST + W1K * 32 + W1K * W1C + 256 + 4 * 16 * 64 + 4 * 2 * 32 + (QG ? 32 * 32 + 4 * 2 * 32 : 0)) * 4;
 };
 
 template <int IN, int PREP, bool QG>
-__device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const PrepArgs *pa)
+__device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const PrepArgs *pa, int bx, int job)
 {
     typedef FwdShape<QG> SH;
     constexpr int WST = SH::WST;
     float *Wc = smem;                          // [256][WST]  W2 panel (rows >= 250: zero)
-    float *xs = Wc + 256 * WST;                // [12][BP]
-    float *w1 = xs + W1K * BP;                 // w1m [12][256]
-    float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile
-    float *xch = ep + 96;                      // [4 quarters][16 rows][64 lanes]
+    float *xs = Wc + 256 * WST;                // [12][32]  the network input, this workgroup's 32 columns
+    float *w1 = xs + W1K * 32;                 // w1m [12][256]
+    float *ep = w1 + W1K * W1C;                // [32][3]: b2, W3[.][0], W3[.][1] of this n-tile (+ 160 unused slots: every thread stores)
+    float *xch = ep + 256;                     // [4 quarters][16 rows][64 lanes]
     float *pp = xch + 4 * 16 * 64;             // [4 row groups][2][32] layer-3 partials
     float *Mt = pp + 4 * 2 * 32;               // QG: [32 n][32 m]
     float *red = Mt + 32 * 32;                 // QG: [4 quarters][2][32]
@@ -385,19 +427,19 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     constexpr int kRegion = PREP == 1 ? 0 : PREP == 0 ? 1 : 3;
     (void)kRegion;
     STAMP(kRegion, 0);
-    if (PREP == 1 && (int)blockIdx.x >= NT * kMTiles) {
+    if (PREP == 1 && bx >= NT * kMTiles) {
         // The six extra workgroups of an update's first launch (job 0 only): one publishes what the later launches read from the
         // workspace (the sampled, gathered and normalised minibatch), four pack the layer-1 images of the four networks, one
         // freezes the output layers the gradient launches must read while their owners are updated in place.  Kept off the tile
         // workgroups so that none of those runs longer than the others.
-        if (blockIdx.y != 0) return;
-        const int duty = (int)blockIdx.x - NT * kMTiles;
+        if (job != 0) return;
+        const int duty = bx - NT * kMTiles;
         const shems_ddpg &d = pa->d;
         if (duty == 0) {
             if (tid < BP) {
                 PrepRegs pr;
                 prep_load(*pa, tid, 0, true, pr);
-                prep_store(*pa, tid, nullptr, 0, true, pr);
+                prep_store(*pa, tid, nullptr, 0, 0, 0, true, pr);
             }
         } else if (duty <= 4) {
             const int net = duty - 1;
@@ -413,52 +455,51 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
         }
         return;
     }
-    const int ntile = (int)blockIdx.x / kMTiles, n0 = ntile * 32;
-    const int mbase = 32 * ((int)blockIdx.x % kMTiles);
+    const int ntile = bx / kMTiles, n0 = ntile * 32;
+    const int mbase = 32 * (bx % kMTiles);
     const float *__restrict__ P = J.P;
 
-    // ---- every global load of the workgroup goes out before the first one is consumed (one exposed latency) ----
-    float epv = 0.0f;
-    if (tid < 96) {                            // epilogue constants
-        const int nl = tid / 3, c = tid - nl * 3, nc = min(n0 + nl, H2N - 1);
-        epv = c == 0 ? P[off_b2(IN) + nc] : P[off_w3(IN) + nc * J.out + min(c - 1, J.out - 1)];
-        if (n0 + nl >= H2N || c - 1 >= J.out) epv = 0.0f;
-    }
-    // W2[0..255][n0..n0+31] (rows of 128 B, 8 float4 each): 2048 float4, 8 per thread.
-    // Columns >= 500 of the last tile read the next row / b2 (in bounds) and only feed output rows that are discarded.
-    const float *__restrict__ W2 = P + off_w2(IN);
-    float4 wv[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int e = it * 256 + tid, k = e >> 3, c = e & 7;
-        const float4 t4 = *reinterpret_cast<const float4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c);
-        wv[it] = k < H1N ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    XRegs<IN> xr;
+    // ---- every global load of the workgroup goes out before the first one is consumed (one exposed latency).  The small operands of
+    // layer 1 (input tile, layer-1 image, epilogue constants) are requested FIRST and the 32 KB W2 panel last: loads return in order,
+    // so layer 1 runs on the matrix pipe while the panel is still arriving ----
+    // (No load of this batch sits under a lane predicate, and no loaded value meets a select right at the load: either makes the
+    // compiler put the load in a branch of its own with an `s_waitcnt vmcnt(0)` inside, which drains everything issued before it.
+    // Padding is applied where the value is CONSUMED, or not at all where the other operand of the product is zero anyway.)
+    const int ep_t = min(tid, 95), ep_nl = ep_t / 3, ep_c = ep_t - ep_nl * 3, ep_nc = min(n0 + ep_nl, H2N - 1);
+    const float epv = P[ep_c == 0 ? off_b2(IN) + ep_nc : off_w3(IN) + ep_nc * J.out + min(ep_c - 1, J.out - 1)];   // epilogue constants
+    const float ep_keep = (n0 + ep_nl >= H2N || ep_c - 1 >= J.out) ? 0.0f : 1.0f;     // (a product, not a select: see above)
+    XTRegs<IN> xr;
     W1mRegs wr;
     PackRegs pk;
     PrepRegs pr;
     float d3q = 0.0f;
     if (QG) d3q = J.d3q[mbase + li];
-    if (PREP != 1) build_x_load<IN>(J.x, xr);
+    if (PREP != 1) xt_load<IN>(J.x, mbase, xr);
     if (PREP == 0) stage_w1m_load(J.w1t, wr); else pack_w1m_load(P, IN, pk);
     // First launch of an update: no separate sample/gather/pack launch.  Every tile workgroup samples the minibatch and gathers +
     // normalises what its network reads straight into its LDS input block, and packs the layer-1 image it needs from the
     // parameter block; the extra workgroups (above) publish the workspace copies for the later launches.
-    if (PREP == 1 && tid < BP) prep_load(*pa, tid, J.which, false, pr);
-    // ---- consume ----
-    if (PREP == 1) {
-        if (tid < BP) prep_store(*pa, tid, xs, J.which, false, pr);
-    } else {
-        build_x_store<IN>(J.x, xr, xs, blockIdx.x == 0);
-    }
-    if (PREP == 0) stage_w1m_store(wr, w1); else pack_w1m_store(pk, IN, w1);
-    if (tid < 96) ep[tid] = epv;
+    if (PREP == 1 && tid < 32) prep_load(*pa, mbase + tid, J.which, false, pr);
+    // W2[0..255][n0..n0+31] (rows of 128 B, 8 float4 each): 2048 float4, 8 per thread.  Rows 250..255 are copies of row 249 (clamped
+    // address): they only ever multiply layer-1 activations that are exactly zero (the image has no columns >= 250), in the forward
+    // product, and in QG's backward product they feed output rows whose relu mask is off.  Columns >= 500 of the last tile read the
+    // next row / b2 (in bounds) and only feed output rows that are discarded.
+    const float *__restrict__ W2 = P + off_w2(IN);
+    f32x4 wv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int e = it * 256 + tid, k = e >> 3, c = e & 7;
-        *reinterpret_cast<float4 *>(Wc + k * WST + 4 * c) = wv[it];
+        wv[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c);
     }
+    // ---- consume the layer-1 operands ----
+    if (PREP == 1) {
+        if (tid < 32) prep_store(*pa, mbase + tid, xs, tid, 32, J.which, false, pr);
+    } else {
+        xt_store<IN>(J.x, xr, mbase, xs, ntile == 0);          // (the four column tiles of n-tile 0 publish actor(s) between them)
+    }
+    if (PREP == 0) stage_w1m_store(wr, w1); else pack_w1m_store(pk, IN, w1);
+    ep[tid] = epv * ep_keep;                   // unconditional (threads >= 96 write copies of entry 95 into the unused slots): a store under
+                                               // `tid < 96` would pull the load into that branch, behind a full drain
     STAMP(kRegion, 1);
     __syncthreads();
     STAMP(kRegion, 2);
@@ -475,7 +516,7 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
 #pragma unroll
         for (int sidx = 0; sidx < W1K / 2; ++sidx) {
             const int j = 2 * sidx + lh;
-            xb[sidx] = xs[j * BP + mbase + li];
+            xb[sidx] = xs[j * 32 + li];
 #pragma unroll
             for (int q = 0; q < 2; ++q) wa[sidx][q] = w1[j * W1C + 64 * wave + 32 * q + li];
         }
@@ -486,6 +527,15 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
             for (int q = 0; q < 2; ++q)
                 t[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[sidx][q], xb[sidx], t[q], 0, 0, 0);
     }
+    // the W2 panel, now landed, goes to LDS (its own rows only are read by this wave in the forward pass, but the staging threads
+    // are spread over all rows: barrier)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid, k = e >> 3, c = e & 7;
+        *reinterpret_cast<f32x4 *>(Wc + k * WST + 4 * c) = wv[it];
+    }
+    __syncthreads();
     STAMP(kRegion, 3);
     // layer 2 over this wave's K quarter: 32 MFMA pairs, B operand = relu of the layer-1 registers, A operand = the W2 rows those
     // registers stand for
@@ -596,15 +646,17 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    FwdJob J = blockIdx.y == 0 ? A.job[0] : blockIdx.y == 1 ? A.job[1] : A.job[2];      // (no dynamic indexing of the kernarg block: that goes through scratch)
+    constexpr int kPerJob = NT * (BP / 32) + 6;    // K1: a one-dimensional grid of 3 x (64 tile + 6 publishing) workgroups
+    const int job = A.prep == 1 ? (int)blockIdx.x / kPerJob : 0, bx = (int)blockIdx.x - job * kPerJob;
+    FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];      // (no dynamic indexing of the kernarg block: that goes through scratch)
     gshift(J, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
     if (A.prep == 1) {                             // K1: three jobs, each workgroup gathers its own input block
         PrepArgs pa = A.pa;
         gshift(pa.d, blockIdx.z * A.gstride); gshift(pa.ring, blockIdx.z * A.gstride); pa.seed += blockIdx.z;
-        if (J.in == SIN) fwd_body<SIN, 1, false>(J, smem, &pa); else fwd_body<CIN, 1, false>(J, smem, &pa);
+        if (J.in == SIN) fwd_body<SIN, 1, false>(J, smem, &pa, bx, job); else fwd_body<CIN, 1, false>(J, smem, &pa, bx, job);
         return;
     }
-    fwd_body<CIN, 2, true>(J, smem, nullptr);      // K4: the updated critic on [s; actor(s)], forward + input gradient
+    fwd_body<CIN, 2, true>(J, smem, nullptr, bx, 0);      // K4: the updated critic on [s; actor(s)], forward + input gradient
 }
 
 // ---- K2: critic_target forward | the three E products ---------------------------------------------------------------------
@@ -635,14 +687,11 @@ __device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = u * 256 + tid, kl = e >> 6, nl = e & 63, k = kt * 32 + kl, n = nb + nl;
-        const float t = W2p[(int64_t)min(k, H1N - 1) * H2N + min(n, H2N - 1)];
-        wvp[u] = (k < H1N && n < H2N) ? t : 0.0f;
+        wvp[u] = W2p[(int64_t)min(k, H1N - 1) * H2N + min(n, H2N - 1)];     // clamped copies: rows k >= 250 are never stored, columns
+                                                                              // n >= 500 meet the zero rows of the M panel below
     }
-    if (tid < NQW) {
-        w3v = P[off_w3(E.in) + min(nb + tid, H2N - 1) * E.out + E.col];
-        if (nb + tid >= H2N) w3v = 0.0f;
-        w3s[tid] = w3v;
-    }
+    w3v = P[off_w3(E.in) + min(nb + min(tid, NQW - 1), H2N - 1) * E.out + E.col];
+    if (tid < NQW) w3s[tid] = nb + tid < H2N ? w3v : 0.0f;
     STAMP(1, 1);
     __syncthreads();
     STAMP(1, 2);
@@ -700,7 +749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if ((int)blockIdx.x < A.nfwd) {
         FwdJob J = A.fwd;
         gshift(J, off);
-        fwd_body<CIN, 0, false>(J, smem, nullptr);
+        fwd_body<CIN, 0, false>(J, smem, nullptr, (int)blockIdx.x, 0);
         return;
     }
     const int e = (int)blockIdx.x - A.nfwd;
@@ -934,7 +983,7 @@ enum { GR_NW = KT * NT, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4
 
 constexpr int GR_BT = BP * 33;                               // W: [128 m][33] D2^T panel (doubles as the [4][4][4][64] exchange block)
 constexpr int GR_AT = BP * 33;                               // W: [128 m][33] h1^T panel
-constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * W1C + AIN * BP + 2 * 512 + 8 + GR_GROWS * 3) * 4;
+constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3) * 4;
 
 // D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
 __device__ __forceinline__ float d2_val(float h2, float w3a, float w3b, float d3a, float d3b)
@@ -994,10 +1043,10 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     float *Bt = smem;                          // W: [128 m][65] D2^T panel
     float *At = Bt + GR_BT;                    // W: [128 m][33] h1^T panel
     float *xs = At + GR_AT;                    // [12][BP]
-    float *w1 = xs + W1K * BP;                 // w1m [12][256]
-    float *d3 = w1 + W1K * W1C;                // [2][BP]
-    float *w3s = d3 + AIN * BP;                // W3 [512][2] (out == 1: [.][0] only), zero beyond row 499
-    float *red = w3s + 2 * 512;                // [8]
+    float *w1 = xs + W1K * BP;                 // W: w1m columns of the k-tile, [12][32]
+    float *d3 = w1 + W1K * 32;                 // [2][BP]
+    float *w3s = d3 + AIN * BP;                // W3 rows of the n-tile (W) / of the 32 rows (G), [32][2] (out == 1: [.][1] zero)
+    float *red = w3s + 2 * 32;                 // [8]
     float *gbuf = red + 8;                     // G: [32 rows][3] sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const bool is_w = (int)blockIdx.x < GR_NW, is_g = !is_w && (int)blockIdx.x < GR_NW + GR_NG;
@@ -1044,31 +1093,26 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
         for (int u = 0; u < 16; ++u) hv[u] = A.H2[min(nt * 32 + 2 * u + half, H2N - 1) * BP + mcol];
     }
     XRegs<IN> xr;
-    W1mRegs wr;
-    float w3v[4];
+    f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+    float w3v = 0.0f;
+    const int nrow0 = is_w ? nt * 32 : ((int)blockIdx.x - GR_NW) * GR_GROWS;                  // first of the 32 W3 rows this workgroup needs
     if (is_w) {
         build_x_load<IN>(A.x, xr);
-        stage_w1m_load(A.w1t, wr);
+        const int t = min(tid, 95);                                                           // 12 rows x 8 float4: the k-tile's 32 image columns
+        wq = *reinterpret_cast<const f32x4 *>(A.w1t + (t >> 3) * W1C + kt * 32 + 4 * (t & 7));
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int e = it * 256 + tid, n = e >> 1, o = e & 1;
-        w3v[it] = A.w3f[n * OUT + min(o, OUT - 1)];                                          // frozen copy: 512 rows, zero padded
+    {
+        const int t = min(tid, 63), o = t & 1;
+        w3v = A.w3f[(nrow0 + (t >> 1)) * OUT + min(o, OUT - 1)];                              // frozen copy: 512 rows, zero padded
     }
     HeadRegs hr;
     if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
     if (is_w) {
         build_x_store<IN>(A.x, xr, xs, false);
-        stage_w1m_store(wr, w1);
+        if (tid < 96) *reinterpret_cast<f32x4 *>(w1 + (tid >> 3) * 32 + 4 * (tid & 7)) = wq;
     }
     if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
-    {   // W3 -> LDS as [n][2] (second column 0 for the critic), from the loads issued above
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int e = it * 256 + tid, o = e & 1;
-            w3s[e] = o < OUT ? w3v[it] : 0.0f;
-        }
-    }
+    if (tid < 64) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
     STAMP(kRegion, 1);
     __syncthreads();
     STAMP(kRegion, 2);
@@ -1081,14 +1125,14 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
         const int nbase = nt * 32;
         // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
         // issued first so that it runs under the VALU work of the D2 panel below.
-        const f32x16 t = l1_tile(w1, xs, kt * 32, wave * 32, li, lh);
+        const f32x16 t = l1_tile<32>(w1, xs, 0, wave * 32, li, lh);
         // D2^T panel Bt[m][nl] (row stride 33), nl = 2*u + half: 16 rows per thread from the loads issued above (W3 comes from LDS;
         // rows >= 500 meet the zero rows of its image)
         {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int nl = 2 * u + half, n = nbase + nl;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * n);
+                const int nl = 2 * u + half;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * nl);
                 Bt[mcol * 33 + nl] = d2_val(hv[u], w.x, w.y, d3a, d3b);
             }
         }
@@ -1153,8 +1197,8 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
             }
 #pragma unroll
             for (int u = 0; u < GR_GU; ++u) {
-                const int rl = wave + 4 * u, nn = g * GR_GROWS + rl;
-                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * min(nn, H2N - 1));
+                const int rl = wave + 4 * u;
+                const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * rl);
                 const float s0 = wave_sum(h0[u] * e0a + h1[u] * e0b);
                 const float s1 = wave_sum(h0[u] * e1a + h1[u] * e1b);
                 const float sb = wave_sum(d2_val(h0[u], w.x, w.y, e0a, e1a) + d2_val(h1[u], w.x, w.y, e0b, e1b));
@@ -1333,7 +1377,7 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     f.job[2] = FwdJob{nullptr, d->actor, SIN, 2, 2, none, SA + SL_H2, SA + SL_P3, nullptr, nullptr};
     f.prep = 1;
     f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx + 6, 3, L), dim3(256), flds, st, f);      // + 6 publishing workgroups (see fwd_body)
+    hipLaunchKernelGGL(k_fwd, dim3(3 * (fgx + 6), 1, L), dim3(256), flds, st, f);      // + 6 publishing workgroups per job (see fwd_body)
     // K2: critic_target on [s'; actor_target(s')] | E of the critic | E of the actor's two outputs
     MidArgs m;
     std::memset(&m, 0, sizeof m);

@@ -447,7 +447,7 @@ class Agent:
         return returns
 
     def run_episodes(self, env_train, env_eval, ring, num_ep, test_every=100, test_runs=100, seed=None,
-                     updates_per_step=1, on_eval=None):
+                     updates_per_step=1, on_eval=None, on_best=None):
         """run_episodes (DDPG.jl:244-298): train episodes, an evaluation sweep every `test_every` episodes
         (when i % test_every == 1) and a snapshot of the best-scoring actor.  Returns
         (total_reward [num_ep], score_mean [ceil(num_ep/test_every)], best_run, best_actor)."""
@@ -468,6 +468,8 @@ class Agent:
                 if score_mean[idx - 1] > best_score:
                     best_score, best_run = score_mean[idx - 1], i
                     best_actor = self.actor.detach().cpu().numpy().copy()
+                    if on_best:                                             # saveBSON(...; idx=i, path="temp"), DDPG.jl:282-286
+                        on_best(i, best_actor, total_reward, score_mean)
                 if on_eval:
                     on_eval(i, total_reward[i - 1], score_mean[idx - 1])
         return total_reward, score_mean, best_run, best_actor

@@ -1,0 +1,81 @@
+"""The R18 entry point (DDPG_reinforce_charger_v1.jl:10-47, 87-110) on the GPU path: env-var contract, MAIN's order, the reference's
+file names and headers.  The decoding rules of the job's input file are host logic and are tested without a GPU."""
+import csv
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import util as U
+
+M = importlib.import_module(U.PKG_NAME + ".main")
+
+
+def test_job_id_decoding_and_case_string():
+    """TUNED = input_templates/input09_08_on_01-09_eval.jl: JOB_ID ...9808 -> Charger98, suffix 08 = ternary 0022 -> BATCH 120,
+    noise_act 0.1, (250, 500), (1f-4, 1f-3); TASK_ID 3 -> rng_run 1233."""
+    c = M.config_from_env({"JOB_ID": "1179808", "TASK_ID": "3", "GPU_ID": "1"})
+    assert (c.charger_id, c.Charger_ID, c.seed_run, c.rng_run, c.gpu_id) == (98, "Charger98", 3, 1233, 1)
+    assert (c.BATCH_SIZE, c.noise_act, c.L1, c.L2, c.eta_act, c.eta_crit, c.NUM_EP, c.MEM_SIZE, c.noise_type) == \
+           (120, 0.1, 250, 500, 1e-4, 1e-3, 1001, 24000, "gn")
+    assert c.case == ("Charger98_dw0.01_p0.1_B120_M24000_gn-o0.1_th0.15_Y0.99_tau0.001_lract0.0001_lrcrit0.001_nact0.1_ntrg0.2")
+    # other digits of the grid
+    c2 = M.config_from_env({"JOB_ID": "1170143", "TASK_ID": "12", "GPU_ID": "0"})      # 43 = 1121 (base 3)
+    assert (c2.charger_id, c2.BATCH_SIZE, c2.noise_act, (c2.L1, c2.L2), (c2.eta_act, c2.eta_crit), c2.rng_run) == \
+           (1, 100, 0.2, (250, 500), (5e-4, 5e-3), 12312)
+    c3 = M.config_from_env({"JOB_ID": "1170100", "TASK_ID": "1", "GPU_ID": "0"})       # 00 -> (300, 600): not what the kernels are built for
+    assert (c3.L1, c3.L2, c3.eta_act) == (300, 600, 1e-5)
+    with pytest.raises(NotImplementedError):
+        M._check_supported(c3)
+    with pytest.raises(KeyError):
+        M.config_from_env({"JOB_ID": "1179808", "GPU_ID": "0"})
+    # Julia's printing of the Float32 / Float64 values that go into file names
+    for x, f32, want in ((1e-4, True, "0.0001"), (1e-5, True, "1.0e-5"), (5e-3, True, "0.005"), (0.99, True, "0.99"), (0.999, True, "0.999"),
+                         (0.01, False, "0.01"), (24000.0, False, "24000.0"), (-0.5, False, "-0.5"), (2.0, True, "2.0")):
+        assert M.julia_float(x, f32) == want, (x, f32)
+    # the untuned template of input.jl decodes three digits
+    c4 = M.config_from_env({"JOB_ID": "1179826", "TASK_ID": "2", "GPU_ID": "0", "SHEMS_INPUT_TEMPLATE": "input"})    # 26 = 222
+    assert (c4.MEM_SIZE, c4.BATCH_SIZE, c4.L1, c4.L2, c4.gamma, c4.sigma, c4.theta, c4.noise_type, c4.NUM_EP) == \
+           (24000, 120, 300, 600, 0.99, 0.2, 0.2, "ou", 101)
+    assert c4.case.startswith("Charger98_disw2_pen0.5_BATCH120_MEM24000_ou-noise_om0.2_th0.2_Y0.99_tau0.001_nact0.0001_ncrit0.001_smart-trainEP")
+
+
+@pytest.mark.gpu
+def test_entry_script_runs_mains_order_and_writes_the_reference_files(tmp_path):
+    torch = pytest.importorskip("torch")
+    env = {"JOB_ID": "1179808", "TASK_ID": "1", "GPU_ID": "0", "SHEMS_NUM_EP": "2", "SHEMS_NUM_SEEDS": "1", "SHEMS_NUM_ENVS": "64",
+           "SHEMS_SYNTHETIC_DATA": "1"}
+    logs = []
+    cwd0 = os.getcwd()
+    try:
+        cfg, written = M.main(env, cwd=str(tmp_path), log=logs.append)
+    finally:
+        os.chdir(cwd0)
+    case = cfg.case
+    stem = f"DDPG_Shems_Charger_v1_72_2_250_500_{case}_1231"
+    for f in (f"out/bson/{stem}_actor_2.npz", f"out/bson/{stem}_scores_2.npz", f"out/bson/temp/{stem}_actor_1.npz",
+              f"out/bson/temp/{stem}_scores_1.npz", "data/Charger98_all_train_fix.csv", "data/Charger98_all_eval_fix.csv"):
+        assert (tmp_path / f).exists(), f
+    last = tmp_path / f"out/tracker/1179808_eval_results_charger_v1_72_2_250_500_{case}_1231_2.csv"
+    best = tmp_path / f"out/tracker/1179808_eval_results_charger_v1_72_2_250_500_{case}_1231_best.csv"
+    assert [os.path.basename(w) for w in written] == [last.name, best.name]
+    H = importlib.import_module(U.PKG_NAME + ".harness")
+    for f in (last, best):
+        rows = list(csv.reader(open(f)))
+        assert rows[0] == H.RESULTS_HEADER and len(rows) == 1 + 1439                  # EP_LENGTH["all", "eval"] steps of the eval pass
+        a = np.array(rows[1:], float)
+        assert (a[:, 0] == np.arange(1, 1440)).all() and np.isfinite(a).all()         # `index` column = idx before the step
+    tr = list(csv.reader(open(tmp_path / "out/Tracker_Charger.csv")))
+    assert tr[0] == H.TRACKER_HEADER and len(tr) == 3
+    assert [r[12] for r in tr[1:]] == ["false", "true"] and [r[13] for r in tr[1:]] == ["2", "1"] and tr[1][9] == "1179808" and tr[1][10] == "1231"
+    assert any("Starting script with JOB_ID: 1179808, TASK_ID: 1 for charger Charger98" in l for l in logs)
+    assert any("is done!" in l for l in logs)
+    # scores file: total_reward [NUM_EP], score_mean [ceil(NUM_EP / test_every)], best_run
+    C = importlib.import_module(U.PKG_NAME + ".checkpoint")
+    os.chdir(tmp_path)
+    try:
+        tr_, sm_, best_run, nm_ = C.load(idx=2, scores_only=True, ep_len=72, num_ep=2, case=case, rng=1231)
+    finally:
+        os.chdir(cwd0)
+    assert tr_.shape == (2,) and sm_.shape == (1,) and best_run == 1 and np.isfinite(sm_).all()

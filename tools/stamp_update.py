@@ -38,7 +38,7 @@ for _ in range(nrep):
 S._capi.check(L.shems_debug_set_stamps(None))
 
 names = ["K1 k_fwd x3", "K2 k_mid", "K3 k_grad critic", "K4 k_fwd QG", "K5 k_grad actor"]
-roles = {0: lambda w: "tile" if (w % 256) < 64 else "duty", 1: lambda w: "fwd" if w < 64 else "E", 2: lambda w: "W" if w < 128 else "G" if w < 144 else "R",
+roles = {0: lambda w: "tile" if (w % 70) < 64 else "duty", 1: lambda w: "fwd" if w < 64 else "E", 2: lambda w: "W" if w < 128 else "G" if w < 144 else "R",
          3: lambda w: "tile", 4: lambda w: "W" if w < 128 else "G" if w < 144 else "R"}
 out = {}
 a = np.stack(acc)                                  # [rep][launch][wg][stamp][2]
