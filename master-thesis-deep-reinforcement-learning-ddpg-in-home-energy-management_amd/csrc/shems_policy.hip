@@ -137,6 +137,82 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
     return make_float2(r * c, r * s);
 }
 
+// One env after layer 3: p0, p1 = the pre-activation outputs (b3 included).  tanh, exploration noise, clamp, scale_action, step!,
+// remember (DDPG.jl:148-184, 199-229).  Returns the env's reward (0 when nothing was stepped).
+__device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, float p0, float p1, int64_t learner, int64_t goff)
+{
+    double reward = 0.0;
+    {
+        p0 = tanhf(p0);
+        p1 = tanhf(p1);
+        float a0, a1;
+        if (A.p.train && A.p.noise_kind == SHEMS_NOISE_EPS) {          // DDPG.jl:161-170
+            const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.p.tick, kStreamNoise, (uint32_t)A.p.seed,
+                                          (uint32_t)(A.p.seed >> 32));
+            const bool explore = !(u01_24(x.z) > A.p.eps);             // rng > eps: greedy; rng <= eps: uniform action
+            a0 = explore ? (float)((double)x.x * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
+            a1 = explore ? (float)((double)x.y * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
+        } else {
+            if (A.p.train) {
+                const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
+                if (A.p.noise_kind == SHEMS_NOISE_OU) {                // DDPG.jl:49-55, 157-158
+                    float2 X = reinterpret_cast<float2 *>(A.p.ou_state)[i];
+                    const float sdt = A.p.noise_sigma * sqrtf(A.p.ou_dt);
+                    X.x += A.p.ou_theta * (A.p.noise_mu - X.x) * A.p.ou_dt + sdt * z.x;
+                    X.y += A.p.ou_theta * (A.p.noise_mu - X.y) * A.p.ou_dt + sdt * z.y;
+                    reinterpret_cast<float2 *>(A.p.ou_state)[i] = X;
+                    p0 += X.x;
+                    p1 += X.y;
+                } else {                                               // DDPG.jl:57-61, 159-160: Normal(mu, sigma_act)
+                    p0 += A.p.noise_mu + A.p.noise_sigma * z.x;
+                    p1 += A.p.noise_mu + A.p.noise_sigma * z.y;
+                }
+            }
+            a0 = fminf(fmaxf(p0, -1.0f), 1.0f);                        // clamp.(act_pred .+ noise, -1f0, 1f0)
+            a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
+        }
+        if (A.a_out) reinterpret_cast<float2 *>(A.a_out)[i] = make_float2(a0, a1);
+        if (A.do_step) {
+            const shems_view &v = A.v;
+            const shems_config c = load_cfg(v, i);
+            float obs[SHEMS_NSTATE], pre[SHEMS_NSTATE];
+#pragma unroll
+            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = v.obs[i * SHEMS_NSTATE + k]; pre[k] = obs[k]; }
+            int32_t idx = v.idx[i], step = v.step[i];
+            StepFlows f;
+            float B, EV, Bt, EVt;
+            if (env_advance(c, v.tables, obs, idx, step, scale_action(a0), scale_action(a1), SHEMS_TRACK_OFF, reward, f,
+                            B, EV, Bt, EVt)) {
+#pragma unroll
+                for (int k = 0; k < SHEMS_NSTATE; ++k) v.obs[i * SHEMS_NSTATE + k] = obs[k];
+                v.idx[i] = idx;
+                v.step[i] = step;
+                if (A.rewards) A.rewards[i] = reward;
+                if (A.rewards_f32) A.rewards_f32[i] = (float)reward;
+                if (A.returns_acc) A.returns_acc[i] += reward;
+                if (A.use_ring) {
+                    const int64_t nl = A.gcount > 1 ? A.genvs : v.n_envs;          // the window rotates inside a learner's env block
+                    int64_t rel = (i - learner * nl) - A.win.offset;
+                    rel %= nl;
+                    if (rel < 0) rel += nl;
+                    if (rel < A.win.count) {
+                        shems_replay ring = A.ring;
+                        if (A.gcount > 1) {
+                            ring.s = gsh(ring.s, goff); ring.a = gsh(ring.a, goff); ring.r = gsh(ring.r, goff);
+                            ring.s2 = gsh(ring.s2, goff); ring.done = gsh(ring.done, goff);
+                        }
+                        ring_push(ring, (A.win.pos + rel) % ring.capacity, pre, a0, a1, (float)reward, obs);
+                    }
+                }
+            } else {
+                reward = 0.0;
+                raise(v.err, SHEMS_ERR_INDEX);
+            }
+        }
+    }
+    return reward;
+}
+
 // Scheduling pipeline of one chunk (one basic block): [DS reads of k-step 0], then per k-step
 // [2*TM MFMAs] [DS reads of the NEXT k-step] [2*TM MFMAs] [one LDS-DMA piece]: the operand fetch sits in the middle of an
 // MFMA group, half a group (~500 cycles) ahead of its first use.  ds_read2_b32 fetches two operands, so a k-step is
@@ -422,72 +498,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
         for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
-        p0 = tanhf(p0);
-        p1 = tanhf(p1);
-        float a0, a1;
-        if (A.p.train && A.p.noise_kind == SHEMS_NOISE_EPS) {          // DDPG.jl:161-170
-            const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.p.tick, kStreamNoise, (uint32_t)A.p.seed,
-                                          (uint32_t)(A.p.seed >> 32));
-            const bool explore = !(u01_24(x.z) > A.p.eps);             // rng > eps: greedy; rng <= eps: uniform action
-            a0 = explore ? (float)((double)x.x * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
-            a1 = explore ? (float)((double)x.y * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
-        } else {
-            if (A.p.train) {
-                const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
-                if (A.p.noise_kind == SHEMS_NOISE_OU) {                // DDPG.jl:49-55, 157-158
-                    float2 X = reinterpret_cast<float2 *>(A.p.ou_state)[i];
-                    const float sdt = A.p.noise_sigma * sqrtf(A.p.ou_dt);
-                    X.x += A.p.ou_theta * (A.p.noise_mu - X.x) * A.p.ou_dt + sdt * z.x;
-                    X.y += A.p.ou_theta * (A.p.noise_mu - X.y) * A.p.ou_dt + sdt * z.y;
-                    reinterpret_cast<float2 *>(A.p.ou_state)[i] = X;
-                    p0 += X.x;
-                    p1 += X.y;
-                } else {                                               // DDPG.jl:57-61, 159-160: Normal(mu, sigma_act)
-                    p0 += A.p.noise_mu + A.p.noise_sigma * z.x;
-                    p1 += A.p.noise_mu + A.p.noise_sigma * z.y;
-                }
-            }
-            a0 = fminf(fmaxf(p0, -1.0f), 1.0f);                        // clamp.(act_pred .+ noise, -1f0, 1f0)
-            a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
-        }
-        if (A.a_out) reinterpret_cast<float2 *>(A.a_out)[i] = make_float2(a0, a1);
-        if (A.do_step) {
-            const shems_view &v = A.v;
-            const shems_config c = load_cfg(v, i);
-            float obs[SHEMS_NSTATE], pre[SHEMS_NSTATE];
-#pragma unroll
-            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = v.obs[i * SHEMS_NSTATE + k]; pre[k] = obs[k]; }
-            int32_t idx = v.idx[i], step = v.step[i];
-            StepFlows f;
-            float B, EV, Bt, EVt;
-            if (env_advance(c, v.tables, obs, idx, step, scale_action(a0), scale_action(a1), SHEMS_TRACK_OFF, reward, f,
-                            B, EV, Bt, EVt)) {
-#pragma unroll
-                for (int k = 0; k < SHEMS_NSTATE; ++k) v.obs[i * SHEMS_NSTATE + k] = obs[k];
-                v.idx[i] = idx;
-                v.step[i] = step;
-                if (A.rewards) A.rewards[i] = reward;
-                if (A.rewards_f32) A.rewards_f32[i] = (float)reward;
-                if (A.returns_acc) A.returns_acc[i] += reward;
-                if (A.use_ring) {
-                    const int64_t nl = A.gcount > 1 ? A.genvs : v.n_envs;          // the window rotates inside a learner's env block
-                    int64_t rel = (i - learner * nl) - A.win.offset;
-                    rel %= nl;
-                    if (rel < 0) rel += nl;
-                    if (rel < A.win.count) {
-                        shems_replay ring = A.ring;
-                        if (A.gcount > 1) {
-                            ring.s = gsh(ring.s, goff); ring.a = gsh(ring.a, goff); ring.r = gsh(ring.r, goff);
-                            ring.s2 = gsh(ring.s2, goff); ring.done = gsh(ring.done, goff);
-                        }
-                        ring_push(ring, (A.win.pos + rel) % ring.capacity, pre, a0, a1, (float)reward, obs);
-                    }
-                }
-            } else {
-                reward = 0.0;
-                raise(v.err, SHEMS_ERR_INDEX);
-            }
-        }
+        reward = act_env_tail(A, i, p0, p1, learner, goff);
     }
     PSTAMP(12);
 #ifndef ABL_STAMP

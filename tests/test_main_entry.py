@@ -65,7 +65,7 @@ def test_entry_script_runs_mains_order_and_writes_the_reference_files(tmp_path):
         rows = list(csv.reader(open(f)))
         assert rows[0] == H.RESULTS_HEADER and len(rows) == 1 + 1439                  # EP_LENGTH["all", "eval"] steps of the eval pass
         a = np.array(rows[1:], float)
-        assert (a[:, 0] == np.arange(1, 1440)).all() and np.isfinite(a).all()         # `index` column = idx before the step
+        assert (a[:, 0] == np.arange(2, 1441)).all() and np.isfinite(a).all()         # `index` column = env.idx after the step (LU1:453, 476)
     tr = list(csv.reader(open(tmp_path / "out/Tracker_Charger.csv")))
     assert tr[0] == H.TRACKER_HEADER and len(tr) == 3
     assert [r[12] for r in tr[1:]] == ["false", "true"] and [r[13] for r in tr[1:]] == ["2", "1"] and tr[1][9] == "1179808" and tr[1][10] == "1231"
