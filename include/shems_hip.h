@@ -259,8 +259,13 @@ typedef struct shems_ddpg {
     float *losses;                                  /* [2] out: critic mse, actor loss (-mean q)   */
     float gamma, tau;
     int32_t batch;                                  /* BATCH_SIZE (<= 128)                         */
-    int32_t reserved;                               /* (round 1: fuse_l1) ignored                  */
+    int32_t flags;                                  /* SHEMS_DDPG_* bits (0 = default)             */
 } shems_ddpg;
+
+/* flags: DEFER_ACTOR_E -- split form only: shems_ddpg_critic_grad leaves the actor's two E products (independent of the critic
+ * update) out of its second launch; the caller issues them with shems_ddpg_actor_prepare between shems_ddpg_critic_grad and
+ * shems_ddpg_actor_grad, typically right after starting the asynchronous all-reduce of grad_critic, so that they run under it. */
+enum { SHEMS_DDPG_DEFER_ACTOR_E = 1 };
 
 int shems_ddpg_workspace_floats(int64_t *out);
 /* The whole replay() for one replica.  grad_actor / grad_critic still receive the complete gradients.  excl_pos / excl_count:
@@ -277,6 +282,7 @@ int shems_ddpg_critic_grad(const shems_ddpg *d, const shems_replay *ring, int64_
  * excl_count = 0 is shems_ddpg_critic_grad. */
 int shems_ddpg_critic_grad_ex(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len,
                               uint64_t seed, uint32_t tick, int64_t excl_pos, int64_t excl_count, void *stream);
+int shems_ddpg_actor_prepare(const shems_ddpg *d, void *stream);   /* see SHEMS_DDPG_DEFER_ACTOR_E */
 int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale,
                             void *stream);
 int shems_ddpg_actor_grad(const shems_ddpg *d, void *stream);

@@ -1352,6 +1352,21 @@ static AdamCtx adam_ctx(const shems_ddpg *d, bool critic, const AdamScalars &s)
 }
 
 // K1 + K2 + K3: the critic side of replay() (DDPG.jl:123-135).  fuse: K3 applies ADAM + the soft target update itself.
+// Data-parallel form only: the actor's two E products, when shems_ddpg.flags asked critic_grad to leave them out of K2 so that they
+// can run under the critic's gradient all-reduce (they need nothing the critic update produces).
+static int actor_e_launch(const shems_ddpg *d, unsigned L, int64_t gs, hipStream_t st)
+{
+    float *ws = d->ws, *SA = slot(ws, SLOT_ACTOR);
+    MidArgs m;
+    std::memset(&m, 0, sizeof m);
+    m.gstride = gs; m.nfwd = 0;
+    m.e[0] = EJob{d->actor, SIN, 2, 0, SA + SL_H2, SA + SL_EP};
+    m.e[1] = EJob{d->actor, SIN, 2, 1, SA + SL_H2, ws + WS_EA1};
+    m.e[2] = m.e[1];
+    hipLaunchKernelGGL(k_mid, dim3(2 * KT * NQ, 1, L), dim3(256), E_LDS, st, m);
+    return hip_ok(hipGetLastError(), "k_mid (actor E) launch");
+}
+
 static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
                        int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
 {
@@ -1386,7 +1401,8 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     m.e[0] = EJob{d->critic, CIN, 1, 0, SC + SL_H2, SC + SL_EP};
     m.e[1] = EJob{d->actor, SIN, 2, 0, SA + SL_H2, SA + SL_EP};
     m.e[2] = EJob{d->actor, SIN, 2, 1, SA + SL_H2, ws + WS_EA1};
-    hipLaunchKernelGGL(k_mid, dim3(fgx + 3 * KT * NQ, 1, L), dim3(256), MID_LDS, st, m);
+    const bool defer_ea = !fuse && (d->flags & SHEMS_DDPG_DEFER_ACTOR_E) != 0;       // the caller runs shems_ddpg_actor_prepare later
+    hipLaunchKernelGGL(k_mid, dim3(fgx + (defer_ea ? 1 : 3) * KT * NQ, 1, L), dim3(256), MID_LDS, st, m);
     // K3: critic gradient (+ ADAM + soft update)
     GradArgs g;
     std::memset(&g, 0, sizeof g);
@@ -1502,6 +1518,12 @@ int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0
 {
     if (int rc = check_group(g, "shems_ddpg_group_critic_grad")) return rc;
     return critic_side(d0, ring0, ring_len, seed, tick, 0, 0, (unsigned)g->count, g->count > 1 ? g->stride_bytes : 0, nullptr, stream);
+}
+
+int shems_ddpg_actor_prepare(const shems_ddpg *d, void *stream)
+{
+    if (int rc = check_ddpg(d, "shems_ddpg_actor_prepare")) return rc;
+    return actor_e_launch(d, 1, 0, (hipStream_t)stream);
 }
 
 int shems_ddpg_critic_apply(const shems_ddpg *d, double eta, double bp1, double bp2, double grad_scale, void *stream)

@@ -52,7 +52,7 @@ def eps_schedule(current_episode, mem_size=24000, ep_length=72, zeta=EPS_ZETA, x
 class DdpgArgs(C.Structure):           # shems_ddpg
     _fields_ = [(n, C.c_void_p) for n in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic",
                                           "v_critic", "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")] + \
-               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("reserved", C.c_int32)]
+               [("gamma", C.c_float), ("tau", C.c_float), ("batch", C.c_int32), ("flags", C.c_int32)]
 
 
 class RingWindow(C.Structure):         # shems_ring_window
@@ -83,6 +83,8 @@ def _declare():
     L.shems_ddpg_actor_apply_pub.restype = C.c_int
     L.shems_ddpg_critic_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_actor_grad.argtypes = [PD, vp]
+    L.shems_ddpg_actor_prepare.argtypes = [PD, vp]
+    L.shems_ddpg_actor_prepare.restype = C.c_int
     L.shems_ddpg_actor_apply.argtypes = [PD, C.c_double, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_sample_indices.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, i64, vp]
     L.shems_minmax_dev.argtypes = [C.POINTER(_capi.Replay), i64, i64, C.c_uint64, vp, vp, vp]
@@ -198,6 +200,8 @@ class Agent:
         self.bp_critic = [0.9, 0.999]
         self.updates = 0
         self.sync = GradSync(None)                 # replicas exchange gradients through this (RCCL)
+        self.dp_overlap = True                     # data parallel: the critic's gradient all-reduce runs asynchronously under the actor's E
+                                                   # products (shems_ddpg_actor_prepare); False = everything in program order (same bits)
         self.fused = True                          # single replica: replay() = ONE call, shems_ddpg_update (5 launches, ADAM inside the
                                                    # gradient launches); False = the split calls the data-parallel path uses (same bits)
 
@@ -332,7 +336,8 @@ class Agent:
         return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
                         self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
                         self.grad_actor.data_ptr(), self.grad_critic.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
-                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch, 0)
+                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch,
+                        1 if (self.sync.world > 1 and self.dp_overlap) else 0)                # SHEMS_DDPG_DEFER_ACTOR_E
 
     def enable_data_parallel(self, dist):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
@@ -365,7 +370,16 @@ class Agent:
                                                      ex_pos, ex_cnt, st))
         if self.noise_type == "pn":                # DDPG.jl:126-128 (the actor is still the pre-update one here)
             self.adapt_param_noise_(ring, tick)
-        self._allreduce(self.grad_critic)
+        if d.flags & 1:
+            # the all-reduce is enqueued on the collective's own stream behind the gradient kernel; the actor's E products -- which
+            # need nothing the critic update produces -- run on the update stream meanwhile; wait() makes the update stream wait for
+            # the collective (no host synchronisation)
+            work = self.sync.sum_async_(self.grad_critic)
+            _capi.check(self.L.shems_ddpg_actor_prepare(C.byref(d), st))
+            if work is not None:
+                work.wait()
+        else:
+            self._allreduce(self.grad_critic)
         gs = self.sync.grad_scale
         _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
         self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
@@ -498,6 +512,9 @@ class TrainWorkload:
         self.agent = Agent(seed=1231, rng_seed=self.env_seed)   # same initial weights on every rank (config: seed 1231)
         if dist is not None:
             self.agent.enable_data_parallel(dist)
+            import os
+            if os.environ.get("SHEMS_DP_OVERLAP") == "0":        # A/B knob of the rehearsal test: collectives in program order
+                self.agent.dp_overlap = False
         self.ring = ReplayRing(MEM_SIZE)
         self.agent.populate_memory(self.env, self.ring, seed=self.env_seed)          # MAIN:28
         self.agent.min_max_buffer(self.ring, MEM_SIZE, seed=self.env_seed)           # MAIN:30
@@ -594,7 +611,10 @@ class TrainWorkload:
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
 
     def extra(self):
+        import zlib
+        crc = zlib.crc32(self.agent.actor.detach().cpu().numpy().tobytes()) ^ zlib.crc32(self.agent.critic_t.detach().cpu().numpy().tobytes())
         return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "overlap": self.overlap,
+                "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8}
 

@@ -16,7 +16,8 @@ Differences that follow from the platform, all explicit:
   * the job's Julia input file (out/input/$JOB_ID--input.jl) cannot be executed; its decoding rules are restated here for the two
     templates the thesis used last (TUNED = input09_08_on_01-09_eval.jl and input.jl), selected with SHEMS_INPUT_TEMPLATE;
   * the kernels are built for the tuned architecture (L1, L2) = (250, 500) and BATCH_SIZE <= 128: other codes raise;
-  * snapshots are .npz under the reference's stems (checkpoint.py) unless the BSON writer is available;
+  * snapshots are BSON files under the reference's names, laid out as BSON.jl lowers a Chain (bson_chain.py; parity unpinned:
+    the reference ships no real .bson to compare with);
   * noise_mean (a diagnostic of act(), DDPG.jl:148-176) is not accumulated by the fused kernel and is stored as zeros;
   * SHEMS_NUM_ENVS (default 1 = the reference's protocol) trains that many households at once;
   * random streams are Philox counters keyed by the same seeds (Julia's MersenneTwister streams do not exist outside Julia).

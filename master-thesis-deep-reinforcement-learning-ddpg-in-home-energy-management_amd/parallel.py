@@ -43,6 +43,13 @@ class GradSync:
             self.dist.all_reduce(t)
         return t
 
+    def sum_async_(self, t):
+        """Start the sum over replicas and return the work handle (None without replicas); handle.wait() orders the CURRENT
+        stream behind the collective without blocking the host (NCCL/RCCL) -- whatever is enqueued between the two runs under it."""
+        if self.dist:
+            return self.dist.all_reduce(t, async_op=True)
+        return None
+
     def minmax_(self, t_min, t_max):
         if self.dist:
             self.dist.all_reduce(t_min, op=self.dist.ReduceOp.MIN)

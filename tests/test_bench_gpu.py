@@ -72,3 +72,16 @@ def test_bench_starts_its_own_ranks_without_torchrun():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["cpu_baseline"] is None and d["value"] > 0
     assert d["updates_per_sec"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_async_gradient_exchange_gives_the_same_bytes():
+    """Data parallel: the critic's gradient all-reduce issued asynchronously with the actor's E products running under it
+    (shems_ddpg_actor_prepare) against everything in program order: the learner must end up bit-identical (2-rank rehearsal on one
+    device; the collective's timing itself cannot be measured on a one-GPU box)."""
+    out = []
+    for knob in ("1", "0"):
+        d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--envs", "4096"],
+                 env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP_OVERLAP": knob})
+        assert d["n_gpus"] == 2 and d["dp_overlap"] is (knob == "1")
+        out.append(d["learner_crc32"])
+    assert out[0] == out[1]

@@ -54,8 +54,8 @@ def test_entry_script_runs_mains_order_and_writes_the_reference_files(tmp_path):
         os.chdir(cwd0)
     case = cfg.case
     stem = f"DDPG_Shems_Charger_v1_72_2_250_500_{case}_1231"
-    for f in (f"out/bson/{stem}_actor_2.npz", f"out/bson/{stem}_scores_2.npz", f"out/bson/temp/{stem}_actor_1.npz",
-              f"out/bson/temp/{stem}_scores_1.npz", "data/Charger98_all_train_fix.csv", "data/Charger98_all_eval_fix.csv"):
+    for f in (f"out/bson/{stem}_actor_2.bson", f"out/bson/{stem}_scores_2.bson", f"out/bson/temp/{stem}_actor_1.bson",
+              f"out/bson/temp/{stem}_scores_1.bson", "data/Charger98_all_train_fix.csv", "data/Charger98_all_eval_fix.csv"):
         assert (tmp_path / f).exists(), f
     last = tmp_path / f"out/tracker/1179808_eval_results_charger_v1_72_2_250_500_{case}_1231_2.csv"
     best = tmp_path / f"out/tracker/1179808_eval_results_charger_v1_72_2_250_500_{case}_1231_best.csv"
