@@ -81,8 +81,9 @@ constexpr int64_t WS_D3C = WS_API + AIN * BP;         // [1][BP]  dq of the crit
 constexpr int64_t WS_D3Q = WS_D3C + BP;               // [1][BP]  -1/B (actor loss through the critic)
 constexpr int64_t WS_D3A = WS_D3Q + BP;               // [2][BP]  error at the actor's pre-tanh output
 constexpr int64_t WS_IDX = WS_D3A + AIN * BP;         // [BP]     sampled ring slots (int32)
-constexpr int64_t WS_DAP = WS_IDX + BP;               // [NT][2][BP]  per-n-tile partial d loss / d a_pi (K4)
-constexpr int64_t WS_FW3C = WS_DAP + NT * AIN * BP;   // [512]     frozen critic W3 (rows >= 500 zero)
+constexpr int NT16 = 32;           // K4 works on 16-wide n-tiles
+constexpr int64_t WS_DAP = WS_IDX + BP;               // [NT16][2][BP]  per-n-tile partial d loss / d a_pi (K4)
+constexpr int64_t WS_FW3C = WS_DAP + NT16 * AIN * BP; // [512]     frozen critic W3 (rows >= 500 zero)
 constexpr int64_t WS_FW3A = WS_FW3C + 512;            // [512][2]  frozen actor W3
 constexpr int64_t WS_FB3 = WS_FW3A + 1024;            // [8]       frozen b3: critic, critic_target, actor[0], actor[1]
 constexpr int64_t WS_W1T = WS_FB3 + 8;                // [4 nets][12][256] packed layer-1 images (see w1m below)
@@ -643,6 +644,195 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     STAMP(kRegion, 9);
 }
 
+// ---- K4 on 16-wide n-tiles: 32 x 4 = 128 workgroups instead of 64, half the W2 panel and half the MFMA chains per workgroup ----
+// Same scheme as fwd_body<QG> on v_mfma_f32_16x16x4_f32 (lane l: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[i = 4 (l >> 4) + r]
+// [j = l & 15], r < 4).  Workgroup = 16 hidden units x 32 columns; wave w = K quarter w (64 hidden units of layer 1 = 4 blocks of 16),
+// both 16-column halves.  Layer 1's D block (kb, mb) holds pre[64 w + 16 kb + 4 g + r][16 mb + c] in lane (g, c): layer-2 step
+// (kb, r) contracts over the four units {.. + 4 g + r : g} with relu(t) straight from the registers as the B operand and the
+// matching W2 rows as the A operand; the backward product D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m] comes out in the same
+// (kb, mb) block layout, so the relu mask is again the layer-1 registers.  Two independent accumulators (the column halves) cover
+// the 40-cycle dependent latency of this instruction.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int QG16_WST = 20;                                   // W2 panel row stride: 16-B aligned rows, both operand reads conflict-free
+constexpr int QG16_LDS = (256 * QG16_WST + W1K * 32 + W1K * W1C + 256 + 4 * 2 * 4 * 64 + 4 * 64 + 16 * 32 + 4 * 2 * 2 * 64) * 4;
+
+__device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
+{
+    constexpr int WST = QG16_WST;
+    float *Wc = smem;                          // [256][WST]  W2[k][n0 .. n0 + 15] (rows >= 250: copies of row 249, never effective)
+    float *xs = Wc + 256 * WST;                // [12][32]
+    float *w1 = xs + W1K * 32;                 // w1m [12][256]
+    float *ep = w1 + W1K * W1C;                // [16][2]: b2, W3 of this n-tile (+ unused slots: every thread stores)
+    float *xch = ep + 256;                     // [4 quarters][2 mb][4 r][64 lanes]
+    float *pp = xch + 4 * 2 * 4 * 64;          // [4 waves][64 lanes] layer-3 partials
+    float *Mt = pp + 4 * 64;                   // [16 n][32 m]
+    float *red = Mt + 16 * 32;                 // [4 quarters][2 j][2 mb][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int ntile = bx >> 2, n0 = ntile * 16, mbase = 32 * (bx & 3);
+    const float *__restrict__ P = J.P;
+    STAMP(3, 0);
+    // ---- one burst of loads: epilogue constants, input tile, layer-1 image, upstream gradient, then the W2 panel ----
+    const int ep_t = min(tid, 31), ep_nl = ep_t >> 1, ep_c = ep_t & 1, ep_nc = min(n0 + ep_nl, H2N - 1);
+    const float epv = P[ep_c == 0 ? off_b2(CIN) + ep_nc : off_w3(CIN) + ep_nc];
+    const float ep_keep = n0 + ep_nl >= H2N ? 0.0f : 1.0f;
+    XTRegs<CIN> xr;
+    PackRegs pk;
+    xt_load<CIN>(J.x, mbase, xr);
+    pack_w1m_load(P, CIN, pk);
+    const float d3q = J.d3q[mbase + (lane & 31)];              // column 16 mb + c of the finishing lane (see below)
+    const float *__restrict__ W2 = P + off_w2(CIN);
+    f32x4 wv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, k = e >> 2, c4 = e & 3;
+        wv[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c4);
+    }
+    xt_store<CIN>(J.x, xr, mbase, xs, ntile == 0);            // (the four column tiles of n-tile 0 publish actor(s) between them)
+    pack_w1m_store(pk, CIN, w1);
+    ep[tid] = epv * ep_keep;
+    STAMP(3, 1);
+    __syncthreads();
+    STAMP(3, 2);
+    // ---- layer 1: 4 k-blocks x 2 column halves, K = 12 = 3 steps ----
+    f32x4 t[4][2];
+    {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) t[kb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float av[3][4], bv[3][2];
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+            const int j = 4 * sx + g;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) av[sx][kb] = w1[j * W1C + 64 * wave + 16 * kb + c];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bv[sx][mb] = xs[j * 32 + 16 * mb + c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) t[kb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sx][kb], bv[sx][mb], t[kb][mb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, k = e >> 2, c4 = e & 3;
+        *reinterpret_cast<f32x4 *>(Wc + k * WST + 4 * c4) = wv[it];
+    }
+    __syncthreads();
+    STAMP(3, 3);
+    // ---- layer 2 over this wave's K quarter: 16 steps x 2 column halves ----
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    {
+        float aw[16];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aw[kb * 4 + r] = Wc[(64 * wave + 16 * kb + 4 * g + r) * WST + c];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[kb * 4 + r], fmaxf(t[kb][mb][r], 0.0f), acc[mb], 0, 0, 0);
+    }
+    STAMP(3, 4);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[((wave * 2 + mb) * 4 + r) * 64 + lane] = acc[mb][r];
+    __syncthreads();
+    STAMP(3, 5);
+    // this wave finishes column half mb = wave >> 1, rows r in {2 (wave & 1), 2 (wave & 1) + 1} of every lane: hidden unit n0 + 4 g + r
+    {
+        const int mb = wave >> 1, r0 = 2 * (wave & 1);
+        float xv[4][2], eb[2], ew[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) xv[q][rr] = xch[((q * 2 + mb) * 4 + r0 + rr) * 64 + lane];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) { const int nl = 4 * g + r0 + rr; eb[rr] = ep[nl * 2]; ew[rr] = ep[nl * 2 + 1]; }
+        const float dq = __shfl(d3q, 16 * mb + c, 64);          // upstream gradient of column 16 mb + c (lanes 0..31 hold columns 0..31)
+        float p0 = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int nl = 4 * g + r0 + rr, n = n0 + nl;
+            const float sum = ((xv[0][rr] + xv[1][rr]) + xv[2][rr]) + xv[3][rr];
+            const float h = n < H2N ? fmaxf(sum + eb[rr], 0.0f) : 0.0f;
+            p0 = fmaf(h, ew[rr], p0);
+            Mt[nl * 32 + 16 * mb + c] = h > 0.0f ? ew[rr] * dq : 0.0f;
+        }
+        pp[wave * 64 + lane] = p0;
+    }
+    __syncthreads();
+    STAMP(3, 6);
+    if (tid < 32) {                                            // layer-3 partial (q, for the loss report): 2 waves x 4 lane groups per column, fixed order
+        const int mb = tid >> 4, cc = tid & 15;
+        float sres = 0.0f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < 2; ++wv_)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) sres += pp[(2 * mb + wv_) * 64 + 16 * gg + cc];
+        J.P3[ntile * BP + mbase + tid] = sres;
+    }
+    // ---- backward through this n-tile: rows k of the wave's quarter (4 blocks) x 2 column halves, K = 16 = 4 steps ----
+    {
+        float bm[4][2];
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) bm[sx][mb] = Mt[(4 * sx + g) * 32 + 16 * mb + c];
+        float da[2][2] = {{0.f, 0.f}, {0.f, 0.f}};             // [j][mb]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float ak[4], wa0[4], wa1[4];
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) ak[sx] = Wc[(64 * wave + 16 * kb + c) * WST + 4 * sx + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 64 * wave + 16 * kb + 4 * g + r;
+                wa0[r] = w1[9 * W1C + k]; wa1[r] = w1[10 * W1C + k];               // W1[9 + j][k]: the action rows (columns >= 250 zero)
+            }
+            f32x4 gk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) gk[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[sx], bm[sx][mb], gk[mb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = t[kb][mb][r] > 0.0f ? gk[mb][r] : 0.0f;         // layer-1 relu mask (pre-activations still in registers)
+                    da[0][mb] = fmaf(wa0[r], v, da[0][mb]);
+                    da[1][mb] = fmaf(wa1[r], v, da[1][mb]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) red[((wave * 2 + j) * 2 + mb) * 64 + lane] = da[j][mb];
+    }
+    STAMP(3, 8);
+    __syncthreads();
+    if (tid < 64) {                                            // (j, column): the four quarters, each the sum of its four lane groups, fixed order
+        const int j = tid >> 5, mm = tid & 31, mb = mm >> 4, cc = mm & 15;
+        float sres = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float *rq = red + ((q * 2 + j) * 2 + mb) * 64 + cc;
+            sres += ((rq[0] + rq[16]) + rq[32]) + rq[48];
+        }
+        J.DAP[(ntile * 2 + j) * BP + mbase + mm] = sres;
+    }
+    STAMP(3, 9);
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -656,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (J.in == SIN) fwd_body<SIN, 1, false>(J, smem, &pa, bx, job); else fwd_body<CIN, 1, false>(J, smem, &pa, bx, job);
         return;
     }
-    fwd_body<CIN, 2, true>(J, smem, nullptr, bx, 0);      // K4: the updated critic on [s; actor(s)], forward + input gradient
+    qg16_body(J, smem, bx);                        // K4: the updated critic on [s; actor(s)], forward + input gradient
 }
 
 // ---- K2: critic_target forward | the three E products ---------------------------------------------------------------------
@@ -832,6 +1022,32 @@ __device__ __forceinline__ void adam_batch(const AdamCtx &c, const int (&idx)[N]
         }
     }
 }
+// The same in two halves, so that a gradient tile can request its moments / parameters / targets with its first burst of loads,
+// long before the gradient exists (the elements are its own: nobody else touches them), and only computes + stores at the end.
+template <int N> struct AdamRegs { float m[N], v[N], p[N], t[N]; };
+template <int N>
+__device__ __forceinline__ void adam_load(const AdamCtx &c, const int (&idx)[N], AdamRegs<N> &R)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int e = max(idx[i], 0);
+        R.m[i] = c.mt[e]; R.v[i] = c.vt[e]; R.p[i] = c.p[e]; R.t[i] = c.target[e];
+    }
+}
+template <int N>
+__device__ __forceinline__ void adam_apply(const AdamCtx &c, const int (&idx)[N], const float (&g)[N], AdamRegs<N> &R)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) adam_math(c, g[i], R.m[i], R.v[i], R.p[i], R.t[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (idx[i] >= 0) {
+            const int e = idx[i];
+            c.mt[e] = R.m[i]; c.vt[e] = R.v[i]; c.p[e] = R.p[i]; c.target[e] = R.t[i];
+            if (c.publish) c.publish[e] = R.p[i];
+        }
+    }
+}
 // Four consecutive elements per thread (16-byte accesses: a quarter of the workgroups, the same bits).  i0 is a multiple of 4.
 __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
 {
@@ -864,7 +1080,8 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
 // The global operands of the two heads, fetched with the rest of a workgroup's first batch of loads (all threads load;
 // the critic head uses the values of threads < BP only).  b3 of both critics comes from the copy K1 froze: the owner of that
 // element updates it (and the target's) in place during this launch.
-struct HeadRegs { float v[2 * NT]; float s[4]; };       // s = {a, b, c, e} scalars of the heads
+struct HeadRegs { float v[2 * NT]; float s[4]; };
+static_assert(2 * NT >= NT16, "HeadRegs.v holds the actor head's NT16 partials");       // s = {a, b, c, e} scalars of the heads
 __device__ __forceinline__ void head_loss_load(const shems_ddpg &d, HeadRegs &R)
 {
     const float *ws = d.ws;
@@ -882,7 +1099,7 @@ __device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R
     const float *ws = d.ws;
     const int t = threadIdx.x, o = t >> 7, m = t & 127;
 #pragma unroll
-    for (int p = 0; p < NT; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
+    for (int p = 0; p < NT16; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
     R.s[0] = ws[WS_API + t];
     R.s[1] = R.s[2] = R.s[3] = 0.0f;
 }
@@ -926,7 +1143,7 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
     const float a = R.s[0];
     float da = 0.0f;
 #pragma unroll
-    for (int p = 0; p < NT; ++p) da += R.v[p];
+    for (int p = 0; p < NT16; ++p) da += R.v[p];
     const float g = da * (1.0f - a * a);                       // through tanh
     d3[t] = g;
     if (publisher) {
@@ -936,7 +1153,7 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
             const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
             q = d.critic[off_b3(CIN, 1)];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) q += Pq[(i * 2) * BP + m];
+            for (int i = 0; i < NT16; ++i) q += Pq[i * BP + m];                  // K4's 32 tiles of 16 hidden units
         }
         const float sg = wave_sum(g), sq = wave_sum(q);
         if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
@@ -1088,9 +1305,17 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     // The H2 panel does not depend on the error signal: its loads go out before the head is evaluated, so the two global latencies
     // overlap instead of following each other.
     float hv[16];
+    int widx[4] = {-1, -1, -1, -1};             // W: the four elements of gW2 this lane finishes and owns (rows 4 wave .. 4 wave + 3 of the tile)
+    AdamRegs<4> ar;
     if (is_w) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) hv[u] = A.H2[min(nt * 32 + 2 * u + half, H2N - 1) * BP + mcol];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 32 + r + 8 * wave + 4 * lh, n = nt * 32 + li;
+            widx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
+        }
+        adam_load<4>(A.c, widx, ar);            // moments, parameter, target: requested with the first burst, consumed after the tile
     }
     XRegs<IN> xr;
     f32x4 wq = {0.f, 0.f, 0.f, 0.f};
@@ -1169,17 +1394,15 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xv[sw][r] = xch[((wave * 4 + sw) * 4 + r) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
-            int idx[4];
             float val[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = kt * 32 + r + 8 * wave + 4 * lh;                               // row (4 wave + r) of the tile
                 val[r] = ((xv[0][r] + xv[1][r]) + xv[2][r]) + xv[3][r];
-                idx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
-                if (idx[r] >= 0) gW2[k * H2N + n] = val[r];
+                if (widx[r] >= 0) gW2[k * H2N + n] = val[r];
             }
             STAMP(kRegion, 6);
-            if (fz) adam_batch<4>(*fz, idx, val);
+            if (fz) adam_apply<4>(*fz, widx, val, ar);
             STAMP(kRegion, 7);
         }
     } else {
@@ -1297,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_action_distance(const float *__restrict
     if (threadIdx.x == 0) out[0] = sqrtf(((part[0] + part[1]) + (part[2] + part[3])) / (float)count);
 }
 
-constexpr int FWD_LDS = FwdShape<false>::LDS, QG_LDS = FwdShape<true>::LDS;
+constexpr int FWD_LDS = FwdShape<false>::LDS, QG_LDS = FWD_LDS > QG16_LDS ? FWD_LDS : QG16_LDS;
 constexpr int MID_LDS = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
 static_assert(QG_LDS <= 160 * 1024, "one workgroup's LDS");
 
@@ -1426,10 +1649,10 @@ static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamSca
     FwdArgs f;
     std::memset(&f, 0, sizeof f);
     f.gstride = gs;
-    const unsigned fgx = NT * (BP / 32);
+    const unsigned fgx = NT16 * (BP / 32);
     f.prep = 2;
     f.job[0] = FwdJob{nullptr, d->critic, CIN, 1, 0, x_spi, nullptr, C2 + SL_P3, ws + WS_D3Q, ws + WS_DAP};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG_LDS, st, f);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG16_LDS, st, f);
     GradArgs g;
     std::memset(&g, 0, sizeof g);
     g.w1t = w1t_of(ws, SLOT_ACTOR); g.P = d->actor; g.in = SIN; g.out = 2; g.x = x_s; g.H2 = SA + SL_H2; g.w3f = ws + WS_FW3A;
