@@ -92,7 +92,7 @@ template <int TM, int NW>
 constexpr size_t act_lds_bytes()
 {
     return sizeof(float) * (2 * kWcFloats + 2 * 32 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
-                            NW * 32 * TM * kOut);
+                            NW * 32 * TM * kOut + 32 * TM * kIn);
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -139,7 +139,9 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
 
 // One env after layer 3: p0, p1 = the pre-activation outputs (b3 included).  tanh, exploration noise, clamp, scale_action, step!,
 // remember (DDPG.jl:148-184, 199-229).  Returns the env's reward (0 when nothing was stepped).
-__device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, float p0, float p1, int64_t learner, int64_t goff)
+// obs_lds: the env's 9 raw observations in LDS (the caller staged them), or null = read them from the view.
+__device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, float p0, float p1, int64_t learner, int64_t goff,
+                                               const float *obs_lds)
 {
     double reward = 0.0;
     {
@@ -177,7 +179,7 @@ __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, floa
             const shems_config c = load_cfg(v, i);
             float obs[SHEMS_NSTATE], pre[SHEMS_NSTATE];
 #pragma unroll
-            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = v.obs[i * SHEMS_NSTATE + k]; pre[k] = obs[k]; }
+            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = obs_lds ? obs_lds[k] : v.obs[i * SHEMS_NSTATE + k]; pre[k] = obs[k]; }
             int32_t idx = v.idx[i], step = v.step[i];
             StepFlows f;
             float B, EV, Bt, EVt;
@@ -265,6 +267,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
     float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
+    float *xR = red + NW * BM * kOut;                        // [BM][9]   the raw observations stage 0 loaded: step! starts from these, not from a
+                                                             //           second (stride-36-byte) read of global memory at the end of the kernel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: LDS-DMA bases (M0) stay on the SALU
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     for (int it = 0; it < kIt; ++it) {
         const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
         const float x = (sv[it] - lo[it]) / ((hi[it] - lo[it]) + 1e-8f);      // MPS:56
-        if (e < BM * kIn) xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f;
+        if (e < BM * kIn) { xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f; xR[e] = sv[it]; }
     }
     for (int e = tid; e < BM; e += NT_) xT[kIn * BM + e] = 1.0f;                               // row 9 = 1: the bias input
     if (tid < kW1C) {
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
         for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
-        reward = act_env_tail(A, i, p0, p1, learner, goff);
+        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr);
     }
     PSTAMP(12);
 #ifndef ABL_STAMP
