@@ -57,7 +57,7 @@ def _rel(a, b):
 # Per-block gradient bound: every Flux.params block (W1, b1, W2, b2, W3, b3) of a gradient is held, on its own, to the float64
 # evaluation of the same formulas, normalised by THAT block's max-abs (a concatenated vector normalised by its global max lets a
 # percent-level error in a small-magnitude block through).  fp32 accumulation over K <= 500, B <= 128 in a different order than
-# BLAS gives ~1e-7 of the block max; measured on MI355X (profiles/r02_gradient_block_errors.txt): worst HIP block 2.8e-7 (actor W2),
+# BLAS gives ~1e-7 of the block max; measured on MI355X (profiles/r02_gradient_block_errors.txt): worst HIP block 1.8e-7 (actor W2),
 # worst block of the f32 NumPy oracle 5.1e-7 (critic W2) -> bound = 4 x the worst measured = 2e-6.
 BLOCK_TOL = 2e-6
 
