@@ -94,3 +94,33 @@ def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
         fh.write("electkwh,PV_generation\n1,2\n")
     with pytest.raises(KeyError):
         T.load_csv(tmp_path / "bad.csv")
+
+
+def test_julia_module_binds_only_declared_entry_points(built_lib):
+    """julia/ShemsEnv_LU1.jl cannot be executed here (no Julia); what CAN be checked statically: every `ccall((:symbol, LIB), ...)` names
+    an entry point that include/shems_hip.h declares and libshems_hip.so exports, with the argument count of the declaration; the
+    struct mirror has the 48-byte layout; the methods the reference's callers use are all defined."""
+    import re
+    S = U.pkg()
+    src = open(os.path.join(U.ROOT, "julia", "ShemsEnv_LU1.jl")).read()
+    hdr = open(os.path.join(U.ROOT, "include", "shems_hip.h")).read()
+    L = S._capi.lib()
+    calls = re.findall(r"ccall\(\(:(\w+), LIB\), (\w+), \(([^)]*)\)", src)
+    assert len(calls) >= 10
+    for name, ret, args in calls:
+        assert hasattr(L, name), name
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
+        assert m, f"{name} is not declared in include/shems_hip.h"
+        n_decl = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
+        n_call = 0 if not args.strip() else len([a for a in args.split(",") if a.strip()])
+        assert n_decl == n_call, (name, n_decl, n_call)
+    for needed in ("struct ShemsConfig", "mutable struct ShemsAction", "Base.minimum(::ShemsAction) = (0f0, 0f0)", "Base.maximum(::ShemsAction) = (1f0, 1f0)",
+                   "function reset!(env::Shems; rng=0)", "function step!(env::Shems, s, a; track=0)", "function action(env::Shems, a::ShemsAction)",
+                   "function action(env::Shems, track::Real=-1)", "finished(env::Shems, s′) = false", "using Distributions: Uniform", "using Random",
+                   "module ShemsEnv_LU1"):
+        assert needed in src, needed
+    # ShemsConfig mirror: Float32 x2, Float64 x3, Float32, Int32 x3 = 48 bytes in declaration order (the C struct of the header)
+    fields = re.search(r"struct ShemsConfig(.*?)\nend", src, re.S).group(1)
+    types = re.findall(r"::(\w+)", fields)
+    assert types == ["Float32", "Float32", "Float64", "Float64", "Float64", "Float32", "Int32", "Int32", "Int32"]
+    assert C.sizeof(S._capi.Config) == 48
