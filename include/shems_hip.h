@@ -198,6 +198,8 @@ typedef struct shems_act_params {
     float    ou_dt;          /* OUNoise dt (1f-2)                                                   */
     float    eps;            /* EpsNoise: current xi = max(0.5 - zeta*(episode - MEM/EP), xi_min), DDPG.jl:69-72 */
     float   *ou_state;       /* dev [n][2]: OUNoise.X per env (persistent, DDPG.jl:49-55); required for SHEMS_NOISE_OU */
+    float   *noise_acc;      /* dev [n] or NULL: += act()'s second return value for this step (DDPG.jl:148-176): mean(noise) of the
+                              * two action noise samples (gn, ou), mean(|act_pred - act_uni|) when an epsilon step explores, else 0 */
 } shems_act_params;
 /* act()'s exploration branches (DDPG.jl:148-176).  GAUSS: clamp(a + N(mu, sigma)); OU: X += theta(mu - X)dt +
  * sigma sqrt(dt) N(0,1), clamp(a + X); EPS: with probability eps a uniform action in [-1,1]^2, else the

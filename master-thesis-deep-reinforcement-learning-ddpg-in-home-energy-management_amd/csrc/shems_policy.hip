@@ -147,13 +147,14 @@ __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, floa
     {
         p0 = tanhf(p0);
         p1 = tanhf(p1);
-        float a0, a1;
+        float a0, a1, nmean = 0.0f;                                    // nmean: act()'s second return value
         if (A.p.train && A.p.noise_kind == SHEMS_NOISE_EPS) {          // DDPG.jl:161-170
             const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.p.tick, kStreamNoise, (uint32_t)A.p.seed,
                                           (uint32_t)(A.p.seed >> 32));
             const bool explore = !(u01_24(x.z) > A.p.eps);             // rng > eps: greedy; rng <= eps: uniform action
             a0 = explore ? (float)((double)x.x * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
             a1 = explore ? (float)((double)x.y * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
+            nmean = explore ? 0.5f * (fabsf(p0 - a0) + fabsf(p1 - a1)) : 0.0f;          // mean(abs.(act_pred .- act_uni)) / 0f0
         } else {
             if (A.p.train) {
                 const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
@@ -165,15 +166,19 @@ __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, floa
                     reinterpret_cast<float2 *>(A.p.ou_state)[i] = X;
                     p0 += X.x;
                     p1 += X.y;
+                    nmean = 0.5f * (X.x + X.y);
                 } else {                                               // DDPG.jl:57-61, 159-160: Normal(mu, sigma_act)
-                    p0 += A.p.noise_mu + A.p.noise_sigma * z.x;
-                    p1 += A.p.noise_mu + A.p.noise_sigma * z.y;
+                    const float n0 = A.p.noise_mu + A.p.noise_sigma * z.x, n1 = A.p.noise_mu + A.p.noise_sigma * z.y;
+                    p0 += n0;
+                    p1 += n1;
+                    nmean = 0.5f * (n0 + n1);
                 }
             }
             a0 = fminf(fmaxf(p0, -1.0f), 1.0f);                        // clamp.(act_pred .+ noise, -1f0, 1f0)
             a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
         }
         if (A.a_out) reinterpret_cast<float2 *>(A.a_out)[i] = make_float2(a0, a1);
+        if (A.p.noise_acc) A.p.noise_acc[i] += nmean;
         if (A.do_step) {
             const shems_view &v = A.v;
             const shems_config c = load_cfg(v, i);

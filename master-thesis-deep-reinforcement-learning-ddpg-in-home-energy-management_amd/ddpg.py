@@ -34,7 +34,7 @@ class ActParams(C.Structure):          # shems_act_params
     _fields_ = [("actor", C.c_void_p), ("s_min", C.c_void_p), ("s_max", C.c_void_p),
                 ("noise_mu", C.c_float), ("noise_sigma", C.c_float), ("train", C.c_int32),
                 ("tick", C.c_uint32), ("seed", C.c_uint64), ("noise_kind", C.c_int32), ("ou_theta", C.c_float),
-                ("ou_dt", C.c_float), ("eps", C.c_float), ("ou_state", C.c_void_p)]
+                ("ou_dt", C.c_float), ("eps", C.c_float), ("ou_state", C.c_void_p), ("noise_acc", C.c_void_p)]
 
 
 NOISE_KINDS = {"gn": 0, "ou": 1, "en": 2, "pn": 0}   # noise_type strings of the reference (DDPG.jl:152-161); "pn" runs the perturbed actor with train = 0
@@ -249,11 +249,12 @@ class Agent:
         self.s_min.copy_(t.as_tensor(np.asarray(s_min, f32)))
         self.s_max.copy_(t.as_tensor(np.asarray(s_max, f32)))
 
-    def _act_params(self, train, tick, actor=None):
+    def _act_params(self, train, tick, actor=None, noise_acc=None):
         a = self.actor if actor is None else actor
         return ActParams(a.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(), self.mu, self.sigma,
                          1 if train else 0, int(tick) & 0xFFFFFFFF, self.rng_seed, NOISE_KINDS[self.noise_type], self.theta,
-                         self.dt, self.eps, self.ou_state.data_ptr() if self.ou_state is not None else None)
+                         self.dt, self.eps, self.ou_state.data_ptr() if self.ou_state is not None else None,
+                         noise_acc.data_ptr() if noise_acc is not None else None)
 
     def _ensure_ou(self, n):
         if self.noise_type == "ou" and (self.ou_state is None or self.ou_state.shape[0] != n):
@@ -316,7 +317,7 @@ class Agent:
         return out
 
     def act_step(self, env, train=True, tick=None, a_out=None, rewards=None, rewards_f32=None, block_reward=None,
-                 returns_acc=None, ring=None, window=None):
+                 returns_acc=None, ring=None, window=None, noise_acc=None):
         """One fused vector step: s = env.state; a = act(s); step!(env, s, scale_action(a)); remember(...)."""
         self._same_device(env, ring)
         env.use_torch_stream()
@@ -324,7 +325,7 @@ class Agent:
         self._ensure_ou(env.n)
         tick = self.tick if tick is None else tick
         train, actor = self._explore(train, tick)
-        p = self._act_params(train, tick, actor)
+        p = self._act_params(train, tick, actor, noise_acc=noise_acc)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         rs = ring.struct() if ring is not None else None
         _capi.check(self.L.shems_act_step_dev(C.byref(v), C.byref(p), ptr(a_out), ptr(rewards), ptr(rewards_f32),
@@ -443,6 +444,7 @@ class Agent:
         else:
             env.reset_(rng_ep, episode=episode)
         returns = t.zeros(env.n, dtype=t.float64, device=self.device)
+        self.last_noise = t.zeros(env.n, dtype=t.float32, device=self.device) if train else None     # noise_eps of episode! (DDPG.jl:224)
         if train and ring is None:
             raise ValueError("training episodes need a replay ring")
         if window_count is None and ring is not None:
@@ -452,7 +454,10 @@ class Agent:
             win = None
             if train:
                 win = RingWindow(ring.pos, window_count, (self.tick * window_count) % env.n)
-            self.act_step(env, train=train, tick=tick, returns_acc=returns, ring=ring if train else None, window=win)
+            self.act_step(env, train=train, tick=tick, returns_acc=returns, ring=ring if train else None, window=win,
+                          noise_acc=self.last_noise)
+            if train and self.noise_type == "pn":
+                self.last_noise += float(self.pn_sigma)                           # act() returns pn.sigma_current as the "noise" (DDPG.jl:155)
             if train:
                 ring.pushed += window_count
                 for _ in range(updates_per_step):
@@ -467,11 +472,13 @@ class Agent:
         (total_reward [num_ep], score_mean [ceil(num_ep/test_every)], best_run, best_actor)."""
         seed = self.seed if seed is None else int(seed)
         total_reward = np.zeros(num_ep, np.float32)
+        self.noise_mean = np.zeros(num_ep, np.float32)                              # noise_mean[i] (DDPG.jl:255), mean over the batch's envs
         score_mean = np.zeros(-(-num_ep // test_every), np.float64)
         best_score, best_run, best_actor = -100000.0, 0, None
         for i in range(1, num_ep + 1):
             ret = self.episode_(env_train, ring, train=True, rng_ep=seed, episode=i, updates_per_step=updates_per_step)
             total_reward[i - 1] = self.sync.mean_scalar(ret.mean().item(), env_train.n)
+            self.noise_mean[i - 1] = self.sync.mean_scalar(self.last_noise.mean().item(), env_train.n)
             if i % test_every == 1:
                 idx = -(-i // test_every)
                 # DDPG.jl:273-277: every evaluation sweep runs the SAME test_runs seeds "123" * test_ep, so best-score

@@ -18,7 +18,6 @@ Differences that follow from the platform, all explicit:
   * the kernels are built for the tuned architecture (L1, L2) = (250, 500) and BATCH_SIZE <= 128: other codes raise;
   * snapshots are BSON files under the reference's names, laid out as BSON.jl lowers a Chain (bson_chain.py; parity unpinned:
     the reference ships no real .bson to compare with);
-  * noise_mean (a diagnostic of act(), DDPG.jl:148-176) is not accumulated by the fused kernel and is stored as zeros;
   * SHEMS_NUM_ENVS (default 1 = the reference's protocol) trains that many households at once;
   * random streams are Philox counters keyed by the same seeds (Julia's MersenneTwister streams do not exist outside Julia).
 """
@@ -238,10 +237,11 @@ def main(environ=os.environ, cwd=".", log=print):
         log(f", Training run: {cfg.rng_run}")
 
         def on_best(i, actor, total_reward, score_mean):                 # saveBSON(...; idx=i, path="temp", rng=rng_run), DDPG.jl:282-286
-            checkpoint.save(actor, total_reward, score_mean, i, noise_mean, idx=i, rng=cfg.rng_run, path="temp", **ck)
+            checkpoint.save(actor, total_reward, score_mean, i, agent.noise_mean, idx=i, rng=cfg.rng_run, path="temp", **ck)
 
         total_reward, score_mean, best_eval, _ = agent.run_episodes(env_train, env_eval, ring, cfg.NUM_EP, test_every=cfg.test_every,
                                                                     test_runs=cfg.test_runs, seed=cfg.rng_run, on_best=on_best)
+        noise_mean = agent.noise_mean
         checkpoint.save(agent.actor, total_reward, score_mean, best_eval, noise_mean, idx=cfg.NUM_EP, rng=cfg.rng_run, **ck)   # MAIN:45-46
         log(f"trained {cfg.NUM_EP} episodes in {time.time() - t0:.1f} s; best evaluation at episode {best_eval}")
 

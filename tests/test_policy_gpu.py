@@ -151,3 +151,30 @@ def test_ou_and_epsilon_noise_branches():
     assert np.abs(out - ref).max() < ATOL
     frac = (np.abs(out - clean).max(1) > 1e-4).mean()
     assert 0.25 < frac < 0.35
+
+
+def test_noise_mean_accumulator_is_acts_second_return_value():
+    """act() returns (action, mean(noise)) and episode! sums the second value into noise_eps / noise_mean[i] (DDPG.jl:172-175, 224, 255).
+    shems_act_params.noise_acc receives that value per env: for Gaussian noise 0.5 * (n0 + n1) -- recovered here from the unclamped
+    actions (tanh of a freshly initialised actor is ~0: nothing clamps) -- and exactly 0 in evaluation mode."""
+    torch, S, D = _mods()
+    tab = U.tables_mod().synthetic_table("train", 98)
+    n = 3000
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    env.reset_(5, episode=1)
+    ag = D.Agent(seed=21)
+    st = env.state
+    ag.set_norm(st.min(0), st.max(0))
+    dev = torch.from_numpy(st).cuda()
+    clean = ag.act(dev, train=False).cpu().numpy()
+    acc = torch.zeros(n, dtype=torch.float32, device="cuda")
+    a_out = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    ag.act_step(env, train=True, tick=4, a_out=a_out, noise_acc=acc)
+    noisy = a_out.cpu().numpy()
+    assert np.abs(noisy).max() < 1.0                                       # nothing clamped
+    want = 0.5 * ((noisy[:, 0] - clean[:, 0]) + (noisy[:, 1] - clean[:, 1]))
+    got = acc.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-6 and 0.05 < got.std() < 0.09      # sigma_act / sqrt(2) = 0.0707
+    ag.act_step(env, train=False, tick=5, a_out=a_out, noise_acc=acc)      # evaluation: adds 0
+    assert (acc.cpu().numpy() == got).all()
+    env.close()
