@@ -1170,8 +1170,8 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
 
 // ---- K3 / K5: every gradient block of one network, by batch contractions only -------------------------------------------
 // D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (h2[n][m] > 0) is generated while staging, never stored.
-//   W workgroups (kt, nt): gW2[32 k][32 n] = sum_m h1[k][m] D2[n][m], one batch quarter per wave (16 MFMA pairs), the four
-//                 partial tiles added in the fixed order ((q0 + q1) + q2) + q3, each wave finishing (and owning) four rows;
+//   W workgroups (kt, nt): gW2[32 k][32 n] = sum_m h1[k][m] D2[n][m], one 16 x 16 block per wave over the whole batch
+//                 (v_mfma_f32_16x16x4_f32), owned by that wave for ADAM;
 //   G workgroups: gb2[n] = sum_m D2[n][m], gW3[n][o] = sum_m h2[n][m] d3[o][m], 32 rows each;
 //   R workgroups: one wave per hidden unit k: D1[k][m] = mask1 * sum_j d3[j][m] * (sum_q Epart_j[q][k][m]); gb1[k] = sum_m D1;
 //                 gW1[j][k] = sum_m x[j][m] D1[k][m].
@@ -1198,8 +1198,9 @@ __device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
 }
 enum { GR_NW = KT * NT, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };   // G: 32 rows of gb2 / gW3 each, 8 per wave
 
-constexpr int GR_BT = BP * 33;                               // W: [128 m][33] D2^T panel (doubles as the [4][4][4][64] exchange block)
-constexpr int GR_AT = BP * 33;                               // W: [128 m][33] h1^T panel
+constexpr int GR_PS = BP + 4;                                // W: row stride of the two operand panels (b128 reads of 16 rows: conflict free)
+constexpr int GR_BT = 32 * GR_PS;                            // W: [32 n][132] D2 panel
+constexpr int GR_AT = 32 * GR_PS;                            // W: [32 k][132] h1 panel
 constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3) * 4;
 
 // D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
@@ -1257,8 +1258,8 @@ __device__ __forceinline__ void l1row_wave(const L1Row<IN, OUT> &R, const float 
 template <int IN, int OUT>
 __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
 {
-    float *Bt = smem;                          // W: [128 m][65] D2^T panel
-    float *At = Bt + GR_BT;                    // W: [128 m][33] h1^T panel
+    float *Bt = smem;                          // W: [32 n][GR_PS] D2 panel
+    float *At = Bt + GR_BT;                    // W: [32 k][GR_PS] h1 panel
     float *xs = At + GR_AT;                    // [12][BP]
     float *w1 = xs + W1K * BP;                 // W: w1m columns of the k-tile, [12][32]
     float *d3 = w1 + W1K * 32;                 // [2][BP]
@@ -1311,8 +1312,8 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
 #pragma unroll
         for (int u = 0; u < 16; ++u) hv[u] = A.H2[min(nt * 32 + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = kt * 32 + r + 8 * wave + 4 * lh, n = nt * 32 + li;
+        for (int r = 0; r < 4; ++r) {            // wave w finishes the 16 x 16 block (k half w >> 1, n half w & 1): D[i = 4 g + r][j = c]
+            const int k = kt * 32 + 16 * (wave >> 1) + 4 * (lane >> 4) + r, n = nt * 32 + 16 * (wave & 1) + (lane & 15);
             widx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
         }
         adam_load<4>(A.c, widx, ar);            // moments, parameter, target: requested with the first burst, consumed after the tile
@@ -1344,62 +1345,56 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     const float d3a = d3[mcol], d3b = d3[BP + mcol];
 
     if (is_w) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const int nbase = nt * 32;
-        // h1^T panel At[m][kl] (row stride 33): this wave's 32 columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
+        // h1 panel At[kl][m] (row stride GR_PS): this wave's 32 batch columns of the k-tile, layer 1 on the matrix pipe.  Its MFMA chain is
         // issued first so that it runs under the VALU work of the D2 panel below.
         const f32x16 t = l1_tile<32>(w1, xs, 0, wave * 32, li, lh);
-        // D2^T panel Bt[m][nl] (row stride 33), nl = 2*u + half: 16 rows per thread from the loads issued above (W3 comes from LDS;
+        // D2 panel Bt[nl][m] (row stride GR_PS), nl = 2*u + half: 16 rows per thread from the loads issued above (W3 comes from LDS;
         // rows >= 500 meet the zero rows of its image)
         {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int nl = 2 * u + half;
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * nl);
-                Bt[mcol * 33 + nl] = d2_val(hv[u], w.x, w.y, d3a, d3b);
+                Bt[nl * GR_PS + mcol] = d2_val(hv[u], w.x, w.y, d3a, d3b);
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) At[(wave * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = fmaxf(t[r], 0.0f);
+        for (int r = 0; r < 16; ++r) At[((r & 3) + 8 * (r >> 2) + 4 * lh) * GR_PS + wave * 32 + li] = fmaxf(t[r], 0.0f);
         STAMP(kRegion, 3);
         __syncthreads();
         STAMP(kRegion, 4);
-        // wave w: the whole 32 x 32 tile over the batch quarter [32 w, +32): 16 MFMA pairs, all operands fetched up front
+        // wave w: the 16 x 16 block (k half w >> 1, n half w & 1) of the tile over the WHOLE batch: 32 steps of v_mfma_f32_16x16x4_f32.
+        // The contraction index may be visited in any order as long as both operands agree: lane (g, c) takes the batch columns
+        // 16 q + 4 g + e (q < 8, e < 4) -- one b128 read per operand and q -- and step (q, e) contracts {16 q + 4 g' + e : g' < 4}.
+        // Four accumulators (one per e), added at the end.  Nothing is exchanged between waves: each owns its 256 elements
+        // (D[i = 4 g + r][j = c], 4 per lane) for ADAM.
+        f32x4 blk;
         {
-            const float *pa = At + (32 * wave) * 33 + li, *pb = Bt + (32 * wave) * 33 + li;
-            float ac[16], bc[16];
+            const int g = lane >> 4, c = lane & 15;
+            const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g, *pb = Bt + (16 * (wave & 1) + c) * GR_PS + 4 * g;
+            f32x4 av[8], bv[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { ac[u] = pa[(2 * u + lh) * 33]; bc[u] = pb[(2 * u + lh) * 33]; }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 8; ++q) {
+                av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
+                bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
+            }
+            f32x4 acc[4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u], bc[u], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
+            blk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         STAMP(kRegion, 5);
-        __syncthreads();                            // everybody is done with the panels: Bt doubles as the exchange buffer
-        // Exchange [owner wave = r >> 2][source wave][r & 3][lane]: every wave hands each row group to the wave that finishes it
-        // (its own group included, so that nothing is indexed dynamically) and then adds the four batch quarters of ITS four rows
-        // in the fixed order ((q0 + q1) + q2) + q3; it owns those elements for ADAM.
-        float *xch = Bt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(((r >> 2) * 4 + wave) * 4 + (r & 3)) * 64 + lane] = acc[r];
-        __syncthreads();
         {
             float *gW2 = A.grad + off_w2(IN);
-            const int n = nbase + li;
-            float xv[4][4];
-#pragma unroll
-            for (int sw = 0; sw < 4; ++sw)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xv[sw][r] = xch[((wave * 4 + sw) * 4 + r) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
             float val[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = kt * 32 + r + 8 * wave + 4 * lh;                               // row (4 wave + r) of the tile
-                val[r] = ((xv[0][r] + xv[1][r]) + xv[2][r]) + xv[3][r];
-                if (widx[r] >= 0) gW2[k * H2N + n] = val[r];
+                val[r] = blk[r];
+                if (widx[r] >= 0) gW2[widx[r] - off_w2(IN)] = val[r];
             }
             STAMP(kRegion, 6);
             if (fz) adam_apply<4>(*fz, widx, val, ar);
