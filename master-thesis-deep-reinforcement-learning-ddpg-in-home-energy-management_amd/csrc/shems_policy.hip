@@ -41,6 +41,7 @@
 namespace shems {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
 template <> struct FVec<1> { typedef float type; };
 template <int N> __device__ __forceinline__ float fvec_get(const typename FVec<N>::type &v, int i) { return v[i]; }
@@ -88,11 +89,16 @@ __device__ __forceinline__ T *gsh(T *p, int64_t off)
     return p ? reinterpret_cast<T *>(reinterpret_cast<B *>(p) + off) : p;
 }
 
-template <int TM, int NW>
+// RD = 0: the workgroup streams W2 as whole 16-row chunks through a shared double buffer and layer 1 is produced 32 rows at a time
+// inside the loop.  RD >= 2 ("free-running waves", small tiles): each wave streams only ITS 128 columns of W2 through a private ring
+// of RD chunks (16 rows x 512 B) and all of relu(layer 1) is laid down before the loop, so the loop has no workgroup barrier.
+constexpr int kFreeChunkFloats = kKC * 128;      // one wave's chunk: 16 rows x 128 columns
+constexpr int kPreDw = 16;                       // TailPre block per env (free-running form)
+template <int TM, int NW, int RD = 0>
 constexpr size_t act_lds_bytes()
 {
-    return sizeof(float) * (2 * kWcFloats + 2 * 32 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
-                            NW * 32 * TM * kOut + 32 * TM * kIn);
+    return sizeof(float) * ((RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats) + (RD ? 256 : 2 * 32) * 32 * TM + kW1K * 32 * TM + kW1K * kW1C +
+                            (kTailFloats + 2) + NW * 32 * TM * kOut + 32 * TM * kIn + (RD ? 32 * TM * kPreDw : 0));
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -137,27 +143,84 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
     return make_float2(r * c, r * s);
 }
 
+#ifdef ABL_STAMP
+#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define PSTAMP(i)
+#endif
+#ifdef ABL_STAMP
+#define TSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PSTAMP(i); } while (0)
+#else
+#define TSTAMP(i)
+#endif
+
+// The random draws of one act() call for env i: they do not depend on the actor's output, so a caller with latency to hide makes them
+// early (k_act's small-tile forms, during stage 0).  eps-greedy: the three raw Philox words; Gaussian / OU: the standard-normal pair.
+struct NoiseDraw { uint32_t a, b, c; };
+__device__ __forceinline__ NoiseDraw noise_draw(const shems_act_params &p, int64_t i)
+{
+    NoiseDraw d = {0u, 0u, 0u};
+    if (!p.train) return d;
+    if (p.noise_kind == SHEMS_NOISE_EPS) {
+        const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), p.tick, kStreamNoise, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+        d.a = x.x; d.b = x.y; d.c = x.z;
+    } else {
+        const float2 z = gauss_pair(p.seed, p.tick, i);
+        d.a = __float_as_uint(z.x); d.b = __float_as_uint(z.y);
+    }
+    return d;
+}
+
+// What the env tail reads from global memory before it can step, fetched ahead by the small-tile forms of k_act (16 dwords per env in
+// LDS): the next table row, h_countdown of the current row, idx, step, the config index and the noise draw.
+struct TailPre {
+    Row nx;
+    float h_cur;
+    int32_t idx, step, ci;
+    NoiseDraw nz;
+};
+__device__ __forceinline__ void tailpre_store(float *lds, const TailPre &t)
+{
+    f32x4 *q = reinterpret_cast<f32x4 *>(lds);
+    q[0] = f32x4{t.nx.h, t.nx.soc_ev, t.nx.d_e, t.nx.g_e};
+    q[1] = f32x4{t.nx.p_buy, t.nx.h_cos, t.nx.h_sin, t.nx.season};
+    q[2] = f32x4{t.h_cur, __int_as_float(t.idx), __int_as_float(t.step), __int_as_float(t.ci)};
+    q[3] = f32x4{__uint_as_float(t.nz.a), __uint_as_float(t.nz.b), __uint_as_float(t.nz.c), 0.0f};
+}
+__device__ __forceinline__ TailPre tailpre_load(const float *lds)
+{
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(lds);
+    const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    TailPre t;
+    t.nx = Row{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    t.h_cur = c[0]; t.idx = __float_as_int(c[1]); t.step = __float_as_int(c[2]); t.ci = __float_as_int(c[3]);
+    t.nz = NoiseDraw{__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2])};
+    return t;
+}
+
 // One env after layer 3: p0, p1 = the pre-activation outputs (b3 included).  tanh, exploration noise, clamp, scale_action, step!,
 // remember (DDPG.jl:148-184, 199-229).  Returns the env's reward (0 when nothing was stepped).
 // obs_lds: the env's 9 raw observations in LDS (the caller staged them), or null = read them from the view.
+// pre_lds: the env's TailPre block in LDS (the caller fetched it ahead), or null = draw / read in place.
 __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, float p0, float p1, int64_t learner, int64_t goff,
-                                               const float *obs_lds)
+                                               const float *obs_lds, const float *pre_lds = nullptr)
 {
     double reward = 0.0;
     {
+        TailPre pre;
+        if (pre_lds) pre = tailpre_load(pre_lds);
+        const NoiseDraw nz = pre_lds ? pre.nz : noise_draw(A.p, i);
         p0 = tanhf(p0);
         p1 = tanhf(p1);
         float a0, a1, nmean = 0.0f;                                    // nmean: act()'s second return value
         if (A.p.train && A.p.noise_kind == SHEMS_NOISE_EPS) {          // DDPG.jl:161-170
-            const u32x4 x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), A.p.tick, kStreamNoise, (uint32_t)A.p.seed,
-                                          (uint32_t)(A.p.seed >> 32));
-            const bool explore = !(u01_24(x.z) > A.p.eps);             // rng > eps: greedy; rng <= eps: uniform action
-            a0 = explore ? (float)((double)x.x * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
-            a1 = explore ? (float)((double)x.y * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
+            const bool explore = !(u01_24(nz.c) > A.p.eps);            // rng > eps: greedy; rng <= eps: uniform action
+            a0 = explore ? (float)((double)nz.a * (1.0 / 4294967296.0) * 2.0 - 1.0) : p0;
+            a1 = explore ? (float)((double)nz.b * (1.0 / 4294967296.0) * 2.0 - 1.0) : p1;
             nmean = explore ? 0.5f * (fabsf(p0 - a0) + fabsf(p1 - a1)) : 0.0f;          // mean(abs.(act_pred .- act_uni)) / 0f0
         } else {
             if (A.p.train) {
-                const float2 z = gauss_pair(A.p.seed, A.p.tick, i);
+                const float2 z = make_float2(__uint_as_float(nz.a), __uint_as_float(nz.b));
                 if (A.p.noise_kind == SHEMS_NOISE_OU) {                // DDPG.jl:49-55, 157-158
                     float2 X = reinterpret_cast<float2 *>(A.p.ou_state)[i];
                     const float sdt = A.p.noise_sigma * sqrtf(A.p.ou_dt);
@@ -177,19 +240,25 @@ __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, floa
             a0 = fminf(fmaxf(p0, -1.0f), 1.0f);                        // clamp.(act_pred .+ noise, -1f0, 1f0)
             a1 = fminf(fmaxf(p1, -1.0f), 1.0f);
         }
+        TSTAMP(5);
         if (A.a_out) reinterpret_cast<float2 *>(A.a_out)[i] = make_float2(a0, a1);
         if (A.p.noise_acc) A.p.noise_acc[i] += nmean;
         if (A.do_step) {
             const shems_view &v = A.v;
-            const shems_config c = load_cfg(v, i);
-            float obs[SHEMS_NSTATE], pre[SHEMS_NSTATE];
+            const shems_config c = pre_lds ? v.cfgs[pre.ci] : load_cfg(v, i);
+            float obs[SHEMS_NSTATE], s0[SHEMS_NSTATE];
 #pragma unroll
-            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = obs_lds ? obs_lds[k] : v.obs[i * SHEMS_NSTATE + k]; pre[k] = obs[k]; }
-            int32_t idx = v.idx[i], step = v.step[i];
+            for (int k = 0; k < SHEMS_NSTATE; ++k) { obs[k] = obs_lds ? obs_lds[k] : v.obs[i * SHEMS_NSTATE + k]; s0[k] = obs[k]; }
+            int32_t idx = pre_lds ? pre.idx : v.idx[i], step = pre_lds ? pre.step : v.step[i];
+            TSTAMP(6);
             StepFlows f;
             float B, EV, Bt, EVt;
-            if (env_advance(c, v.tables, obs, idx, step, scale_action(a0), scale_action(a1), SHEMS_TRACK_OFF, reward, f,
-                            B, EV, Bt, EVt)) {
+            const bool ok = pre_lds ? env_advance_rows(c, pre.nx, pre.h_cur, obs, idx, step, scale_action(a0), scale_action(a1), SHEMS_TRACK_OFF,
+                                                       reward, f, B, EV, Bt, EVt)
+                                    : env_advance(c, v.tables, obs, idx, step, scale_action(a0), scale_action(a1), SHEMS_TRACK_OFF, reward, f,
+                                                  B, EV, Bt, EVt);
+            if (ok) {
+                TSTAMP(7);
 #pragma unroll
                 for (int k = 0; k < SHEMS_NSTATE; ++k) v.obs[i * SHEMS_NSTATE + k] = obs[k];
                 v.idx[i] = idx;
@@ -208,7 +277,7 @@ __device__ __forceinline__ double act_env_tail(const ActArgs &A, int64_t i, floa
                             ring.s = gsh(ring.s, goff); ring.a = gsh(ring.a, goff); ring.r = gsh(ring.r, goff);
                             ring.s2 = gsh(ring.s2, goff); ring.done = gsh(ring.done, goff);
                         }
-                        ring_push(ring, (A.win.pos + rel) % ring.capacity, pre, a0, a1, (float)reward, obs);
+                        ring_push(ring, (A.win.pos + rel) % ring.capacity, s0, a0, a1, (float)reward, obs);
                     }
                 }
             } else {
@@ -241,6 +310,16 @@ __device__ __forceinline__ void sched_chunk()
     }
 }
 
+// Free-running form: after chunk c the wave needs its chunk c + 1; the LDS-DMA pieces of chunks c + 2 .. c + RD - 1 (8 each, 5 for
+// the short chunk 15) are younger and may stay in flight.
+template <int RD>
+constexpr int free_keep(int c)
+{
+    int n = 0;
+    for (int j = c + 2; j <= c + RD - 1; ++j) n += j > kChunks - 1 ? 0 : j == kChunks - 1 ? (kH1 - (kChunks - 1) * kKC) / 2 : 8;
+    return n;
+}
+
 #ifndef ABL_NOL1
 #define ABL_NOL1 0
 #endif
@@ -250,30 +329,30 @@ __device__ __forceinline__ void sched_chunk()
 #ifndef ABL_NOBAR
 #define ABL_NOBAR 0
 #endif
+#ifndef ABL_NOLDS
+#define ABL_NOLDS 0
+#endif
 #ifndef ABL_NOSCHED
 #define ABL_NOSCHED 0
 #endif
-#ifdef ABL_STAMP
-#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define PSTAMP(i)
-#endif
-template <int TM, int NW>
+template <int TM, int NW, int RD>
 __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 {
+    static_assert(RD == 0 || (NW == 4 && RD >= 2 && RD <= 4), "free-running form: 4 waves, ring of 2..4 chunks");
     constexpr int NT_ = 64 * NW;            // threads per workgroup
     constexpr int NA = 16 / NW;             // 32-wide n-tiles per wave (4 waves: 4, 8 waves: 2)
     PSTAMP(0);
     constexpr int BM = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Wc = reinterpret_cast<float *>(smem);             // [2][kWcFloats]   W2 chunks (16 rows x 500)
-    float *Hc = Wc + 2 * kWcFloats;                          // [2][32][BM]      relu(layer 1), 32-row groups
-    float *xT = Hc + 2 * 32 * BM;                            // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
+    float *Wc = reinterpret_cast<float *>(smem);             // RD = 0: [2][kWcFloats] W2 chunks (16 rows x 500); else [NW][RD][16][128]
+    float *Hc = Wc + (RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats);   // RD = 0: [2][32][BM] relu(layer 1), 32-row groups; else [256][BM]
+    float *xT = Hc + (RD ? 256 : 2 * 32) * BM;               // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
     float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
     float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
     float *xR = red + NW * BM * kOut;                        // [BM][9]   the raw observations stage 0 loaded: step! starts from these, not from a
                                                              //           second (stride-36-byte) read of global memory at the end of the kernel
+    float *xP = xR + BM * kIn;                               // RD > 0: [BM][kPreDw] TailPre blocks
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: LDS-DMA bases (M0) stay on the SALU
@@ -306,7 +385,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     } while (0)
 #define W2_ISSUE(chunk, buf)                                                                      \
     do { _Pragma("unroll") for (int pc_ = wave; pc_ < 32; pc_ += NW) W2_PIECE(chunk, buf, pc_); } while (0)
-#define STAGE0_DMA() W2_ISSUE(0, 0)
+    // Free-running form: wave w moves rows [16 c, +16) x columns [128 w, +128) of W2 -- piece q = rows 2q, 2q + 1 (lanes 0..31 /
+    // 32..63), 512 B each -- into its own ring.  Columns 500..511 of wave 3 run into the next row (the last row: into b2); those
+    // accumulator columns meet zero W3 rows.  Rows >= 250 (pieces 5..7 of chunk 15) are never read and never fetched.
+    float *Wf = Wc + wave * (RD * kFreeChunkFloats);
+    // One address pair per chunk: the chunk's base is wave-uniform (SGPR pair), a lane's 32-bit offset for piece q is constant over the
+    // whole kernel (8 registers), and the instruction's immediate -- added to the global AND the LDS address -- selects the LDS piece:
+    //   global = (W2 + 512 w + 32000 c) + [lane part + 4000 q - 1024 (q - 4)] + 1024 (q - 4),   LDS = (ring buffer + 4096) + 1024 (q - 4)
+    const char *wsbase = W2g + wave * 512;
+    uint32_t wvoff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wvoff[q] = (uint32_t)((lane >> 5) * (kH2 * 4) + (lane & 31) * 16 + q * (2 * kH2 * 4) - (q - 4) * 1024);
+#define FREE_PIECE(chunk, q)                                                                      \
+    glds16_piece(wsbase + (size_t)(chunk) * (kKC * kH2 * 4) + wvoff[q],                            \
+                 reinterpret_cast<char *>(Wf + ((chunk) % (RD ? RD : 1)) * kFreeChunkFloats) + 4 * 1024, (q))
+#define STAGE0_DMA()                                                                              \
+    do {                                                                                          \
+        if constexpr (RD == 0) W2_ISSUE(0, 0);                                                    \
+        else {                                                                                    \
+            _Pragma("unroll") for (int ch_ = 0; ch_ < RD - 1; ++ch_)                              \
+                _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) FREE_PIECE(ch_, q_);             \
+        }                                                                                         \
+    } while (0)
     // Every global load of the stage is issued before the first value is used (obs + normalisation, layer-1 image, b2|W3|b3;
     // the first W2 chunk goes out by LDS-DMA right behind them): one exposed latency instead of one per block.  Addresses are
     // clamped, never predicated -- a guarded load becomes a branch with its own s_waitcnt and serialises the batch.
@@ -328,7 +428,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // b2 | W3 | b3 are contiguous in the parameter block (1502 floats)
 #pragma unroll
     for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
+    // Small tiles: what the env tail needs from global memory is fetched now, and its random draws are made while stage 0 waits for
+    // its loads (TailPre; at one 32-env tile per workgroup the tail is ~10 % of the kernel and a chain of three dependent global reads).
+    // Every thread does it for env tid % BM (identical values, unconditional LDS stores: a predicated load would be sunk into a branch
+    // behind an s_waitcnt vmcnt(0)); without a view (actor forward only) the pointers fall back to the parameter block.
+    [[maybe_unused]] TailPre tp;
+    [[maybe_unused]] const float *tp_tables = nullptr;
+    [[maybe_unused]] int64_t tp_row = 0;
+    if constexpr (RD != 0) {
+        const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
+        const bool view = A.do_step != 0;
+        const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
+        const uint16_t *pci = view && A.v.n_cfg > 1 ? A.v.cfg_of_env : reinterpret_cast<const uint16_t *>(P);
+        tp.idx = pidx[view ? pe : 0];
+        tp.step = pstep[view ? pe : 0];
+        tp.ci = view && A.v.n_cfg > 1 ? (int)pci[pe] : 0;
+    }
     STAGE0_DMA();
+    if constexpr (RD != 0) tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
@@ -351,18 +468,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
         if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
     }
-    if (tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
+    if (RD == 0 && tid < 16) { Wc[kKC * kH2 + tid] = 0.0f; Wc[kWcFloats + kKC * kH2 + tid] = 0.0f; }
 
     // Layer 1 on the matrix pipe (K = 10 = 5 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
     // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
-#define L1_GROUP(g)                                                                               \
+#define L1_TILE(g, b, dst)                                                                        \
     do {                                                                                          \
-        if (wave < TM) {                                                                          \
             float a_[kW1K / 2], b_[kW1K / 2];                                                     \
             _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
                 const int j_ = 2 * s_ + lh;                                                       \
                 a_[s_] = w1[j_ * kW1C + 32 * (g) + li];                                           \
-                b_[s_] = xT[j_ * BM + TM * li + wave];            /* env column m = TM*j + tile */  \
+                b_[s_] = xT[j_ * BM + TM * li + (b)];             /* env column m = TM*j + tile */  \
             }                                                                                     \
             /* The accumulator of this tile must stay in VGPRs: given the builtin, the compiler parks it in a[0:15] and moves */ \
             /* a layer-2 accumulator tile out and back around every group (drain + 48 register moves).  Wait states are ours */ \
@@ -378,16 +494,78 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
                          : "=&v"(t_)                                                              \
                          : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]),            \
                            "v"(b_[0]), "v"(b_[1]), "v"(b_[2]), "v"(b_[3]), "v"(b_[4]));           \
-            float *dst_ = Hc + ((g) & 1) * (32 * BM) + TM * li + wave;                            \
+            float *dst_ = (dst);                                                                  \
             _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
                 dst_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t_[r_], 0.0f);             \
-        }                                                                                         \
     } while (0)
+/* Two tiles at once: the two 5-MFMA chains interleaved (each MFMA's C is the D of the one two back: no dependent-issue stall), */
+/* one operand fetch and one D -> VALU wait for both. */
+#define L1_TILE2(g0, b0, dst0, g1, b1, dst1)                                                      \
+    do {                                                                                          \
+            float a0_[kW1K / 2], c0_[kW1K / 2], a1_[kW1K / 2], c1_[kW1K / 2];                     \
+            _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
+                const int j_ = 2 * s_ + lh;                                                       \
+                a0_[s_] = w1[j_ * kW1C + 32 * (g0) + li];                                         \
+                c0_[s_] = xT[j_ * BM + TM * li + (b0)];                                           \
+                a1_[s_] = w1[j_ * kW1C + 32 * (g1) + li];                                         \
+                c1_[s_] = xT[j_ * BM + TM * li + (b1)];                                           \
+            }                                                                                     \
+            f32x16 t0_, t1_;                                                                      \
+            asm volatile("s_nop 1\n\t"                                                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %2, %7, 0\n\t"                               \
+                         "v_mfma_f32_32x32x2_f32 %1, %12, %17, 0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %3, %8, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %1, %13, %18, %1\n\t"                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %4, %9, %0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %1, %14, %19, %1\n\t"                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %15, %20, %1\n\t"                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %6, %11, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %16, %21, %1\n\t"                            \
+                         "s_nop 15\n\ts_nop 7"                                                    \
+                         : "=&v"(t0_), "=&v"(t1_)                                                 \
+                         : "v"(a0_[0]), "v"(a0_[1]), "v"(a0_[2]), "v"(a0_[3]), "v"(a0_[4]),       \
+                           "v"(c0_[0]), "v"(c0_[1]), "v"(c0_[2]), "v"(c0_[3]), "v"(c0_[4]),       \
+                           "v"(a1_[0]), "v"(a1_[1]), "v"(a1_[2]), "v"(a1_[3]), "v"(a1_[4]),       \
+                           "v"(c1_[0]), "v"(c1_[1]), "v"(c1_[2]), "v"(c1_[3]), "v"(c1_[4]));      \
+            float *d0_ = (dst0), *d1_ = (dst1);                                                   \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                   \
+                d0_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t0_[r_], 0.0f);             \
+                d1_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(t1_[r_], 0.0f);             \
+            }                                                                                     \
+    } while (0)
+#define L1_GROUP(g)                                                                               \
+    do { if (wave < TM) L1_TILE(g, wave, Hc + ((g) & 1) * (32 * BM) + TM * li + wave); } while (0)
 
-    __syncthreads();                     // xT, w1 visible
+    if constexpr (RD != 0) {
+        const bool view = A.do_step != 0;
+        const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
+        constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
+        const int32_t row0 = pc[o_row0], nrow = pc[o_nrow];
+        tp_tables = view ? A.v.tables : P;
+        // row idx + 1 (1-based) of the env's table, clamped into the table: env_advance_rows rejects idx + 1 > nrow before it looks at it
+        tp_row = view ? (int64_t)row0 + max(min(tp.idx + 1, nrow), 2) - 1 : 1;
+    }
+    // xT, w1 visible.  Only LDS stores are being published: a barrier that does not also drain the W2 pieces in flight (what
+    // __syncthreads() would do with its vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PSTAMP(1);
-    L1_GROUP(0);
-    __syncthreads();
+    if constexpr (RD == 0) L1_GROUP(0);
+    else {
+        const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
+        const f32x4 ra = rp[0], rb = rp[1];                                    // row idx + 1
+        tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
+        // all of relu(layer 1): 8 row groups x TM column tiles over the four waves
+#pragma unroll
+        for (int u = 0; u < TM; ++u) {
+            const int t0 = wave + 8 * u, g0 = t0 / TM, b0 = t0 - g0 * TM, t1 = t0 + 4, g1 = t1 / TM, b1 = t1 - g1 * TM;
+            L1_TILE2(g0, b0, Hc + g0 * (32 * BM) + TM * li + b0, g1, b1, Hc + g1 * (32 * BM) + TM * li + b1);
+        }
+        tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+        tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
+    }
+    if constexpr (RD == 0) __syncthreads();                                   // + chunk 0 of the shared stream
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // h1 only: every wave waits for its own ring below
     PSTAMP(2);
 
     // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
@@ -454,6 +632,53 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         if (!ABL_NOBAR) __syncthreads();                                                                        \
     } while (0)
 
+    // Free-running form: chunk c of a wave = 8 k-steps on its own ring buffer c % RD and rows [16 c, +16) of the resident h1; the
+    // pieces of chunk c + RD - 1 go out during k-steps 0..3 into the buffer chunk c - 1 was read from; at the end the wave waits for
+    // ITS OWN chunk c + 1 (vmcnt counts LDS-DMA in issue order: the pieces of younger chunks may stay in flight).  No barrier.
+#define FREE_NPIECES(ch) ((ch) > kChunks - 1 ? 0 : (ch) == kChunks - 1 ? (kH1 - (kChunks - 1) * kKC) / 2 : 8)
+    /* k-step K = 8 c + ks of the whole layer (0 .. 124): operands sit in register buffer K % 3 and were requested two k-steps ago. */ \
+    /* One scheduling region per k-step: [first MFMA: its lgkmcnt wait comes before the new reads are issued] [operand reads of    */ \
+    /* k-step K + 2] [the other MFMAs] [two LDS-DMA pieces].                                                                     */
+#define FREE_KSTEP(c, ks)                                                                                       \
+    do {                                                                                                        \
+        const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
+        if (K2_ < kFreeKsteps && !ABL_NOLDS) {                                                                  \
+            const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
+            af_[K2_ % 3] = *reinterpret_cast<const AVec *>(Wf + (c2_ % RD) * kFreeChunkFloats + NA * li + kr_ * 128); \
+            bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + (c2_ * kKC + kr_) * BM + TM * li);              \
+        }                                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                          \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[K_ % 3], a), fvec_get<TM>(bf_[K_ % 3], b), acc[a][b], 0, 0, 0); \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                        \
+            if (!ABL_NODMA && (ks) < kDmaKs && 2 * (ks) + h_ < FREE_NPIECES((c) + RD - 1)) FREE_PIECE((c) + RD - 1, 2 * (ks) + h_); \
+        if (!ABL_NOSCHED) {                                                                                     \
+            /* at most one memory instruction between two MFMAs */                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+    } while (0)
+    /* Chunk c: k-steps 0..5 read inside the chunk; before k-step 6 (whose reads open chunk c + 1) the wave waits for ITS OWN next   */ \
+    /* chunk, issued RD - 1 chunks ago -- the pieces of younger chunks may stay in flight.                                         */
+#define FREE_CHUNK(c, NKS)                                                                                      \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < ((NKS) < 6 ? (NKS) : 6); ++ks) FREE_KSTEP(c, ks);               \
+        if ((c) + 1 < kChunks) {                                                                                \
+            constexpr int keep_ = free_keep<RD>(c);                                                             \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep_) : "memory");                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+        _Pragma("unroll") for (int ks = 6; ks < (NKS); ++ks) FREE_KSTEP(c, ks);                                 \
+    } while (0)
+
+    if constexpr (RD == 0) {
 #pragma unroll 1
     for (int cp = 0; cp < (kChunks - 2) / 2; ++cp) {     // chunks 0..13: the next chunk (1..14) is whole
         CHUNK_BODY(2 * cp, 0, false, kKC / 2);
@@ -463,6 +688,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     CHUNK_BODY(kChunks - 2, 1, false, kKC / 2);           // chunk 14 fetches the short last chunk
     PSTAMP(4);
     CHUNK_BODY(kChunks - 1, 2, false, (kH1 - (kChunks - 1) * kKC) / 2);   // chunk 15: rows 240..249 only = 5 k-steps
+    } else {
+        {
+            constexpr int keep0_ = free_keep<RD>(-1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep0_) : "memory");        // this wave's chunk 0 has landed
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int kFreeKsteps = (kChunks - 1) * (kKC / 2) + (kH1 - (kChunks - 1) * kKC) / 2;      // 125 k-steps of two rows
+        AVec af_[3];                                                             // operand ring of three k-steps, carried from chunk to chunk
+        BVec bf_[3];
+#pragma unroll
+        for (int k0 = 0; k0 < 2; ++k0) {
+            af_[k0] = *reinterpret_cast<const AVec *>(Wf + NA * li + (2 * k0 + lh) * 128);
+            bf_[k0] = *reinterpret_cast<const BVec *>(Hc + TM * li + (2 * k0 + lh) * BM);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FREE_CHUNK(0, kKC / 2);  PSTAMP(3); FREE_CHUNK(1, kKC / 2);  FREE_CHUNK(2, kKC / 2);  FREE_CHUNK(3, kKC / 2);
+        FREE_CHUNK(4, kKC / 2);  FREE_CHUNK(5, kKC / 2);  FREE_CHUNK(6, kKC / 2);  FREE_CHUNK(7, kKC / 2);
+        FREE_CHUNK(8, kKC / 2);  FREE_CHUNK(9, kKC / 2);  FREE_CHUNK(10, kKC / 2); FREE_CHUNK(11, kKC / 2);
+        FREE_CHUNK(12, kKC / 2); FREE_CHUNK(13, kKC / 2); FREE_CHUNK(14, kKC / 2);
+        PSTAMP(4);
+        FREE_CHUNK(15, (kH1 - (kChunks - 1) * kKC) / 2);                       // rows 240..249 only = 5 k-steps
+    }
     PSTAMP(10);
 
     // ---- epilogue: relu(acc + b2), layer 3 partial dot products ------------------------------------
@@ -477,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     for (int a = 0; a < NA; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the W3 LDS reads near their rows (VGPR pressure)
+            if ((r & (TM == 4 ? 3 : 15)) == 0) __builtin_amdgcn_sched_barrier(0);   // TM = 4: keep the W3 LDS reads near their rows (VGPR pressure); small tiles: a whole tile's reads in flight
             const int n = nbase + NA * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;   // C/D row i of v_mfma_f32_32x32x* -> column n
             const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);   // rows >= 500: zero weights (and finite h)
 #pragma unroll
@@ -507,7 +754,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
         for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
-        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr);
+        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, RD != 0 ? xP + tid * kPreDw : nullptr);
     }
     PSTAMP(12);
 #ifndef ABL_STAMP
@@ -528,31 +775,34 @@ static int pick_tm(int64_t m)
     return 1;
 }
 
-template <int TM, int NW>
+template <int TM, int NW, int RD = 0>
 static int launch_act(const ActArgs &a, hipStream_t st)
 {
     constexpr int BM = 32 * TM;
-    const size_t lds = act_lds_bytes<TM, NW>();
+    const size_t lds = act_lds_bytes<TM, NW, RD>();
+    static_assert(act_lds_bytes<TM, NW, RD>() <= 160 * 1024, "k_act: LDS image exceeds 160 KB");
     static bool attr_done = false;
     if (!attr_done) {
-        if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_act<TM, NW>),
+        if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_act<TM, NW, RD>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                             "hipFuncSetAttribute(k_act)"))
             return rc;
         attr_done = true;
     }
     const unsigned grid = (unsigned)((a.m + BM - 1) / BM);
-    hipLaunchKernelGGL((k_act<TM, NW>), dim3(grid), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((k_act<TM, NW, RD>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hip_ok(hipGetLastError(), "k_act launch");
 }
 
 static int dispatch_act(const ActArgs &a, hipStream_t st)
 {
     static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    // small tiles (TM <= 2): 0 = shared W2 stream (as TM = 4), 2 / 3 = free-running waves with a private ring of 2 / 3 chunks
+    static const int form = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : 3; }();
     switch (pick_tm(a.m)) {
     case 4: return nw == 8 ? launch_act<4, 8>(a, st) : launch_act<4, 4>(a, st);
-    case 2: return launch_act<2, 4>(a, st);
-    default: return launch_act<1, 4>(a, st);
+    case 2: return form == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
+    default: return form == 0 ? launch_act<1, 4>(a, st) : form == 2 ? launch_act<1, 4, 2>(a, st) : launch_act<1, 4, 3>(a, st);
     }
 }
 
