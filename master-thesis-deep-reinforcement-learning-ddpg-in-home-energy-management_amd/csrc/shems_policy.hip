@@ -94,11 +94,16 @@ __device__ __forceinline__ T *gsh(T *p, int64_t off)
 // of RD chunks (16 rows x 512 B) and all of relu(layer 1) is laid down before the loop, so the loop has no workgroup barrier.
 constexpr int kFreeChunkFloats = kKC * 128;      // one wave's chunk: 16 rows x 128 columns
 constexpr int kPreDw = 16;                       // TailPre block per env (free-running form)
+// Rows of relu(layer 1) resident in LDS: the shared-stream form keeps two 32-row groups; the free-running form all 256 rows for
+// TM <= 2 and, for TM = 4 (128 envs per workgroup: 256 rows would be 128 KB), one half at a time -- the second half is laid down
+// between chunk 7 and chunk 8, the only two workgroup barriers of the layer.
+constexpr int act_h_rows(int tm, int rd) { return rd == 0 ? 64 : tm == 4 ? 128 : 256; }
+constexpr bool act_tail_pre(int tm, int rd) { return rd != 0 && tm <= 2; }    // TailPre blocks: the small tiles only (LDS)
 template <int TM, int NW, int RD = 0>
 constexpr size_t act_lds_bytes()
 {
-    return sizeof(float) * ((RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats) + (RD ? 256 : 2 * 32) * 32 * TM + kW1K * 32 * TM + kW1K * kW1C +
-                            (kTailFloats + 2) + NW * 32 * TM * kOut + 32 * TM * kIn + (RD ? 32 * TM * kPreDw : 0));
+    return sizeof(float) * ((RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats) + act_h_rows(TM, RD) * 32 * TM + kW1K * 32 * TM + kW1K * kW1C +
+                            (kTailFloats + 2) + NW * 32 * TM * kOut + 32 * TM * kIn + (act_tail_pre(TM, RD) ? 32 * TM * kPreDw : 0));
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -345,14 +350,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     constexpr int BM = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Wc = reinterpret_cast<float *>(smem);             // RD = 0: [2][kWcFloats] W2 chunks (16 rows x 500); else [NW][RD][16][128]
-    float *Hc = Wc + (RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats);   // RD = 0: [2][32][BM] relu(layer 1), 32-row groups; else [256][BM]
-    float *xT = Hc + (RD ? 256 : 2 * 32) * BM;               // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
+    constexpr int HR = act_h_rows(TM, RD);                   // rows of relu(layer 1) resident at a time
+    constexpr bool PRE = act_tail_pre(TM, RD);               // env-tail inputs fetched in stage 0
+    float *Hc = Wc + (RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats);   // [HR][BM] relu(layer 1)
+    float *xT = Hc + HR * BM;                                // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
     float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
     float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
     float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
     float *xR = red + NW * BM * kOut;                        // [BM][9]   the raw observations stage 0 loaded: step! starts from these, not from a
                                                              //           second (stride-36-byte) read of global memory at the end of the kernel
-    float *xP = xR + BM * kIn;                               // RD > 0: [BM][kPreDw] TailPre blocks
+    [[maybe_unused]] float *xP = xR + BM * kIn;              // PRE: [BM][kPreDw] TailPre blocks
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a scalar: LDS-DMA bases (M0) stay on the SALU
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     [[maybe_unused]] TailPre tp;
     [[maybe_unused]] const float *tp_tables = nullptr;
     [[maybe_unused]] int64_t tp_row = 0;
-    if constexpr (RD != 0) {
+    if constexpr (PRE) {
         const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
         const bool view = A.do_step != 0;
         const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         tp.ci = view && A.v.n_cfg > 1 ? (int)pci[pe] : 0;
     }
     STAGE0_DMA();
-    if constexpr (RD != 0) tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
+    if constexpr (PRE) tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
         const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #define L1_GROUP(g)                                                                               \
     do { if (wave < TM) L1_TILE(g, wave, Hc + ((g) & 1) * (32 * BM) + TM * li + wave); } while (0)
 
-    if constexpr (RD != 0) {
+    if constexpr (PRE) {
         const bool view = A.do_step != 0;
         const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
         constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
@@ -550,20 +557,75 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // __syncthreads() would do with its vmcnt(0))
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PSTAMP(1);
+    /* TM = 4: one wave lays down a whole 32-row group for all four column tiles.  A lane's four env columns m = 4 j + b are adjacent: */
+    /* the B operands come as one b128 read per k-step and the result leaves as one b128 store per row (the per-tile form's b32      */
+    /* accesses at a 16-byte lane stride are 4-way bank conflicts).  20 MFMAs, k-step outer / tile inner: C is the D of four back.   */
+#define L1_GROUP4(g, dst)                                                                         \
+    do {                                                                                          \
+            float a_[kW1K / 2];                                                                   \
+            f32x4 x_[kW1K / 2];                                                                   \
+            _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
+                const int j_ = 2 * s_ + lh;                                                       \
+                a_[s_] = w1[j_ * kW1C + 32 * (g) + li];                                           \
+                x_[s_] = *reinterpret_cast<const f32x4 *>(xT + j_ * BM + 4 * li);                 \
+            }                                                                                     \
+            f32x16 t0_, t1_, t2_, t3_;                                                            \
+            asm volatile("s_nop 1\n\t"                                                            \
+                         "v_mfma_f32_32x32x2_f32 %0, %4, %9, 0\n\t"                               \
+                         "v_mfma_f32_32x32x2_f32 %1, %4, %10, 0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %2, %4, %11, 0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %3, %4, %12, 0\n\t"                              \
+                         "v_mfma_f32_32x32x2_f32 %0, %5, %13, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %5, %14, %1\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %2, %5, %15, %2\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %3, %5, %16, %3\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %6, %17, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %6, %18, %1\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %2, %6, %19, %2\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %3, %6, %20, %3\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %7, %21, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %7, %22, %1\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %2, %7, %23, %2\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %3, %7, %24, %3\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %0, %8, %25, %0\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %1, %8, %26, %1\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %2, %8, %27, %2\n\t"                             \
+                         "v_mfma_f32_32x32x2_f32 %3, %8, %28, %3\n\t"                             \
+                         "s_nop 15\n\ts_nop 7"                                                    \
+                         : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)                         \
+                         : "v"(a_[0]), "v"(a_[1]), "v"(a_[2]), "v"(a_[3]), "v"(a_[4]),            \
+                           "v"(x_[0][0]), "v"(x_[0][1]), "v"(x_[0][2]), "v"(x_[0][3]),            \
+                           "v"(x_[1][0]), "v"(x_[1][1]), "v"(x_[1][2]), "v"(x_[1][3]),            \
+                           "v"(x_[2][0]), "v"(x_[2][1]), "v"(x_[2][2]), "v"(x_[2][3]),            \
+                           "v"(x_[3][0]), "v"(x_[3][1]), "v"(x_[3][2]), "v"(x_[3][3]),            \
+                           "v"(x_[4][0]), "v"(x_[4][1]), "v"(x_[4][2]), "v"(x_[4][3]));           \
+            float *d_ = (dst) + 4 * li;                                                           \
+            _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                     \
+                *reinterpret_cast<f32x4 *>(d_ + ((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM) =       \
+                    f32x4{fmaxf(t0_[r_], 0.0f), fmaxf(t1_[r_], 0.0f), fmaxf(t2_[r_], 0.0f), fmaxf(t3_[r_], 0.0f)}; \
+    } while (0)
+    // One phase of relu(layer 1) in the free-running form: row groups gbase .. gbase + HR / 32 - 1, TM column tiles each, over the four
+    // waves in interleaved pairs
+#define L1_PHASE(gbase)                                                                           \
+    do {                                                                                          \
+        if constexpr (TM == 4) {                       /* HR / 32 = 4 groups: one per wave */      \
+            const int g_ = (gbase) + wave;                                                        \
+            L1_GROUP4(g_, Hc + ((g_ * 32) % HR) * BM);                                            \
+        } else                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < (HR / 32) * TM / 8; ++u) {                          \
+            const int t0 = wave + 8 * u, g0 = (gbase) + t0 / TM, b0 = t0 % TM, t1 = t0 + 4, g1 = (gbase) + t1 / TM, b1 = t1 % TM; \
+            L1_TILE2(g0, b0, Hc + ((g0 * 32) % HR) * BM + TM * li + b0, g1, b1, Hc + ((g1 * 32) % HR) * BM + TM * li + b1); \
+        }                                                                                         \
+    } while (0)
     if constexpr (RD == 0) L1_GROUP(0);
-    else {
+    else if constexpr (PRE) {
         const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
         const f32x4 ra = rp[0], rb = rp[1];                                    // row idx + 1
         tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
-        // all of relu(layer 1): 8 row groups x TM column tiles over the four waves
-#pragma unroll
-        for (int u = 0; u < TM; ++u) {
-            const int t0 = wave + 8 * u, g0 = t0 / TM, b0 = t0 - g0 * TM, t1 = t0 + 4, g1 = t1 / TM, b1 = t1 - g1 * TM;
-            L1_TILE2(g0, b0, Hc + g0 * (32 * BM) + TM * li + b0, g1, b1, Hc + g1 * (32 * BM) + TM * li + b1);
-        }
+        L1_PHASE(0);
         tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
         tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
-    }
+    } else L1_PHASE(0);
     if constexpr (RD == 0) __syncthreads();                                   // + chunk 0 of the shared stream
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // h1 only: every wave waits for its own ring below
     PSTAMP(2);
@@ -642,10 +704,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #define FREE_KSTEP(c, ks)                                                                                       \
     do {                                                                                                        \
         const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
-        if (K2_ < kFreeKsteps && !ABL_NOLDS) {                                                                  \
+        /* a half-resident h1 (TM = 4): nothing of the second half is requested before it has been laid down */ \
+        const int klim_ = (HR < 256 && (c) < kChunks / 2) ? (kChunks / 2) * (kKC / 2) : kFreeKsteps;            \
+        if (K2_ < klim_ && !ABL_NOLDS) {                                                                        \
             const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
             af_[K2_ % 3] = *reinterpret_cast<const AVec *>(Wf + (c2_ % RD) * kFreeChunkFloats + NA * li + kr_ * 128); \
-            bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + (c2_ * kKC + kr_) * BM + TM * li);              \
+            bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + ((c2_ * kKC) % HR + kr_) * BM + TM * li);       \
         }                                                                                                       \
         _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                          \
             _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
@@ -705,6 +769,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         __builtin_amdgcn_sched_barrier(0);
         FREE_CHUNK(0, kKC / 2);  PSTAMP(3); FREE_CHUNK(1, kKC / 2);  FREE_CHUNK(2, kKC / 2);  FREE_CHUNK(3, kKC / 2);
         FREE_CHUNK(4, kKC / 2);  FREE_CHUNK(5, kKC / 2);  FREE_CHUNK(6, kKC / 2);  FREE_CHUNK(7, kKC / 2);
+        if constexpr (HR < 256) {
+            // every wave has read the first half of h1 to the end (its last requests were waited for): lay down rows 128..255 over it
+            // and restart the operand ring at k-step 64.  The W2 pieces in flight keep flying.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            L1_PHASE(HR / 32);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int k0 = 0; k0 < 2; ++k0) {
+                constexpr int Kp = (kChunks / 2) * (kKC / 2);
+                af_[(Kp + k0) % 3] = *reinterpret_cast<const AVec *>(Wf + ((kChunks / 2) % RD) * kFreeChunkFloats + NA * li + (2 * k0 + lh) * 128);
+                bf_[(Kp + k0) % 3] = *reinterpret_cast<const BVec *>(Hc + TM * li + (2 * k0 + lh) * BM);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         FREE_CHUNK(8, kKC / 2);  FREE_CHUNK(9, kKC / 2);  FREE_CHUNK(10, kKC / 2); FREE_CHUNK(11, kKC / 2);
         FREE_CHUNK(12, kKC / 2); FREE_CHUNK(13, kKC / 2); FREE_CHUNK(14, kKC / 2);
         PSTAMP(4);
@@ -754,7 +832,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
         for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
-        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, RD != 0 ? xP + tid * kPreDw : nullptr);
+        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, PRE ? xP + tid * kPreDw : nullptr);
     }
     PSTAMP(12);
 #ifndef ABL_STAMP
@@ -799,8 +877,10 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     // small tiles (TM <= 2): 0 = shared W2 stream (as TM = 4), 2 / 3 = free-running waves with a private ring of 2 / 3 chunks
     static const int form = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : 3; }();
+    // 128-env tiles: 0 = shared W2 stream, 1 = free-running waves (ring of 2 chunks, layer 1 resident one half at a time)
+    static const int form4 = []() { const char *e = getenv("SHEMS_ACT_FORM4"); return e ? atoi(e) : 1; }();
     switch (pick_tm(a.m)) {
-    case 4: return nw == 8 ? launch_act<4, 8>(a, st) : launch_act<4, 4>(a, st);
+    case 4: return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
     case 2: return form == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
     default: return form == 0 ? launch_act<1, 4>(a, st) : form == 2 ? launch_act<1, 4, 2>(a, st) : launch_act<1, 4, 3>(a, st);
     }
