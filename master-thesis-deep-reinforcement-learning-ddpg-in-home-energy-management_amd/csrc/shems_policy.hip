@@ -352,6 +352,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     float *Wc = reinterpret_cast<float *>(smem);             // RD = 0: [2][kWcFloats] W2 chunks (16 rows x 500); else [NW][RD][16][128]
     constexpr int HR = act_h_rows(TM, RD);                   // rows of relu(layer 1) resident at a time
     constexpr bool PRE = act_tail_pre(TM, RD);               // env-tail inputs fetched in stage 0
+    constexpr bool PRE2 = RD != 0 && TM == 4;                // 128-env tiles: indices in stage 0, rows + noise while the second half of h1
+                                                             // is laid down, TailPre blocks over the then dead layer-1 operand image
     float *Hc = Wc + (RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats);   // [HR][BM] relu(layer 1)
     float *xT = Hc + HR * BM;                                // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
     float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     [[maybe_unused]] TailPre tp;
     [[maybe_unused]] const float *tp_tables = nullptr;
     [[maybe_unused]] int64_t tp_row = 0;
-    if constexpr (PRE) {
+    if constexpr (PRE || PRE2) {
         const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
         const bool view = A.do_step != 0;
         const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #define L1_GROUP(g)                                                                               \
     do { if (wave < TM) L1_TILE(g, wave, Hc + ((g) & 1) * (32 * BM) + TM * li + wave); } while (0)
 
-    if constexpr (PRE) {
+    if constexpr (PRE || PRE2) {
         const bool view = A.do_step != 0;
         const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
         constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
@@ -773,8 +775,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             // every wave has read the first half of h1 to the end (its last requests were waited for): lay down rows 128..255 over it
             // and restart the operand ring at k-step 64.  The W2 pieces in flight keep flying.
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            [[maybe_unused]] f32x4 ra, rb;
+            if constexpr (PRE2) {
+                const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
+                ra = rp[0]; rb = rp[1];                                                // row idx + 1
+                tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
+            }
             L1_PHASE(HR / 32);
+            if constexpr (PRE2) tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (PRE2) {                                                      // w1 / xT are dead from here on
+                tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+                tailpre_store(w1 + (tid & (BM - 1)) * kPreDw, tp);
+            }
 #pragma unroll
             for (int k0 = 0; k0 < 2; ++k0) {
                 constexpr int Kp = (kChunks / 2) * (kKC / 2);
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     PSTAMP(10);
 
     // ---- epilogue: relu(acc + b2), layer 3 partial dot products ------------------------------------
-    float o0[TM], o1[TM];
+    float o0[TM], o1[TM];                       // (scalar FMAs: v_pk_fma_f32 on splat operands measured slower, 5 524 -> 5 856 cycles at TM = 4)
 #pragma unroll
     for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
     const float *w3s = tl + kH2P;
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
 #pragma unroll
         for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
-        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, PRE ? xP + tid * kPreDw : nullptr);
+        reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, PRE ? xP + tid * kPreDw : PRE2 ? w1 + tid * kPreDw : nullptr);
     }
     PSTAMP(12);
 #ifndef ABL_STAMP
