@@ -178,3 +178,42 @@ def test_noise_mean_accumulator_is_acts_second_return_value():
     ag.act_step(env, train=False, tick=5, a_out=a_out, noise_acc=acc)      # evaluation: adds 0
     assert (acc.cpu().numpy() == got).all()
     env.close()
+
+
+_FORM_SCRIPT = r"""
+import sys, zlib, importlib
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import util as U
+S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg"); R = importlib.import_module(U.PKG_NAME + ".replay")
+import torch
+out = []
+for n in (2048 + 13, 20000, 40000):                      # 32-, 64- and 128-env tiles
+    tab = S.tables.synthetic_table("train", 98)
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    ag = D.Agent(seed=7)
+    env.reset_(3, episode=0)
+    st = env.state; ag.set_norm(st.min(0), st.max(0))
+    ring = R.ReplayRing(24000)
+    for t in range(3):
+        ag.act_step(env, train=True, tick=t, ring=ring)
+    torch.cuda.synchronize()
+    out.append(zlib.crc32(env.state.tobytes()) ^ zlib.crc32(ring.s2.cpu().numpy().tobytes()) ^ zlib.crc32(ring.a.cpu().numpy().tobytes()))
+print("FORMS", *out)
+"""
+
+
+def test_every_form_of_the_act_kernel_writes_the_same_bytes():
+    """k_act exists in several forms (shared W2 stream / free-running waves with private rings, ring depth 2 or 3, half-resident layer 1
+    for 128-env tiles), chosen by tile size; SHEMS_ACT_FORM / SHEMS_ACT_FORM4 force the others.  They accumulate in the same order, so
+    three fused steps (actions, next states, ring contents) must agree bit for bit -- run in child processes, the form is read once."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _FORM_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    got = {}
+    for name, env in {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "ring2": {"SHEMS_ACT_FORM": "2"}}.items():
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("FORMS")][-1]
+    assert got["default"] == got["shared"] == got["ring2"], got
