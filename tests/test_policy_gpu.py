@@ -188,9 +188,13 @@ import util as U
 S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg"); R = importlib.import_module(U.PKG_NAME + ".replay")
 import torch
 out = []
-for n in (2048 + 13, 20000, 40000):                      # 32-, 64- and 128-env tiles
-    tab = S.tables.synthetic_table("train", 98)
-    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+for n, mixed in ((2048 + 13, False), (20000, False), (40000, False), (3000, True), (40000 + 7, True)):   # 32-, 64- and 128-env tiles
+    if mixed:                                            # ten charger profiles x weight sweep: a config index per env
+        tabs, cfgs, co = S.mixed_profile_setup(n)
+        env = S.ShemsBatch(n, 72, tabs, cfgs, co).use_torch_stream()
+    else:
+        tab = S.tables.synthetic_table("train", 98)
+        env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
     ag = D.Agent(seed=7)
     env.reset_(3, episode=0)
     st = env.state; ag.set_norm(st.min(0), st.max(0))
