@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         tp.step = pstep[view ? pe : 0];
         tp.ci = view && A.v.n_cfg > 1 ? (int)pci[pe] : 0;
     }
-    STAGE0_DMA();
+    if constexpr (RD == 0) STAGE0_DMA();
     if constexpr (PRE) tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
@@ -558,6 +558,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // xT, w1 visible.  Only LDS stores are being published: a barrier that does not also drain the W2 pieces in flight (what
     // __syncthreads() would do with its vmcnt(0))
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // The ring's first chunks go out only now: issued with stage 0's loads, 256 workgroups x 64 KB of pieces queue in front of the
+    // few KB every workgroup is actually waiting for (measured: -0.6 % at 65 536 envs, -1.7 % at 8 192).
+    if constexpr (RD != 0) STAGE0_DMA();
     PSTAMP(1);
     /* TM = 4: one wave lays down a whole 32-row group for all four column tiles.  A lane's four env columns m = 4 j + b are adjacent: */
     /* the B operands come as one b128 read per k-step and the result leaves as one b128 store per row (the per-tile form's b32      */
