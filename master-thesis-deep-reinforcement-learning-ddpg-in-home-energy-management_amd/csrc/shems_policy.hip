@@ -560,7 +560,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // The ring's first chunks go out only now: issued with stage 0's loads, 256 workgroups x 64 KB of pieces queue in front of the
     // few KB every workgroup is actually waiting for (measured: -0.6 % at 65 536 envs, -1.7 % at 8 192).
-    if constexpr (RD != 0) STAGE0_DMA();
+    // (small tiles: behind the TailPre row loads below, so that waiting for those does not mean waiting for the pieces)
+    if constexpr (RD != 0 && !PRE) STAGE0_DMA();
     PSTAMP(1);
     /* TM = 4: one wave lays down a whole 32-row group for all four column tiles.  A lane's four env columns m = 4 j + b are adjacent: */
     /* the B operands come as one b128 read per k-step and the result leaves as one b128 store per row (the per-tile form's b32      */
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
         const f32x4 ra = rp[0], rb = rp[1];                                    // row idx + 1
         tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
+        STAGE0_DMA();
         L1_PHASE(0);
         tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
         tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
