@@ -73,11 +73,11 @@ def test_actor_forward_matches_float64_reference(m):
     assert np.abs(outn - out).max() > 0.05         # the noise is really there (its N(0,1) shape: test_ddpg_oracle.py)
 
 
-def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
+@pytest.mark.parametrize("n,nsteps", [(20000, 6), (2048 + 5, 3), (65536, 2)])      # 64-, 32- and 128-env tiles (the first two ragged)
+def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps):
     torch, S, D = _mods()
     ReplayRing = importlib.import_module(U.PKG_NAME + ".replay").ReplayRing
     T = S.tables
-    n = 20000                                      # ragged vs BM = 32
     tab = T.synthetic_table("train", 98)
     env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
     ref = oracle_c.Batch(n, 72, tab, oracle_c.profile(98))
@@ -95,7 +95,7 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
     rew32 = torch.empty(n, dtype=torch.float32, device="cuda")
     blk = torch.zeros(ag.act_step_blocks(n), dtype=torch.float64, device="cuda")
     pos = 0
-    for t in range(6):
+    for t in range(nsteps):
         pre = env.state
         win = D.RingWindow(pos % ring.capacity, 333, (t * 333) % n)
         ag.act_step(env, train=True, tick=t, a_out=a_out, rewards=rew, rewards_f32=rew32, block_reward=blk, ring=ring, window=win)
@@ -121,7 +121,7 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring():
         assert (U.bits32(ring.a.cpu().numpy()[slots]) == U.bits32(a[sel])).all()
         assert (ring.r.cpu().numpy()[slots] == r_ref[sel].astype(np.float32)).all()
         pos += 333
-    assert (env.idx == ref.idx()).all() and (env.step == 6).all()
+    assert (env.idx == ref.idx()).all() and (env.step == nsteps).all()
     env.close()
 
 
