@@ -23,7 +23,8 @@ def _run(cmd, env=None, timeout=420):
 
 
 def test_bench_json_contract_small():
-    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline"])
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline", "--prewarm-s", "0.2"])
+    assert d["prewarm_steps"] >= 50 and d["steps"] == 16 and d["warmup"] == 4          # the pre-warm is extra, untimed and reported
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -80,7 +81,8 @@ def test_async_gradient_exchange_gives_the_same_bytes():
     device; the collective's timing itself cannot be measured on a one-GPU box)."""
     out = []
     for knob in ("1", "0"):
-        d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--envs", "4096"],
+        # --prewarm-s 0: the pre-warm runs for a wall-clock time, i.e. a different number of updates from run to run
+        d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "12", "--warmup", "2", "--envs", "4096", "--prewarm-s", "0"],
                  env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP_OVERLAP": knob})
         assert d["n_gpus"] == 2 and d["dp_overlap"] is (knob == "1")
         out.append(d["learner_crc32"])
