@@ -407,7 +407,8 @@ def main():
         roof = {"bound": k["bound"], "achieved": achieved, "peak": k["peak"], "unit": k["unit"],
                 "frac": achieved / k["peak"], "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
-                "algorithmic_per_launch": k["algorithmic"]}
+                "algorithmic_per_launch": k["algorithmic"],
+                "timing": k.get("method", "HIP events over back-to-back groups of 8 launches")}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)
     if dist is not None:

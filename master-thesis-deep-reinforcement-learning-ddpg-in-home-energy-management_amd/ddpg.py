@@ -588,34 +588,51 @@ class TrainWorkload:
             raise RuntimeError("non-finite network parameters after the timed steps")
 
     def kernel_pass(self, reps):
-        """HIP-event timing of the dominant kernel (the fused actor/step launch) on its own stream."""
+        """HIP-event timing of the dominant kernel (the fused actor/step launch) IN THE LOOP IT RUNS IN.
+
+        The train loop alternates k_act with the launches of replay(), and the clock the chip holds in that mix is not the clock of
+        k_act launched back to back: one rocprofv3 trace of `bench.py` shows 133.3 us per k_act inside the loop and 139.6 us for the
+        same kernel in a back-to-back pass.  So the pass times groups of 8 whole vector steps [act, replay x updates] and, separately,
+        groups of 8 x replay() alone; the difference per step is the act launch together with the gap in front of it.  A pair of events
+        around every single launch would add the command processor's hand-off (3-5 us) to each reading (timing.py)."""
         torch = self.torch
         from .timing import time_launches
+        reps = min(reps, 200)
         reset = lambda g, i: self.env.reset_(self.env_seed, episode=100000 + i) if g % 8 == 0 else None     # 64 launches < one episode
-        avg_us, med_us, reps = time_launches(torch, self._act, min(reps, 200), before_group=reset)
-        # one replay() alone, for the updates/sec breakdown.  This pass runs on rank 0 only: no collective may be issued
-        # here (the other ranks are not in this code), so the gradient exchange is switched off for its duration.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        nup = 50
-        # the learner state is put back afterwards, so rank 0's replica stays identical to the others
+        # This pass runs on rank 0 only: no collective may be issued here (the other ranks are not in this code), so the gradient
+        # exchange is switched off for its duration; the learner state is put back afterwards, so rank 0's replica stays identical.
         snap = self.agent.snapshot()
         saved_sync, self.agent.sync = self.agent.sync, GradSync(None)
         world = saved_sync.world
         self.agent.fused = world == 1                   # time the launch structure the benchmarked world size runs (minus the exchange)
-        try:
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(nup):
+
+        def vector_step(i):
+            self._act(i)
+            for _ in range(self.updates):
                 self.agent.replay(self.ring)
-            e1.record()
-            torch.cuda.synchronize()
+
+        def updates_only(i):
+            for _ in range(self.updates):
+                self.agent.replay(self.ring)
+
+        try:
+            reset(0, 0)
+            for i in range(16):                          # settle into the loop's regime before the first timed group
+                vector_step(i)
+            step_avg, step_med, n = time_launches(torch, vector_step, reps, before_group=reset)
+            if self.updates:
+                upd_avg, upd_med, _ = time_launches(torch, updates_only, reps)
+            else:
+                upd_avg = upd_med = 0.0
         finally:
             self.agent.sync = saved_sync
             self.agent.restore(snap)
-        self.update_us = e0.elapsed_time(e1) * 1e3 / nup
+        self.update_us = upd_avg / self.updates if self.updates else None
+        self.step_us_in_pass = step_avg
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # SURVEY.md 8(d): 256 500 FLOP / env-step
-        return dict(kernel="shems::k_act<TM>", avg_us=avg_us, median_us=med_us, launches=reps,
-                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
+        return dict(kernel="shems::k_act<TM>", avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
+                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
+                    method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)")
 
     def extra(self):
         import zlib
