@@ -2,7 +2,9 @@
 
 A pair of events around a single launch also times the command processor's hand-off (≈3-5 µs on this stack: a 6.6 µs kernel
 reads 11.6 µs), so launches are timed in back-to-back groups and the group time is divided by its length; rocprofv3's
-per-kernel average of the same command is the cross-check (profiles/)."""
+per-kernel average of the same command is the cross-check (profiles/).  `launch(i)` may be a whole vector step: the train workload
+times groups of steps and groups of replay() alone and reports their difference, because k_act launched back to back runs 4-5 %
+slower than the same kernel between the update's launches (ddpg.TrainWorkload.kernel_pass)."""
 from __future__ import annotations
 
 
