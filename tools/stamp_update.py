@@ -53,6 +53,9 @@ for k in range(5):
     skew = (rt0.max(1) - rt0.min(1)) * 0.01
     print(f"   span first-start -> last-end: median {np.median(span):.2f} us; start skew {np.median(skew):.2f} us")
     out[names[k]] = {"span_us": float(np.median(span)), "start_skew_us": float(np.median(skew)), "roles": {}}
+    # where the start skew sits: median start offset (us after the launch's first workgroup) per block of 32 workgroup ids
+    rel = np.median(rt0 - rt0.min(1, keepdims=True), 0) * 0.01
+    print("   start offset by workgroup id (blocks of 32): " + " ".join(f"{rel[i:i + 32].mean():.2f}" for i in range(0, len(wgs), 32)))
     for role in sorted(set(roles[k](int(w)) for w in wgs)):
         sel = [i for i, w in enumerate(wgs) if roles[k](int(w)) == role]
         t = ak[:, wgs[sel]][:, :, :, 0].astype(np.float64)               # shader cycles
