@@ -209,7 +209,12 @@ def main(environ=os.environ, cwd=".", log=print):
         for split in ("train", "eval", "test"):
             p = data_path(cfg, split)
             if not os.path.exists(p):
-                tables.save_csv(p, tables.profile_table(cfg.charger_id, split))
+                t = tables.profile_table(cfg.charger_id, split)
+                need = 1 + (EP_LENGTH["train"] if split == "train" else EP_LENGTH[cfg.season, split])    # a pass of n steps reads row n + 1
+                if t.shape[0] < need:                                      # a real series with one row per MPC decision: see tables.pad_rows
+                    log(f"{os.path.basename(p)}: {t.shape[0]} rows in the reconstructed series, {need} needed; padded with the rows 24 h earlier")
+                    t = tables.pad_rows(t, need)
+                tables.save_csv(p, t)
     tabs = {split: tables.load_csv(data_path(cfg, split)) for split in ("train", "eval", "test")}       # env_dict, INPUT:162-164
     n_envs = int(environ.get("SHEMS_NUM_ENVS", "1"))
     # the env's reward weights are module constants of shems_LU1.jl:40-43 (0.01f0, 2f0, 0.1f0) whatever the input file says ("REMEMBER TO

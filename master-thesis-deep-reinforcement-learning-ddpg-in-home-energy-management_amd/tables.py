@@ -203,6 +203,16 @@ def profile_table(charger_id, split="train", prefer_real=True):
     return synthetic_table(split, charger_id) if t is None else t
 
 
+def pad_rows(table, nrow):
+    """A table with at least `nrow` rows: missing rows are copies of the row 24 h earlier (same hour-of-day features).  The series
+    reconstructed from the reference's MPC result files hold one row per DECISION (eval: 1 439, test: 2 999), while a pass of that
+    many steps reads one row more (next_state! looks at row idx + 1, LU1:264-281): the last hour's exogenous data is not in the files."""
+    t = np.asarray(table, dtype=np.float32)
+    while t.shape[0] < nrow:
+        t = np.concatenate([t, t[-24:-23] if t.shape[0] >= 24 else t[-1:]], 0)
+    return t
+
+
 def episode_start_table(table, maxsteps):
     """Resolved episode start for every possible first draw (pure function of the draw:
     shems_LU1.jl:227-246 redraws with the SAME seed, i.e. the same value).  Host-side helper

@@ -79,3 +79,27 @@ def test_entry_script_runs_mains_order_and_writes_the_reference_files(tmp_path):
     finally:
         os.chdir(cwd0)
     assert tr_.shape == (2,) and sm_.shape == (1,) and best_run == 1 and np.isfinite(sm_).all()
+
+
+@pytest.mark.gpu
+def test_entry_script_on_a_charger_with_real_series(tmp_path):
+    """Charger04: train and eval tables are the series reconstructed from the reference's MPC results (4 319 / 1 439 rows, one per MPC
+    decision).  The 1 439-step tracking pass reads row 1 440, which those files do not hold: the demo data writer pads it (tables.pad_rows)."""
+    pytest.importorskip("torch")
+    env = {"JOB_ID": "1170408", "TASK_ID": "1", "GPU_ID": "0", "SHEMS_NUM_EP": "2", "SHEMS_NUM_SEEDS": "1", "SHEMS_NUM_ENVS": "64",
+           "SHEMS_SYNTHETIC_DATA": "1"}
+    logs = []
+    cwd0 = os.getcwd()
+    try:
+        cfg, written = M.main(env, cwd=str(tmp_path), log=logs.append)
+    finally:
+        os.chdir(cwd0)
+    assert cfg.Charger_ID == "Charger04" and len(written) == 2
+    T = U.tables_mod()
+    real = T.real_series(4, "eval")
+    got = T.load_csv(str(tmp_path / "data/Charger04_all_eval_fix.csv"))
+    assert real.shape == (1439, 8) and got.shape == (1440, 8) and (got[:1439] == real).all() and (got[1439] == real[1415]).all()
+    assert (T.load_csv(str(tmp_path / "data/Charger04_all_train_fix.csv")) == T.real_series(4, "train")).all()
+    assert any("padded with the rows 24 h earlier" in l for l in logs)
+    rows = list(csv.reader(open(tmp_path / written[0])))
+    assert len(rows) == 1 + 1439 and np.isfinite(np.array(rows[1:], float)).all()
