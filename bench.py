@@ -138,22 +138,29 @@ class PolicyWorkload(EnvWorkload):
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
 
-def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
-    """The CPU oracle (`kind: port`: C restatement of shems_LU1.jl + NumPy restatement of the DDPG learner) on this
-    box's host cores, ONE thread, on a bounded sample of the same workload: the same vector step (act + noise +
-    scale_action + step! + remember [+ `updates` x replay()]) over a 4096-env slice, timed for ~10 s."""
+def cpu_baseline(n_envs, mode, updates, scale=1.0):
+    """The CPU oracle (`kind: port`: C restatement of shems_LU1.jl + restatement of the DDPG learner) timed on this box's host
+    cores, on bounded samples of the same workload (about 20 s in all).  No timed region contains a per-env foreign call: the
+    env batch is stepped, reset and read with ONE C call each (orc_batch_step[_omp] with obs_out, orc_batch_reset).
+
+      value / cores            the FULL vector step (act + Gaussian noise + scale_action + step! + remember [+ `updates` x replay()])
+                               on ALL host cores: OpenMP env step, actor forward on torch's CPU thread pool, NumPy learner with
+                               the BLAS thread count that is fastest for B = 120 on this box (measured here, reported)
+      one_thread_value         the same step on ONE thread (C env, NumPy actor + learner, BLAS capped at 1) on a 4096-env slice
+      env_only_*               step! alone, one thread / all cores (whole episodes per OpenMP region)
+      update_only_per_sec      replay() alone at each BLAS thread count tried
+    scale shrinks every leg's time budget (tests)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_c
     import ddpg_oracle as DO
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:                                            # pragma: no cover
-        threadpool_limits = None
+    import torch
+    from threadpoolctl import threadpool_limits
     S = importlib.import_module(PKG)
     tab = S.tables.synthetic_table("train", 98)
     rng = np.random.default_rng(0)
     L = oracle_c.lib()
+    cores = os.cpu_count() or 1
 
     def env_batch(n):
         b = oracle_c.Batch(n, EP_LEN, tab, oracle_c.profile(98))
@@ -166,11 +173,9 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
     b, idx0, soc0 = env_batch(n)
     acts = [rng.random((n, 2)).astype(np.float32) for _ in range(4)]
     rew = np.empty(n)
-    obs = np.empty((n, 9), np.float32)
     steps, t_step = 0, 0.0
-    t_all0 = time.perf_counter()
-    while time.perf_counter() - t_all0 < 4.0:
-        b.reset(False, idx0, soc0)                  # python-loop reset: not timed
+    while t_step < 2.0 * scale:
+        b.reset(False, idx0, soc0)                  # one C call, not timed
         t0 = time.perf_counter()
         for t in range(EP_LEN):
             L.orc_batch_step(b.ptr, n, acts[t % 4].ctypes.data, 0, rew.ctypes.data, None, None)
@@ -178,12 +183,12 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
         steps += n * EP_LEN
     env_one = steps / t_step
     # all host cores: each OpenMP thread carries its envs through whole 72-step episodes inside one parallel region
-    # (orc_batch_episode_omp); one untimed episode warms the thread pool, then whole episodes for >= 3 s
+    # (orc_batch_episode_omp); one untimed episode warms the thread pool
     sets = np.stack(acts)
     b.reset(False, idx0, soc0)
     b.episode_omp(sets, EP_LEN)
     steps_all, t_all = 0, 0.0
-    while t_all < 3.0:
+    while t_all < 1.5 * scale:
         b.reset(False, idx0, soc0)
         t0 = time.perf_counter()
         rc, _ = b.episode_omp(sets, EP_LEN)
@@ -194,77 +199,112 @@ def cpu_baseline(n_envs, mode, updates, budget_s=14.0):
     # BASELINE config 1 / B1: ONE env, rule-based 72-step episodes (reset!(env; rng=-1), action(env, track), step!), one thread
     one = oracle_c.Batch(1, EP_LEN, tab, oracle_c.profile(98))
     nrep, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 1.0:
+    while time.perf_counter() - t0 < 0.5 * scale:
         one.reset(True)
         one.rule_episode(0, EP_LEN)
         nrep += 1
     rule_us = (time.perf_counter() - t0) / (nrep * EP_LEN) * 1e6
-    out = {"env_only_value": env_one, "env_only_all_cores_value": env_all, "all_cores": os.cpu_count() or 1,
+    out = {"env_only_value": env_one, "env_only_all_cores_value": env_all, "all_cores": cores,
            "config1_rule_episode_us_per_step": rule_us}
     if mode == "env":
-        out.update({"value": env_one, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                    "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes, {steps} env-steps in {t_step:.1f} s"})
+        out.update({"value": env_all, "unit": "env-steps/s", "cores": cores, "kind": "port", "one_thread_value": env_one,
+                    "sample": f"oracle/shems_oracle.c step! only, {n} envs x {EP_LEN}-step episodes: {steps_all} env-steps in {t_all:.1f} s "
+                              f"on all cores (OpenMP), {steps} in {t_step:.1f} s on one thread"})
         return out
 
-    # (b) the full vector step of the train / policy workload on a 4096-env slice, 1 thread
-    n = min(n_envs, 4096)
-    b, idx0, soc0 = env_batch(n)
-    b.reset(False, idx0, soc0)
-    actor, critic = DO.init_params(1231, 9, 2, 0), DO.init_params(1231, 11, 1, 1)
-    st = b.state()
-    s_min, s_max = st.min(0), st.max(0)
-    learner = DO.Learner(actor, critic, s_min, s_max)
     cap = 24000
-    ring = dict(s=np.zeros((cap, 9), np.float32), a=np.zeros((cap, 2), np.float32), r=np.zeros(cap, np.float32),
-                s2=np.zeros((cap, 9), np.float32), d=np.zeros(cap, bool))
-    ring["s"][:] = st[rng.integers(0, n, cap)]
-    ring["s2"][:] = ring["s"]
-    win = min(n, cap // EP_LEN)
-    ctx = threadpool_limits(limits=1) if threadpool_limits else None
-    if ctx is not None:
-        ctx.__enter__()
-    try:
-        nstep, t0, pos = 0, time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s - 5.0 or nstep < 2:
-            s = b.state()
-            a = DO.act(learner.actor, s, s_min, s_max, True, seed=1, tick=nstep)              # actor + Gaussian noise + clamp
-            L.orc_batch_step(b.ptr, n, oracle_c.scale_action(a).ctypes.data, 0, rew.ctypes.data, None, None)
-            s2 = b.state()
-            sl = (pos + np.arange(win)) % cap                                                 # remember(): rotating window
-            ring["s"][sl], ring["a"][sl], ring["r"][sl], ring["s2"][sl] = s[:win], a[:win], rew[:win], s2[:win]
-            pos += win
-            if mode == "train":
-                for u in range(updates):
-                    i = DO.sample_indices(1, nstep * 8 + u, 120, cap)
-                    learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
-            nstep += 1
-            if nstep % (EP_LEN - 1) == 0:
-                b.reset(False, idx0, soc0)
-        dt = time.perf_counter() - t0
-    finally:
-        if ctx is not None:
-            ctx.__exit__(None, None, None)
+    actor, critic = DO.init_params(1231, 9, 2, 0), DO.init_params(1231, 11, 1, 1)
+
+    def make_ring(st):
+        ring = dict(s=np.zeros((cap, 9), np.float32), a=np.zeros((cap, 2), np.float32), r=np.zeros(cap, np.float32),
+                    s2=np.zeros((cap, 9), np.float32), d=np.zeros(cap, bool))
+        ring["s"][:] = st[rng.integers(0, len(st), cap)]
+        ring["s2"][:] = ring["s"]
+        return ring
+
+    def upd_rate(learner, ring, nrep):
+        t1 = time.perf_counter()
+        for u in range(nrep):
+            i = DO.sample_indices(2, u, 120, cap)
+            learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
+        return nrep / (time.perf_counter() - t1)
+
+    def full_step_loop(n, budget, env_step, policy, blas_threads):
+        """`budget` seconds of whole vector steps on an n-env batch; returns (vector steps, seconds)."""
+        b, idx0, soc0 = env_batch(n)
+        b.reset(False, idx0, soc0)
+        s, s2 = b.state(), np.empty((n, 9), np.float32)
+        s_min, s_max = s.min(0), s.max(0)
+        learner = DO.Learner(actor, critic, s_min, s_max)
+        ring = make_ring(s)
+        win = min(n, cap // EP_LEN)
+        rew = np.empty(n)
+        sc = np.empty((n, 2), np.float32)
+        with threadpool_limits(limits=blas_threads):
+            nstep, pos, t0 = 0, 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget or nstep < 2:
+                a = policy(learner.actor, s, s_min, s_max, nstep)                                  # actor + Gaussian noise + clamp
+                L.orc_scale_actions(a.ctypes.data, a.size, sc.ctypes.data)                         # scale_action, one call
+                env_step(b.ptr, n, sc.ctypes.data, 0, rew.ctypes.data, s2.ctypes.data)             # step!, s' written by the same call
+                sl = (pos + np.arange(win)) % cap                                                  # remember(): rotating window
+                ring["s"][sl], ring["a"][sl], ring["r"][sl], ring["s2"][sl] = s[:win], a[:win], rew[:win], s2[:win]
+                pos += win
+                if mode == "train":
+                    for u in range(updates):
+                        i = DO.sample_indices(1, nstep * 8 + u, 120, cap)
+                        learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
+                s, s2 = s2, s
+                nstep += 1
+                if nstep % (EP_LEN - 1) == 0:
+                    b.reset(False, idx0, soc0)                                                     # one C call
+                    b.state(out=s)
+            return nstep, time.perf_counter() - t0, learner, ring
+
+    # (b) ONE thread: C env, NumPy actor and learner, BLAS capped at 1, 4096-env slice
+    np_policy = lambda act_p, s, lo, hi, k: DO.act(act_p, s, lo, hi, True, seed=1, tick=k)
+    step1 = lambda ptr, n, a, tm, r, o: L.orc_batch_step(ptr, n, a, tm, r, o, None)
+    n1 = min(n_envs, 4096)
+    nstep1, dt1, learner, ring = full_step_loop(n1, 6.0 * scale, step1, np_policy, 1)
+    one_thread = n1 * nstep1 / dt1
     if mode == "train":
-        # replay() alone, one thread (BLAS capped) and BLAS on all host cores -- informational
-        def upd_rate(nrep):
-            t1 = time.perf_counter()
-            for u in range(nrep):
-                i = DO.sample_indices(2, u, 120, cap)
-                learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
-            return nrep / (time.perf_counter() - t1)
-        ctx = threadpool_limits(limits=1) if threadpool_limits else None
-        if ctx is not None:
-            ctx.__enter__()
-        try:
-            out["update_only_per_sec"] = upd_rate(40)
-        finally:
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
-        out["update_only_all_cores_per_sec"] = upd_rate(40)
-    out.update({"value": n * nstep / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                "sample": f"CPU oracle (C env + NumPy learner, BLAS limited to 1 thread), the same vector step "
-                          f"(mode={mode}, {updates} update/step) on a {n}-env slice: {nstep} vector steps = {n * nstep} env-steps in {dt:.1f} s",
-                "updates_per_sec": (updates * nstep / dt) if mode == "train" else None})
+        # replay() alone (BASELINE.md B4) at several BLAS thread counts: at B = 120 the matrices are small and more threads are
+        # not faster; the all-cores leg below uses whichever count wins here
+        rates = {}
+        for th in sorted({1, min(4, cores), min(16, cores)}):
+            with threadpool_limits(limits=th):
+                upd_rate(learner, ring, 5)
+                rates[th] = upd_rate(learner, ring, max(3, int(30 * scale)))
+        best_blas = max(rates, key=rates.get)
+        out["update_only_per_sec"] = rates[1]
+        out["update_only_per_sec_by_blas_threads"] = {str(k): v for k, v in rates.items()}
+    else:
+        best_blas = 1
+
+    # (c) ALL cores: OpenMP env step over the whole batch, actor forward + noise on torch's CPU thread pool (GEMMs and the
+    # elementwise work both threaded), learner as above with the best BLAS thread count
+    W = [torch.from_numpy(x.copy()) for x in DO.split(actor, 9, 2)]
+
+    def torch_policy(act_p, s, lo, hi, k):
+        with torch.no_grad():
+            W1, b1, W2, b2, W3, b3 = [torch.from_numpy(x) for x in DO.split(act_p, 9, 2)]
+            x = (torch.from_numpy(s) - torch.from_numpy(lo)) / ((torch.from_numpy(hi) - torch.from_numpy(lo)) + 1e-8)
+            h = torch.relu_(torch.addmm(b1, x, W1))
+            h = torch.relu_(torch.addmm(b2, h, W2))
+            a = torch.tanh_(torch.addmm(b3, h, W3))
+            a.add_(torch.randn_like(a), alpha=0.1).clamp_(-1.0, 1.0)
+            return a.numpy()
+    stepN = lambda ptr, n, a, tm, r, o: L.orc_batch_step_omp(ptr, n, a, tm, r, o)
+    nN = n_envs
+    nstepN, dtN, _, _ = full_step_loop(nN, 6.0 * scale, stepN, torch_policy, best_blas)
+    all_cores = nN * nstepN / dtN
+    out.update({"value": all_cores, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                "updates_per_sec": (updates * nstepN / dtN) if mode == "train" else None,
+                "one_thread_value": one_thread, "one_thread_updates_per_sec": (updates * nstep1 / dt1) if mode == "train" else None,
+                "torch_cpu_threads": torch.get_num_threads(), "learner_blas_threads": best_blas,
+                "sample": f"CPU oracle, the same vector step (mode={mode}, {updates} update/step).  All {cores} host threads: OpenMP C env + "
+                          f"torch-CPU actor ({torch.get_num_threads()} threads) + NumPy learner (BLAS x{best_blas}) on {nN} envs: {nstepN} vector "
+                          f"steps = {nN * nstepN} env-steps in {dtN:.1f} s.  One thread: C env + NumPy actor/learner on a {n1}-env slice: "
+                          f"{nstep1} vector steps = {n1 * nstep1} env-steps in {dt1:.1f} s.  No per-env foreign call in any timed loop."})
     return out
 
 
@@ -390,10 +430,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Who took part: one entry per rank (device index, uuid / PCI id, host, pid) and the size of the collective group, so that "did
+    # RCCL see N distinct GPUs" is answerable from the JSON line alone.
+    census = None
+    if dist is not None:
+        import socket
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": torch.cuda.current_device(),
+              "uuid": str(getattr(pr, "uuid", None)), "pci_bus_id": getattr(pr, "pci_bus_id", None), "name": pr.name,
+              "host": socket.gethostname(), "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        census = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "ranks": gathered,
+                  "distinct_devices": len({(g["host"], g["uuid"], g["pci_bus_id"], g["device_index"]) for g in gathered})}
+
     roof = None
     cpu = None
-    if rank == 0:
+    all_ranks_pass = dist is not None and mode == "train"      # the data-parallel pass issues collectives: every rank runs it
+    if rank == 0 or all_ranks_pass:
         k = wl.kernel_pass(max(200, min(args.steps, 500)))
+    if rank == 0:
         achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes, see profiles/README.md
@@ -436,6 +492,11 @@ def main():
             "cpu_baseline": cpu,
         }
         out.update(wl.extra())
+        if census is not None:
+            out["rccl_ranks"] = census["rccl_ranks"]
+            out["collective_backend"] = census["backend"]
+            out["distinct_devices"] = census["distinct_devices"]
+            out["rank_census"] = census["ranks"]
         if mode == "train":
             out["updates_per_sec"] = args.updates * args.steps / dt      # complete replay() equivalents (B = 120)
         if mode == "group":

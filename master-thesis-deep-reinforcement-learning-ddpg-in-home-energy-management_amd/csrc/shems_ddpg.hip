@@ -1521,12 +1521,10 @@ static_assert(QG_LDS <= 160 * 1024, "one workgroup's LDS");
 
 static int set_lds_attrs()
 {
-    static bool done = false;
-    if (done) return SHEMS_OK;
-    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, QG_LDS), "attr k_fwd")) return rc;
-    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mid), hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS), "attr k_mid")) return rc;
-    if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_grad), hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS), "attr k_grad")) return rc;
-    done = true;
+    static std::atomic<uint64_t> m_fwd{0}, m_mid{0}, m_grad{0};          // per device: see lds_optin
+    if (int rc = lds_optin(m_fwd, reinterpret_cast<const void *>(&k_fwd), QG_LDS, "attr k_fwd")) return rc;
+    if (int rc = lds_optin(m_mid, reinterpret_cast<const void *>(&k_mid), MID_LDS, "attr k_mid")) return rc;
+    if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), GR_LDS, "attr k_grad")) return rc;
     return SHEMS_OK;
 }
 

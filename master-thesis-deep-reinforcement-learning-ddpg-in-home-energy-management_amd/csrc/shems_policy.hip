@@ -877,14 +877,8 @@ static int launch_act(const ActArgs &a, hipStream_t st)
     constexpr int BM = 32 * TM;
     const size_t lds = act_lds_bytes<TM, NW, RD>();
     static_assert(act_lds_bytes<TM, NW, RD>() <= 160 * 1024, "k_act: LDS image exceeds 160 KB");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (int rc = hip_ok(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_act<TM, NW, RD>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                            "hipFuncSetAttribute(k_act)"))
-            return rc;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> optin{0};                   // per device: see lds_optin
+    if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_act<TM, NW, RD>), (int)lds, "hipFuncSetAttribute(k_act)")) return rc;
     const unsigned grid = (unsigned)((a.m + BM - 1) / BM);
     hipLaunchKernelGGL((k_act<TM, NW, RD>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hip_ok(hipGetLastError(), "k_act launch");

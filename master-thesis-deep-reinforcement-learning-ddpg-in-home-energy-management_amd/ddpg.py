@@ -594,17 +594,21 @@ class TrainWorkload:
         k_act launched back to back: one rocprofv3 trace of `bench.py` shows 133.3 us per k_act inside the loop and 139.6 us for the
         same kernel in a back-to-back pass.  So the pass times groups of 8 whole vector steps [act, replay x updates] and, separately,
         groups of 8 x replay() alone; the difference per step is the act launch together with the gap in front of it.  A pair of events
-        around every single launch would add the command processor's hand-off (3-5 us) to each reading (timing.py)."""
+        around every single launch would add the command processor's hand-off (3-5 us) to each reading (timing.py).
+
+        Data parallel (world > 1): EVERY rank runs this pass, with the gradient exchange in place (the same number of collectives on
+        every rank: the group counts below do not depend on the rank), and it additionally times (i) replay() with its two all-reduces
+        (`update_us_dp`), (ii) the same split launches without the exchange (`update_us_split_local`) and (iii) each all-reduce alone on
+        a scratch tensor of the gradient's size, back to back (`allreduce_critic_us`, `allreduce_actor_us`); the figures are the MAX over
+        ranks.  The learner state is put back afterwards on every rank, so the replicas stay identical."""
         torch = self.torch
         from .timing import time_launches
         reps = min(reps, 200)
         reset = lambda g, i: self.env.reset_(self.env_seed, episode=100000 + i) if g % 8 == 0 else None     # 64 launches < one episode
-        # This pass runs on rank 0 only: no collective may be issued here (the other ranks are not in this code), so the gradient
-        # exchange is switched off for its duration; the learner state is put back afterwards, so rank 0's replica stays identical.
         snap = self.agent.snapshot()
-        saved_sync, self.agent.sync = self.agent.sync, GradSync(None)
-        world = saved_sync.world
-        self.agent.fused = world == 1                   # time the launch structure the benchmarked world size runs (minus the exchange)
+        sync = self.agent.sync
+        world = sync.world
+        self.agent.fused = world == 1                   # the launch structure the benchmarked world size runs
 
         def vector_step(i):
             self._act(i)
@@ -615,6 +619,7 @@ class TrainWorkload:
             for _ in range(self.updates):
                 self.agent.replay(self.ring)
 
+        self.dp = None
         try:
             reset(0, 0)
             for i in range(16):                          # settle into the loop's regime before the first timed group
@@ -624,15 +629,34 @@ class TrainWorkload:
                 upd_avg, upd_med, _ = time_launches(torch, updates_only, reps)
             else:
                 upd_avg = upd_med = 0.0
+            if world > 1:
+                self.agent.sync = GradSync(None)         # same 7 launches, no exchange
+                self.agent.fused = False
+                loc_avg = time_launches(torch, updates_only, reps)[0] if self.updates else 0.0
+                self.agent.sync = sync
+                gc, ga = torch.zeros_like(self.agent.grad_critic), torch.zeros_like(self.agent.grad_actor)
+                for g in (gc, ga):
+                    sync.sum_(g)
+                ar_c = time_launches(torch, lambda i: sync.sum_(gc), 64)[0]
+                ar_a = time_launches(torch, lambda i: sync.sum_(ga), 64)[0]
+                fig = torch.tensor([step_avg, step_med, upd_avg, upd_med, loc_avg, ar_c, ar_a], dtype=torch.float64, device=self.agent.device)
+                sync.dist.all_reduce(fig, op=sync.dist.ReduceOp.MAX)
+                step_avg, step_med, upd_avg, upd_med, loc_avg, ar_c, ar_a = (float(x) for x in fig.tolist())
+                per = max(1, self.updates)
+                self.dp = {"update_us_dp": upd_avg / per, "update_us_split_local": loc_avg / per, "allreduce_critic_us": ar_c,
+                           "allreduce_actor_us": ar_a, "allreduce_bytes": [4 * N_CRITIC, 4 * N_ACTOR],
+                           "exchange_us_in_update": (upd_avg - loc_avg) / per,
+                           "k_act_us_at_shard": step_avg - upd_avg, "figures": "max over ranks; HIP events over groups of 8"}
         finally:
-            self.agent.sync = saved_sync
+            self.agent.sync = sync
             self.agent.restore(snap)
         self.update_us = upd_avg / self.updates if self.updates else None
         self.step_us_in_pass = step_avg
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
         return dict(kernel="shems::k_act<TM>", avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
-                    method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)")
+                    method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
+                           + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))
 
     def extra(self):
         import zlib
@@ -640,7 +664,7 @@ class TrainWorkload:
         return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "overlap": self.overlap,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
-                "update_mflop": 307.8}
+                "update_mflop": 307.8, "data_parallel": getattr(self, "dp", None)}
 
 
 def smoke():

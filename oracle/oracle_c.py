@@ -70,6 +70,21 @@ def lib():
     L.orc_env_get_state.restype = None
     L.orc_env_set_state.argtypes = [vp, vp, i64, i64]
     L.orc_env_set_state.restype = None
+    L.orc_batch_init.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
+    L.orc_batch_init.restype = None
+    L.orc_batch_reset.argtypes = [vp, i64, C.c_int, vp, vp]
+    L.orc_batch_get_state.argtypes = [vp, i64, vp]
+    L.orc_batch_get_state.restype = None
+    L.orc_batch_set_state.argtypes = [vp, i64, vp, vp, vp]
+    L.orc_batch_set_state.restype = None
+    L.orc_batch_get_idx.argtypes = [vp, i64, vp, vp]
+    L.orc_batch_get_idx.restype = None
+    L.orc_batch_action_drl.argtypes = [vp, i64, vp, vp]
+    L.orc_batch_action_drl.restype = None
+    L.orc_batch_action_rule.argtypes = [vp, i64, vp]
+    L.orc_batch_action_rule.restype = None
+    L.orc_scale_actions.argtypes = [vp, i64, vp]
+    L.orc_scale_actions.restype = None
     _lib = L
     return L
 
@@ -88,7 +103,7 @@ def profile(charger_id=98, disc_weight=None, disc_pot=None, penalty_weight=None)
 
 
 class Batch:
-    """n scalar oracle envs sharing tables (kept alive here)."""
+    """n scalar oracle envs sharing tables (kept alive here).  Every accessor is ONE foreign call for the whole batch."""
 
     def __init__(self, n, maxsteps, tables, profiles, table_of_env=None, profile_of_env=None):
         L = lib()
@@ -97,12 +112,13 @@ class Batch:
         self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in (tables if isinstance(tables, (list, tuple)) else [tables])]
         self.profiles = list(profiles) if isinstance(profiles, (list, tuple)) else [profiles]
         self.ptr = L.orc_batch_alloc(self.n)
-        to = np.zeros(self.n, np.int64) if table_of_env is None else np.asarray(table_of_env)
-        po = np.zeros(self.n, np.int64) if profile_of_env is None else np.asarray(profile_of_env)
-        for i in range(self.n):
-            t = self.tables[int(to[i])]
-            L.orc_env_init(L.orc_batch_at(self.ptr, i), self.maxsteps, t.ctypes.data, t.shape[0],
-                           C.byref(self.profiles[int(po[i])]))
+        tptr = (C.c_void_p * len(self.tables))(*[t.ctypes.data for t in self.tables])
+        nrows = np.array([t.shape[0] for t in self.tables], np.int64)
+        profs = (Profile * len(self.profiles))(*self.profiles)
+        to = None if table_of_env is None else np.ascontiguousarray(table_of_env, dtype=np.int64)
+        po = None if profile_of_env is None else np.ascontiguousarray(profile_of_env, dtype=np.int64)
+        L.orc_batch_init(self.ptr, self.n, self.maxsteps, tptr, nrows.ctypes.data, None if to is None else to.ctypes.data,
+                         profs, None if po is None else po.ctypes.data)
 
     def __del__(self):
         try:
@@ -114,49 +130,44 @@ class Batch:
         return lib().orc_batch_at(self.ptr, i)
 
     def reset(self, rng_is_minus1=True, idx0=None, soc_b0=None):
-        L = lib()
-        rc = 0
-        for i in range(self.n):
-            rc |= L.orc_reset(self.at(i), 1 if rng_is_minus1 else 0,
-                              1 if idx0 is None else int(idx0[i]),
-                              0.0 if soc_b0 is None else float(np.float32(soc_b0[i])))
-        return rc
+        i0 = None if idx0 is None else np.ascontiguousarray(idx0, dtype=np.int64)
+        s0 = None if soc_b0 is None else np.ascontiguousarray(soc_b0, dtype=np.float32)
+        assert (i0 is None or i0.shape == (self.n,)) and (s0 is None or s0.shape == (self.n,))
+        return lib().orc_batch_reset(self.ptr, self.n, 1 if rng_is_minus1 else 0, None if i0 is None else i0.ctypes.data,
+                                     None if s0 is None else s0.ctypes.data)
 
     def set_state(self, obs, idx, step=None):
-        L = lib()
         obs = np.ascontiguousarray(obs, dtype=np.float32)
-        for i in range(self.n):
-            L.orc_env_set_state(self.at(i), obs[i].ctypes.data, int(idx[i]), 0 if step is None else int(step[i]))
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        st = None if step is None else np.ascontiguousarray(step, dtype=np.int64)
+        assert obs.shape == (self.n, 9) and idx.shape == (self.n,)
+        lib().orc_batch_set_state(self.ptr, self.n, obs.ctypes.data, idx.ctypes.data, None if st is None else st.ctypes.data)
 
-    def state(self):
-        L = lib()
-        out = np.empty((self.n, 9), np.float32)
-        for i in range(self.n):
-            L.orc_env_get_state(self.at(i), out[i].ctypes.data)
+    def state(self, out=None):
+        out = np.empty((self.n, 9), np.float32) if out is None else out
+        lib().orc_batch_get_state(self.ptr, self.n, out.ctypes.data)
         return out
 
     def idx(self):
-        L = lib()
-        return np.array([L.orc_env_idx(self.at(i)) for i in range(self.n)], np.int64)
+        out = np.empty(self.n, np.int64)
+        lib().orc_batch_get_idx(self.ptr, self.n, out.ctypes.data, None)
+        return out
 
     def steps(self):
-        L = lib()
-        return np.array([L.orc_env_step(self.at(i)) for i in range(self.n)], np.int64)
+        out = np.empty(self.n, np.int64)
+        lib().orc_batch_get_idx(self.ptr, self.n, None, out.ctypes.data)
+        return out
 
     def action_drl(self, targets):
-        L = lib()
-        targets = np.asarray(targets, np.float32)
+        targets = np.ascontiguousarray(targets, dtype=np.float32)
+        assert targets.shape == (self.n, 2)
         out = np.empty((self.n, 2), np.float32)
-        for i in range(self.n):
-            L.orc_action_drl(self.at(i), float(targets[i, 0]), float(targets[i, 1]),
-                             out[i].ctypes.data_as(C.POINTER(C.c_float)))
+        lib().orc_batch_action_drl(self.ptr, self.n, targets.ctypes.data, out.ctypes.data)
         return out
 
     def action_rule(self):
-        L = lib()
         out = np.empty((self.n, 2), np.float32)
-        for i in range(self.n):
-            L.orc_action_rule(self.at(i), out[i].ctypes.data_as(C.POINTER(C.c_float)))
+        lib().orc_batch_action_rule(self.ptr, self.n, out.ctypes.data)
         return out
 
     def step(self, actions, track_mode=0, want_results=False, omp=False):
@@ -197,5 +208,7 @@ def resolve_start(table, maxsteps, idx0):
 
 
 def scale_action(a):
-    a = np.asarray(a, np.float32)
-    return np.array([lib().orc_scale_action(float(x)) for x in a.ravel()], np.float32).reshape(a.shape)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty_like(a)
+    lib().orc_scale_actions(a.ctypes.data, a.size, out.ctypes.data)
+    return out

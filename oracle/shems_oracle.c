@@ -495,3 +495,38 @@ int64_t  orc_env_step(const orc_env *e) { return e->step; }
 void     orc_env_get_state(const orc_env *e, float *out9) { memcpy(out9, e->state, sizeof(float) * ORC_NSTATE); }
 void     orc_env_set_state(orc_env *e, const float *in9, int64_t idx, int64_t step)
 { memcpy(e->state, in9, sizeof(float) * ORC_NSTATE); e->idx = idx; e->step = step; }
+
+/* Whole-batch forms of the accessors above: ONE foreign call per batch, so that a timed loop (bench.py's cpu_baseline) or a
+ * parity test never pays a Python/ctypes round trip per env.  NULL idx0/soc_b0 = (1, 0.f) for every env; NULL step = 0. */
+void orc_batch_init(orc_env *envs, int64_t n, int64_t maxsteps, const float *const *tables, const int64_t *nrows,
+                    const int64_t *table_of_env, const orc_profile *profiles, const int64_t *profile_of_env)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t t = table_of_env ? table_of_env[i] : 0, p = profile_of_env ? profile_of_env[i] : 0;
+        orc_env_init(&envs[i], maxsteps, tables[t], nrows[t], &profiles[p]);
+    }
+}
+int orc_batch_reset(orc_env *envs, int64_t n, int rng_is_minus1, const int64_t *idx0, const float *soc_b0)
+{
+    int rc = 0;
+    for (int64_t i = 0; i < n; ++i)
+        rc |= orc_reset(&envs[i], rng_is_minus1, idx0 ? idx0[i] : 1, soc_b0 ? soc_b0[i] : 0.f);
+    return rc;
+}
+void orc_batch_get_state(const orc_env *envs, int64_t n, float *obs_out)
+{ for (int64_t i = 0; i < n; ++i) memcpy(obs_out + ORC_NSTATE * i, envs[i].state, sizeof(float) * ORC_NSTATE); }
+void orc_batch_set_state(orc_env *envs, int64_t n, const float *obs, const int64_t *idx, const int64_t *step)
+{ for (int64_t i = 0; i < n; ++i) orc_env_set_state(&envs[i], obs + ORC_NSTATE * i, idx[i], step ? step[i] : 0); }
+void orc_batch_get_idx(const orc_env *envs, int64_t n, int64_t *idx_out, int64_t *step_out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (idx_out) idx_out[i] = envs[i].idx;
+        if (step_out) step_out[i] = envs[i].step;
+    }
+}
+void orc_batch_action_drl(const orc_env *envs, int64_t n, const float *targets, float *out)
+{ for (int64_t i = 0; i < n; ++i) orc_action_drl(&envs[i], targets[2 * i], targets[2 * i + 1], out + 2 * i); }
+void orc_batch_action_rule(const orc_env *envs, int64_t n, float *out)
+{ for (int64_t i = 0; i < n; ++i) orc_action_rule(&envs[i], out + 2 * i); }
+void orc_scale_actions(const float *a, int64_t count, float *out)                 /* scale_action over a whole array */
+{ for (int64_t i = 0; i < count; ++i) out[i] = orc_scale_action(a[i]); }

@@ -119,6 +119,17 @@ int64_t  orc_env_step(const orc_env *e);
 void     orc_env_get_state(const orc_env *e, float *out9);
 void     orc_env_set_state(orc_env *e, const float *in9, int64_t idx, int64_t step);
 
+/* Whole-batch accessors (one call per batch; NULL idx0/soc_b0 -> (1, 0.f), NULL step -> 0). */
+void orc_batch_init(orc_env *envs, int64_t n, int64_t maxsteps, const float *const *tables, const int64_t *nrows,
+                    const int64_t *table_of_env /* or NULL */, const orc_profile *profiles, const int64_t *profile_of_env /* or NULL */);
+int  orc_batch_reset(orc_env *envs, int64_t n, int rng_is_minus1, const int64_t *idx0, const float *soc_b0);
+void orc_batch_get_state(const orc_env *envs, int64_t n, float *obs_out /* [n][9] */);
+void orc_batch_set_state(orc_env *envs, int64_t n, const float *obs, const int64_t *idx, const int64_t *step);
+void orc_batch_get_idx(const orc_env *envs, int64_t n, int64_t *idx_out, int64_t *step_out);
+void orc_batch_action_drl(const orc_env *envs, int64_t n, const float *targets /* [n][2] */, float *out /* [n][2] */);
+void orc_batch_action_rule(const orc_env *envs, int64_t n, float *out /* [n][2] */);
+void orc_scale_actions(const float *a, int64_t count, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,34 @@ def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
         T.load_csv(tmp_path / "bad.csv")
 
 
+_C_SCALARS = {"int": "Cint", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint32_t": "UInt32", "uint16_t": "UInt16",
+              "uint8_t": "UInt8", "float": "Float32", "double": "Float64", "shems_config": "ShemsConfig", "void": "Cvoid",
+              "shems_env": "Cvoid"}
+
+
+def _julia_types_for(c_arg):
+    """The Julia ccall argument types that are ABI-identical to one C parameter declaration (name stripped).  `T *` accepts Ptr{T}
+    and Ref{T}; an opaque `shems_env *` is Ptr{Cvoid}, `shems_env **` Ptr{Ptr{Cvoid}}."""
+    import re
+    c = re.sub(r"/\*.*?\*/", "", c_arg).replace("const", " ").strip()
+    m = re.match(r"^(\w+)\s*(\*{0,2})\s*(\w*)$", c)
+    assert m, c_arg
+    base, stars = _C_SCALARS[m.group(1)], len(m.group(2))
+    if stars == 0:
+        return {base}
+    inner = base if stars == 1 else f"Ptr{{{base}}}"
+    return {f"Ptr{{{inner}}}", f"Ref{{{inner}}}"}
+
+
+def test_julia_type_mapping_rejects_wrong_widths():
+    assert _julia_types_for("int32_t maxsteps") == {"Int32"} and _julia_types_for("int device") == {"Cint"}
+    assert "Int64" not in _julia_types_for("int32_t n_cfg") and "Int32" not in _julia_types_for("int track_mode")
+    assert _julia_types_for("const uint16_t *cfg_of_env") == {"Ptr{UInt16}", "Ref{UInt16}"}
+    assert _julia_types_for("shems_env **out") == {"Ptr{Ptr{Cvoid}}", "Ref{Ptr{Cvoid}}"}
+    assert _julia_types_for("shems_env *env") == {"Ptr{Cvoid}", "Ref{Cvoid}"}
+    assert _julia_types_for("const shems_config *cfgs") == {"Ptr{ShemsConfig}", "Ref{ShemsConfig}"}
+
+
 def test_julia_module_binds_only_declared_entry_points(built_lib):
     """julia/ShemsEnv_LU1.jl cannot be executed here (no Julia); what CAN be checked statically: every `ccall((:symbol, LIB), ...)` names
     an entry point that include/shems_hip.h declares and libshems_hip.so exports, with the argument count of the declaration; the
@@ -111,9 +139,15 @@ def test_julia_module_binds_only_declared_entry_points(built_lib):
         assert hasattr(L, name), name
         m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
         assert m, f"{name} is not declared in include/shems_hip.h"
-        n_decl = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
-        n_call = 0 if not args.strip() else len([a for a in args.split(",") if a.strip()])
-        assert n_decl == n_call, (name, n_decl, n_call)
+        decl = [] if m.group(1).strip() in ("", "void") else [a.strip() for a in m.group(1).split(",")]
+        call = [a.strip() for a in args.split(",") if a.strip()]
+        assert len(decl) == len(call), (name, decl, call)
+        # argument WIDTHS, position by position: the likeliest defect of a never-executed binding is a wrong integer width or pointee
+        # in the ccall tuple (Int32 vs Cint vs Int64, Ptr{UInt16} vs Ptr{Int32}), which would still pass a count check
+        for pos, (c_arg, j_arg) in enumerate(zip(decl, call)):
+            assert j_arg in _julia_types_for(c_arg), (name, pos, c_arg, j_arg)
+        c_ret = re.search(r"(const char \*|int)\s*" + name + r"\s*\(", hdr).group(1).strip()
+        assert ret == {"int": "Cint", "const char *": "Cstring"}[c_ret], (name, c_ret, ret)
     for needed in ("struct ShemsConfig", "mutable struct ShemsAction", "Base.minimum(::ShemsAction) = (0f0, 0f0)", "Base.maximum(::ShemsAction) = (1f0, 1f0)",
                    "function reset!(env::Shems; rng=0)", "function step!(env::Shems, s, a; track=0)", "function action(env::Shems, a::ShemsAction)",
                    "function action(env::Shems, track::Real=-1)", "finished(env::Shems, s′) = false", "using Distributions: Uniform", "using Random",

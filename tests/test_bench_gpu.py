@@ -54,6 +54,22 @@ def test_two_rank_data_parallel_rehearsal():
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--envs", "4096"],
              env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["value"] > 0
+    _check_data_parallel_fields(d, 2)
+
+
+def _check_data_parallel_fields(d, world):
+    """The N > 1 line must explain itself: who took part, what the exchange cost, what the shard-sized k_act does."""
+    assert d["rccl_ranks"] == world and d["collective_backend"] in ("nccl", "gloo")
+    cen = d["rank_census"]
+    assert sorted(c["rank"] for c in cen) == list(range(world)) and all("uuid" in c and "device_index" in c and "pid" in c for c in cen)
+    assert len({c["pid"] for c in cen}) == world                       # one process per rank
+    assert d["distinct_devices"] == 1                                   # the rehearsal puts every rank on device 0 -- and the line says so
+    dp = d["data_parallel"]
+    for k in ("update_us_dp", "update_us_split_local", "allreduce_critic_us", "allreduce_actor_us", "k_act_us_at_shard", "exchange_us_in_update"):
+        assert dp[k] is not None and dp[k] == dp[k], k
+    assert dp["update_us_dp"] > dp["update_us_split_local"] > 10.0     # the exchange is inside the first and not the second
+    assert dp["allreduce_critic_us"] > 0 and dp["allreduce_actor_us"] > 0 and dp["allreduce_bytes"] == [516004, 516008]
+    assert abs(d["update_us"] - dp["update_us_dp"]) < 1e-6 and d["roofline"]["kernel_avg_us"] > 0
 
 
 def test_bench_starts_its_own_ranks_without_torchrun():
@@ -73,6 +89,7 @@ def test_bench_starts_its_own_ranks_without_torchrun():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["cpu_baseline"] is None and d["value"] > 0
     assert d["updates_per_sec"] > 0 and d["roofline"]["frac"] > 0
+    _check_data_parallel_fields(d, 2)
 
 
 def test_async_gradient_exchange_gives_the_same_bytes():

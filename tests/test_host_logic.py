@@ -43,3 +43,25 @@ def test_bench_rejects_mismatched_world_size():
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=U.ROOT, env=e,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
+
+
+def test_cpu_baseline_times_the_port_not_python():
+    """bench.py's cpu_baseline leg: both figures (all cores / one thread) with the thread counts stated, and no per-env foreign
+    call in a timed loop (the batch accessors of oracle_c are single C calls)."""
+    import importlib.util
+    import inspect
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(U.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = inspect.getsource(bench.cpu_baseline)
+    assert "b.at(" not in src and "orc_env_get_state" not in src and "orc_reset(" not in src
+    import oracle_c
+    for name in ("reset", "state", "set_state", "idx", "steps", "action_drl", "action_rule"):
+        body = inspect.getsource(getattr(oracle_c.Batch, name))
+        assert "for i in range" not in body, name
+    out = bench.cpu_baseline(2048, "train", 1, scale=0.08)
+    assert out["kind"] == "port" and out["cores"] == (os.cpu_count() or 1) and out["value"] > 0 and out["one_thread_value"] > 0
+    assert out["updates_per_sec"] > 0 and out["one_thread_updates_per_sec"] > 0 and "learner_blas_threads" in out
+    assert out["env_only_all_cores_value"] > 0 and out["env_only_value"] > 0
+    e = bench.cpu_baseline(2048, "env", 0, scale=0.08)
+    assert e["value"] == e["env_only_all_cores_value"] and e["one_thread_value"] == e["env_only_value"]
