@@ -144,8 +144,9 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
     env batch is stepped, reset and read with ONE C call each (orc_batch_step[_omp] with obs_out, orc_batch_reset).
 
       value / cores            the FULL vector step (act + Gaussian noise + scale_action + step! + remember [+ `updates` x replay()])
-                               on ALL host cores: OpenMP env step, actor forward on torch's CPU thread pool, NumPy learner with
-                               the BLAS thread count that is fastest for B = 120 on this box (measured here, reported)
+                               on ALL usable host cores: one OpenMP region per step takes blocks of 32 households through actor,
+                               noise, scale_action and step! (oracle/shems_policy_omp.c); NumPy learner with the BLAS thread
+                               count that is fastest for B = 120 on this box (measured here, reported)
       one_thread_value         the same step on ONE thread (C env, NumPy actor + learner, BLAS capped at 1) on a 4096-env slice
       env_only_*               step! alone, one thread / all cores (whole episodes per OpenMP region)
       update_only_per_sec      replay() alone at each BLAS thread count tried
@@ -154,13 +155,13 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
     import numpy as np
     import oracle_c
     import ddpg_oracle as DO
-    import torch
     from threadpoolctl import threadpool_limits
     S = importlib.import_module(PKG)
     tab = S.tables.synthetic_table("train", 98)
     rng = np.random.default_rng(0)
     L = oracle_c.lib()
-    cores = os.cpu_count() or 1
+    cores = oracle_c.usable_cpus()                 # affinity mask / cgroup quota, not the CPUs merely visible
+    oracle_c.set_threads(cores)
 
     def env_batch(n):
         b = oracle_c.Batch(n, EP_LEN, tab, oracle_c.profile(98))
@@ -229,7 +230,7 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
             learner.replay(ring["s"][i], ring["a"][i], ring["r"][i], ring["s2"][i], ring["d"][i])
         return nrep / (time.perf_counter() - t1)
 
-    def full_step_loop(n, budget, env_step, policy, blas_threads):
+    def full_step_loop(n, budget, env_step, policy, blas_threads, fused=None):
         """`budget` seconds of whole vector steps on an n-env batch; returns (vector steps, seconds)."""
         b, idx0, soc0 = env_batch(n)
         b.reset(False, idx0, soc0)
@@ -243,9 +244,13 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
         with threadpool_limits(limits=blas_threads):
             nstep, pos, t0 = 0, 0, time.perf_counter()
             while time.perf_counter() - t0 < budget or nstep < 2:
-                a = policy(learner.actor, s, s_min, s_max, nstep)                                  # actor + Gaussian noise + clamp
-                L.orc_scale_actions(a.ctypes.data, a.size, sc.ctypes.data)                         # scale_action, one call
-                env_step(b.ptr, n, sc.ctypes.data, 0, rew.ctypes.data, s2.ctypes.data)             # step!, s' written by the same call
+                if fused is not None:
+                    a = sc
+                    fused(b.ptr, n, learner.actor, s, s_min, s_max, nstep, a, rew, s2)             # everything up to s', one call
+                else:
+                    a = policy(learner.actor, s, s_min, s_max, nstep)                              # actor + Gaussian noise + clamp
+                    L.orc_scale_actions(a.ctypes.data, a.size, sc.ctypes.data)                     # scale_action, one call
+                    env_step(b.ptr, n, sc.ctypes.data, 0, rew.ctypes.data, s2.ctypes.data)         # step!, s' written by the same call
                 sl = (pos + np.arange(win)) % cap                                                  # remember(): rotating window
                 ring["s"][sl], ring["a"][sl], ring["r"][sl], ring["s2"][sl] = s[:win], a[:win], rew[:win], s2[:win]
                 pos += win
@@ -280,29 +285,21 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
     else:
         best_blas = 1
 
-    # (c) ALL cores: OpenMP env step over the whole batch, actor forward + noise on torch's CPU thread pool (GEMMs and the
-    # elementwise work both threaded), learner as above with the best BLAS thread count
-    W = [torch.from_numpy(x.copy()) for x in DO.split(actor, 9, 2)]
-
-    def torch_policy(act_p, s, lo, hi, k):
-        with torch.no_grad():
-            W1, b1, W2, b2, W3, b3 = [torch.from_numpy(x) for x in DO.split(act_p, 9, 2)]
-            x = (torch.from_numpy(s) - torch.from_numpy(lo)) / ((torch.from_numpy(hi) - torch.from_numpy(lo)) + 1e-8)
-            h = torch.relu_(torch.addmm(b1, x, W1))
-            h = torch.relu_(torch.addmm(b2, h, W2))
-            a = torch.tanh_(torch.addmm(b3, h, W3))
-            a.add_(torch.randn_like(a), alpha=0.1).clamp_(-1.0, 1.0)
-            return a.numpy()
-    stepN = lambda ptr, n, a, tm, r, o: L.orc_batch_step_omp(ptr, n, a, tm, r, o)
+    # (c) ALL cores: the whole vector step (normalize + actor + noise + clamp + scale_action + step!) in ONE OpenMP region per step
+    # (oracle/shems_policy_omp.c: a thread takes blocks of 32 households through all of it), learner as above with the best BLAS
+    # thread count.  `policy` = None tells the loop that the env step is part of the fused call.
+    def fused_step(ptr, n, learner_actor, s, lo, hi, k, a_out, rew, s2):
+        return L.orc_policy_step_omp(ptr, n, learner_actor.ctypes.data, lo.ctypes.data, hi.ctypes.data, 0.1, 1, k & 0xFFFFFFFF, 1,
+                                     s.ctypes.data, a_out.ctypes.data, rew.ctypes.data, s2.ctypes.data)
     nN = n_envs
-    nstepN, dtN, _, _ = full_step_loop(nN, 6.0 * scale, stepN, torch_policy, best_blas)
+    nstepN, dtN, _, _ = full_step_loop(nN, 6.0 * scale, None, None, best_blas, fused=fused_step)
     all_cores = nN * nstepN / dtN
     out.update({"value": all_cores, "unit": "env-steps/s", "cores": cores, "kind": "port",
                 "updates_per_sec": (updates * nstepN / dtN) if mode == "train" else None,
                 "one_thread_value": one_thread, "one_thread_updates_per_sec": (updates * nstep1 / dt1) if mode == "train" else None,
-                "torch_cpu_threads": torch.get_num_threads(), "learner_blas_threads": best_blas,
-                "sample": f"CPU oracle, the same vector step (mode={mode}, {updates} update/step).  All {cores} host threads: OpenMP C env + "
-                          f"torch-CPU actor ({torch.get_num_threads()} threads) + NumPy learner (BLAS x{best_blas}) on {nN} envs: {nstepN} vector "
+                "visible_cpus": os.cpu_count(), "learner_blas_threads": best_blas,
+                "sample": f"CPU oracle, the same vector step (mode={mode}, {updates} update/step).  All {cores} usable host threads: the fused "
+                          f"C/OpenMP step (actor + noise + scale_action + step!, shems_policy_omp.c) + NumPy learner (BLAS x{best_blas}) on {nN} envs: {nstepN} vector "
                           f"steps = {nN * nstepN} env-steps in {dtN:.1f} s.  One thread: C env + NumPy actor/learner on a {n1}-env slice: "
                           f"{nstep1} vector steps = {n1 * nstep1} env-steps in {dt1:.1f} s.  No per-env foreign call in any timed loop."})
     return out

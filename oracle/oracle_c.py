@@ -21,7 +21,7 @@ class Profile(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("shems_oracle.c", "shems_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("shems_oracle.c", "shems_policy_omp.c", "shems_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "libshems_oracle.so"])
@@ -85,8 +85,33 @@ def lib():
     L.orc_batch_action_rule.restype = None
     L.orc_scale_actions.argtypes = [vp, i64, vp]
     L.orc_scale_actions.restype = None
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads.restype = None
+    L.orc_policy_step_omp.argtypes = [vp, i64, vp, vp, vp, C.c_float, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
+
+
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def profile(charger_id=98, disc_weight=None, disc_pot=None, penalty_weight=None):
@@ -192,6 +217,21 @@ class Batch:
         ret = np.empty(self.n, np.float64)
         rc = lib().orc_batch_episode_omp(self.ptr, self.n, a.ctypes.data, a.shape[0], int(nsteps), track_mode, ret.ctypes.data)
         return rc, ret
+
+    def policy_step_omp(self, actor, s_min, s_max, obs, sigma=0.1, seed=0, tick=0, train=True):
+        """The whole vector step (normalize + actor + noise + clamp + scale_action + step!) on all host cores in one OpenMP region
+        (shems_policy_omp.c; throughput baseline).  Returns (rc, a [n][2] unscaled, rewards [n], obs' [n][9])."""
+        actor = np.ascontiguousarray(actor, dtype=np.float32)
+        lo, hi = np.ascontiguousarray(s_min, dtype=np.float32), np.ascontiguousarray(s_max, dtype=np.float32)
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        assert actor.size == 129002 and obs.shape == (self.n, 9)
+        a = np.empty((self.n, 2), np.float32)
+        rew = np.empty(self.n, np.float64)
+        out = np.empty((self.n, 9), np.float32)
+        rc = lib().orc_policy_step_omp(self.ptr, self.n, actor.ctypes.data, lo.ctypes.data, hi.ctypes.data, float(sigma), int(seed),
+                                       int(tick) & 0xFFFFFFFF, 1 if train else 0, obs.ctypes.data, a.ctypes.data, rew.ctypes.data,
+                                       out.ctypes.data)
+        return rc, a, rew, out
 
     def rule_episode(self, i, steps, want_results=False):
         L = lib()

@@ -60,8 +60,37 @@ def test_cpu_baseline_times_the_port_not_python():
         body = inspect.getsource(getattr(oracle_c.Batch, name))
         assert "for i in range" not in body, name
     out = bench.cpu_baseline(2048, "train", 1, scale=0.08)
-    assert out["kind"] == "port" and out["cores"] == (os.cpu_count() or 1) and out["value"] > 0 and out["one_thread_value"] > 0
+    assert out["kind"] == "port" and out["cores"] == oracle_c.usable_cpus() and out["value"] > 0 and out["one_thread_value"] > 0
     assert out["updates_per_sec"] > 0 and out["one_thread_updates_per_sec"] > 0 and "learner_blas_threads" in out
     assert out["env_only_all_cores_value"] > 0 and out["env_only_value"] > 0
     e = bench.cpu_baseline(2048, "env", 0, scale=0.08)
     assert e["value"] == e["env_only_all_cores_value"] and e["one_thread_value"] == e["env_only_value"]
+
+
+def test_all_cores_fused_step_agrees_with_the_oracle():
+    """oracle/shems_policy_omp.c (the all-cores leg of bench.py's cpu_baseline) is a throughput baseline, but it must compute the
+    same vector step: its actions within float rounding of ddpg_oracle.act (same Philox noise stream), and -- given those actions --
+    rewards and next states bit-identical to the scalar oracle's step!.  A ragged batch size exercises the block tails."""
+    import oracle_c
+    import ddpg_oracle as DO
+    T = U.tables_mod()
+    tab = T.synthetic_table("train", 98)
+    n = 1000 + 27
+    rng = np.random.default_rng(3)
+    a, b = (oracle_c.Batch(n, 72, tab, oracle_c.profile(98)) for _ in range(2))
+    idx0 = rng.integers(1, tab.shape[0] - 72 + 1, n)
+    soc0 = (rng.random(n) * 6.75).astype(np.float32)
+    assert a.reset(False, idx0, soc0) == 0 and b.reset(False, idx0, soc0) == 0
+    actor = DO.init_params(77, 9, 2, 0)
+    actor[-1004:-2] *= 60.0                                   # W3 of the fresh init is +-3e-3: make the outputs span [-1, 1]
+    s = a.state()
+    lo, hi = s.min(0), s.max(0)
+    for tick in range(3):
+        rc, act, rew, s2 = a.policy_step_omp(actor, lo, hi, s, sigma=0.1, seed=9, tick=tick, train=True)
+        want = DO.act(actor, s, lo, hi, True, seed=9, tick=tick)
+        assert rc == 0 and np.abs(act - want).max() < 2e-6 and np.abs(act).max() <= 1.0 and np.abs(act).mean() > 0.1
+        rc2, rew2, s2b, _ = b.step(oracle_c.scale_action(act), 0)
+        assert rc2 == 0 and (rew.view(np.uint64) == rew2.view(np.uint64)).all() and (s2.view(np.uint32) == s2b.view(np.uint32)).all()
+        s = s2
+    rc, act, _, _ = a.policy_step_omp(actor, lo, hi, s, train=False)
+    assert np.abs(act - DO.act(actor, s, lo, hi, False)).max() < 2e-6
