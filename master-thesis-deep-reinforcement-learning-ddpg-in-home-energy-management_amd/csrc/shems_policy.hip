@@ -42,12 +42,33 @@ namespace shems {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int N> struct FVec { typedef float type __attribute__((ext_vector_type(N))); };
 template <> struct FVec<1> { typedef float type; };
 template <int N> __device__ __forceinline__ float fvec_get(const typename FVec<N>::type &v, int i) { return v[i]; }
 template <> __device__ __forceinline__ float fvec_get<1>(const float &v, int) { return v; }
 
 constexpr int kIn = 9, kH1 = SHEMS_L1, kH2 = SHEMS_L2, kOut = 2;
+
+// CANONICAL COLUMN ORDER of layer 2 / layer 3 (every form of the kernel follows it, so all forms write the same bytes):
+// the 512 (padded) hidden-2 columns are 8 GROUPS of 64; a group is two MFMA tiles, tile a in {0, 1} of group g holding the columns
+// n = 64 g + 2 i + a (i = MFMA row).  Layer 3 is summed per tile (one FMA chain over a lane's 16 rows), a lane adds the chains of the
+// group's two tiles, the two lane halves are added; the group sums of each column HALF are added in order, H0 = ((g0 + g1) + g2) + g3,
+// H1 = ((g4 + g5) + g6) + g7, and the output is b3 + (H0 + H1).  A wave that owns NA tiles
+// owns NA / 2 consecutive groups; the weights a lane needs for a k-step are 8 contiguous bytes per group (one ds_read2_b64 for two
+// groups).  Because the order is defined on groups, a group can be computed by any wave of any workgroup: the 8-wave and the
+// column-split (two workgroups per env tile) forms below produce the bits of the 4-wave forms.
+template <int NA> __device__ __forceinline__ int act_col(int nbase, int t, int row) { return nbase + 64 * (t >> 1) + 2 * row + (t & 1); }
+template <int NA> __device__ __forceinline__ typename FVec<NA>::type act_load_a(const float *row_at_nbase, int li);
+template <> __device__ __forceinline__ FVec<4>::type act_load_a<4>(const float *p, int li)
+{
+    const f32x2 x = *reinterpret_cast<const f32x2 *>(p + 2 * li), y = *reinterpret_cast<const f32x2 *>(p + 64 + 2 * li);
+    return FVec<4>::type{x[0], x[1], y[0], y[1]};
+}
+template <> __device__ __forceinline__ FVec<2>::type act_load_a<2>(const float *p, int li)
+{
+    return *reinterpret_cast<const f32x2 *>(p + 2 * li);
+}
 constexpr int kKC = 16;                         // k-rows per staged W2 chunk (8 MFMA k-steps)
 constexpr int kChunks = 16;                     // K = 250 padded to 256: the padded rows of layer 1 are exactly 0
 constexpr int kWcFloats = 8192 + 16;             // 32 whole 1-KiB LDS-DMA pieces (16 rows = 8000 floats, + 192 of the next row) + read pad
@@ -103,7 +124,7 @@ template <int TM, int NW, int RD = 0>
 constexpr size_t act_lds_bytes()
 {
     return sizeof(float) * ((RD ? NW * RD * kFreeChunkFloats + 16 : 2 * kWcFloats) + act_h_rows(TM, RD) * 32 * TM + kW1K * 32 * TM + kW1K * kW1C +
-                            (kTailFloats + 2) + NW * 32 * TM * kOut + 32 * TM * kIn + (act_tail_pre(TM, RD) ? 32 * TM * kPreDw : 0));
+                            (kTailFloats + 2) + 32 * TM * kIn + (act_tail_pre(TM, RD) ? 32 * TM * kPreDw : 0));
 }
 
 __device__ __forceinline__ void glds16(const void *g, void *lds)
@@ -133,6 +154,23 @@ __device__ __forceinline__ void glds16_piece(const char *base, char *lds, int q)
     case 6: glds16_imm<6>(base, lds); break;
     default: glds16_imm<7>(base, lds); break;
     }
+}
+
+// LDS-DMA as an asm statement (k_actg).  Given the builtin, the compiler books a global_load_lds as a FLAT access that may touch LDS
+// and VMEM both, and while one is pending every later LDS dependency is waited for with lgkmcnt(0) (and VMEM ones with vmcnt(0)): the
+// operand reads of the NEXT k-steps, just issued, are waited for too.  Issued from asm the piece is invisible to that bookkeeping (its
+// completion is counted by hand: the s_waitcnt vmcnt(N) of the chunk loops), the compiler's own waits stay exact, and any vmcnt wait it
+// emits for its own loads can only be stricter than needed, never weaker (the counter retires in issue order).  M0 = LDS base, written
+// in the same statement that reads it (the compiler does not preserve M0 across statements and uses it for nothing else here).
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+template <int IMM>
+__device__ __forceinline__ void glds16_asm(const char *sbase, uint32_t voff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(voff), "s"(sbase), "s"(lds_base), "i"(IMM) : "memory");
 }
 
 // Standard-normal pair from one Philox block (Box-Muller, f32).
@@ -358,8 +396,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     float *xT = Hc + HR * BM;                                // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
     float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
     float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
-    float *red = tl + (kTailFloats + 2);                     // [4 waves][BM][2]
-    float *xR = red + NW * BM * kOut;                        // [BM][9]   the raw observations stage 0 loaded: step! starts from these, not from a
+    // Layer-3 group sums [8 column groups][BM][2]: kept over the W2 stream, which is dead by then -- a wave's groups at the start of
+    // ITS OWN ring (free-running form: nobody else touches it) / of its slice of the shared double buffer (dead for everybody after the
+    // last chunk's barrier).  red_of(g) = where the owner of group g put it.
+    constexpr int kRedStride = RD ? RD * kFreeChunkFloats : (16 / NW / 2) * BM * kOut;
+    static_assert((16 / NW / 2) * BM * kOut <= (RD ? RD * kFreeChunkFloats : 2 * kWcFloats / NW), "group sums fit the dead W2 buffer");
+#define RED_OF(g) (Wc + ((g) / (NA / 2)) * kRedStride + ((g) % (NA / 2)) * (BM * kOut))
+    float *xR = tl + (kTailFloats + 2);                        // [BM][9]   the raw observations stage 0 loaded: step! starts from these, not from a
                                                              //           second (stride-36-byte) read of global memory at the end of the kernel
     [[maybe_unused]] float *xP = xR + BM * kIn;              // PRE: [BM][kPreDw] TailPre blocks
 
@@ -639,9 +682,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 
     // ---- layer 2: 128 k-steps of 4 x TM MFMA tiles per wave ----------------------------------------------------
     f32x16 acc[NA][TM];
-    // Tile (a, b) of a wave covers the columns n = nbase + NA*i + a and the envs m = TM*j + b (i, j = the MFMA row / column index
-    // of a lane): the NA weights and TM activations a lane needs for a k-step are then contiguous in LDS -- ONE ds_read_b128 each
-    // for TM = NA = 4 instead of four strided reads, and a fixed DS count per k-step for the pinned schedule.
+    // Tile (a, b) of a wave covers the canonical columns act_col(nbase, a, i) = nbase + 64 (a >> 1) + 2 i + (a & 1) and the envs
+    // m = TM*j + b (i, j = the MFMA row / column index of a lane): the weights a lane needs for a k-step are 8 contiguous bytes per
+    // column group (NA = 4: two groups, one ds_read2_b64), its TM activations one vector read -- a fixed DS count per k-step for the
+    // pinned schedule.
     typedef typename FVec<NA>::type AVec;
     typedef typename FVec<TM>::type BVec;
     const int nbase = wave * (32 * NA);
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bias = tl[nbase + NA * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a];       // tile a holds the columns n = nbase + NA*i + a
+            const float bias = tl[act_col<NA>(nbase, a, (r & 3) + 8 * (r >> 2) + 4 * lh)];   // canonical column of tile a, MFMA row i
 #pragma unroll
             for (int b = 0; b < TM; ++b) acc[a][b][r] = bias;
         }
@@ -665,16 +709,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     do {                                                                                                        \
         const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
         if (ODD && !ABL_NOL1) L1_GROUP(((c) + 1) >> 1);                                                         \
-        const float *Wb_ = Wc + cur_ * kWcFloats + nbase + NA * li;                                             \
+        const float *Wb_ = Wc + cur_ * kWcFloats + nbase;                                                       \
         const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + TM * li;                \
         AVec af_[2];                                                                                            \
         BVec bf_[2];                                                                                            \
-        af_[0] = *reinterpret_cast<const AVec *>(Wb_ + lh * kH2);                                               \
+        af_[0] = act_load_a<NA>(Wb_ + lh * kH2, li);                                                            \
         bf_[0] = *reinterpret_cast<const BVec *>(Hb_ + lh * BM);                                                \
         _Pragma("unroll") for (int ks = 0; ks < (NKS); ++ks) {                                                  \
             if (ks + 1 < (NKS)) {                                                                               \
                 const int kr_ = 2 * (ks + 1) + lh;                                                              \
-                af_[(ks + 1) & 1] = *reinterpret_cast<const AVec *>(Wb_ + kr_ * kH2);                           \
+                af_[(ks + 1) & 1] = act_load_a<NA>(Wb_ + kr_ * kH2, li);                                        \
                 bf_[(ks + 1) & 1] = *reinterpret_cast<const BVec *>(Hb_ + kr_ * BM);                            \
             }                                                                                                   \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                      \
@@ -715,7 +759,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         const int klim_ = (HR < 256 && (c) < kChunks / 2) ? (kChunks / 2) * (kKC / 2) : kFreeKsteps;            \
         if (K2_ < klim_ && !ABL_NOLDS) {                                                                        \
             const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
-            af_[K2_ % 3] = *reinterpret_cast<const AVec *>(Wf + (c2_ % RD) * kFreeChunkFloats + NA * li + kr_ * 128); \
+            af_[K2_ % 3] = act_load_a<NA>(Wf + (c2_ % RD) * kFreeChunkFloats + kr_ * 128, li);                  \
             bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + ((c2_ * kKC) % HR + kr_) * BM + TM * li);       \
         }                                                                                                       \
         _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                          \
@@ -770,7 +814,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         BVec bf_[3];
 #pragma unroll
         for (int k0 = 0; k0 < 2; ++k0) {
-            af_[k0] = *reinterpret_cast<const AVec *>(Wf + NA * li + (2 * k0 + lh) * 128);
+            af_[k0] = act_load_a<NA>(Wf + (2 * k0 + lh) * 128, li);
             bf_[k0] = *reinterpret_cast<const BVec *>(Hc + TM * li + (2 * k0 + lh) * BM);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -796,7 +840,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #pragma unroll
             for (int k0 = 0; k0 < 2; ++k0) {
                 constexpr int Kp = (kChunks / 2) * (kKC / 2);
-                af_[(Kp + k0) % 3] = *reinterpret_cast<const AVec *>(Wf + ((kChunks / 2) % RD) * kFreeChunkFloats + NA * li + (2 * k0 + lh) * 128);
+                af_[(Kp + k0) % 3] = act_load_a<NA>(Wf + ((kChunks / 2) % RD) * kFreeChunkFloats + (2 * k0 + lh) * 128, li);
                 bf_[(Kp + k0) % 3] = *reinterpret_cast<const BVec *>(Hc + TM * li + (2 * k0 + lh) * BM);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -808,36 +852,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     }
     PSTAMP(10);
 
-    // ---- epilogue: relu(acc + b2), layer 3 partial dot products ------------------------------------
-    float o0[TM], o1[TM];                       // (scalar FMAs: v_pk_fma_f32 on splat operands measured slower, 5 524 -> 5 856 cycles at TM = 4)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
+    // ---- epilogue: relu(acc + b2), layer 3 in the canonical order: one FMA chain per tile, lane halves, tile pairs -> group sums ----
+    // (scalar FMAs: v_pk_fma_f32 on splat operands measured slower, 5 524 -> 5 856 cycles at TM = 4)
     const float *w3s = tl + kH2P;
     // The accumulators live in AGPRs; the sched_barrier every four rows keeps the compiler from hoisting all 64*TM*4
     // v_accvgpr_reads to the top (VGPR pressure).  The reads are the compiler's own, so it pads the MFMA -> read hazard itself
     // (hand-written asm reads also made it shuffle accumulators between AGPRs to satisfy the operand constraints).
 #pragma unroll
-    for (int a = 0; a < NA; ++a) {
+    for (int gl = 0; gl < NA / 2; ++gl) {                        // this wave's column groups
+        float u0[TM], u1[TM];                                    // a lane's two tile chains, added
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if ((r & (TM == 4 ? 3 : 15)) == 0) __builtin_amdgcn_sched_barrier(0);   // TM = 4: keep the W3 LDS reads near their rows (VGPR pressure); small tiles: a whole tile's reads in flight
-            const int n = nbase + NA * ((r & 3) + 8 * (r >> 2) + 4 * lh) + a;   // C/D row i of v_mfma_f32_32x32x* -> column n
-            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);   // rows >= 500: zero weights (and finite h)
+        for (int t = 0; t < 2; ++t) {
+            const int a = 2 * gl + t;
+            float o0[TM], o1[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((r & (TM == 4 ? 3 : 15)) == 0) __builtin_amdgcn_sched_barrier(0);   // TM = 4: keep the W3 LDS reads near their rows (VGPR pressure); small tiles: a whole tile's reads in flight
+                const int n = act_col<NA>(nbase, a, (r & 3) + 8 * (r >> 2) + 4 * lh);   // C/D row i of v_mfma_f32_32x32x* -> column n
+                const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);       // rows >= 500: zero weights (and finite h)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const float h = fmaxf(acc[a][b][r], 0.0f);
+                    o0[b] = fmaf(h, w3.x, o0[b]);
+                    o1[b] = fmaf(h, w3.y, o1[b]);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-                const float h = fmaxf(acc[a][b][r], 0.0f);
-                o0[b] = fmaf(h, w3.x, o0[b]);
-                o1[b] = fmaf(h, w3.y, o1[b]);
+                u0[b] = t == 0 ? o0[b] : u0[b] + o0[b];
+                u1[b] = t == 0 ? o1[b] : u1[b] + o1[b];
             }
         }
-    }
+        const int g = nbase / 64 + gl;
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        o0[b] += __shfl_xor(o0[b], 32, 64);
-        o1[b] += __shfl_xor(o1[b], 32, 64);
-        if (lh == 0) {
-            red[(wave * BM + TM * li + b) * 2 + 0] = o0[b];
-            red[(wave * BM + TM * li + b) * 2 + 1] = o1[b];
+        for (int b = 0; b < TM; ++b) {
+            const float g0 = u0[b] + __shfl_xor(u0[b], 32, 64), g1 = u1[b] + __shfl_xor(u1[b], 32, 64);   // + the other lane half
+            if (lh == 0) *reinterpret_cast<float2 *>(RED_OF(g) + (TM * li + b) * 2) = make_float2(g0, g1);
         }
     }
     __syncthreads();
@@ -847,9 +899,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     double reward = 0.0;
     const int64_t i = env0 + tid;
     if (tid < BM && i < A.m) {
-        float p0 = tl[kH2P + kH2P * kOut + 0], p1 = tl[kH2P + kH2P * kOut + 1];  // b3
+        float hs[2][2];                                                          // canonical: the two column halves, groups in order
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { p0 += red[(w * BM + tid) * 2 + 0]; p1 += red[(w * BM + tid) * 2 + 1]; }
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                hs[hf][j] = ((RED_OF(4 * hf)[tid * 2 + j] + RED_OF(4 * hf + 1)[tid * 2 + j]) + RED_OF(4 * hf + 2)[tid * 2 + j]) + RED_OF(4 * hf + 3)[tid * 2 + j];
+        const float p0 = tl[kH2P + kH2P * kOut + 0] + (hs[0][0] + hs[1][0]), p1 = tl[kH2P + kH2P * kOut + 1] + (hs[0][1] + hs[1][1]);   // b3 + (H0 + H1)
         reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, PRE ? xP + tid * kPreDw : PRE2 ? w1 + tid * kPreDw : nullptr);
     }
     PSTAMP(12);
@@ -859,6 +915,353 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         double *red64 = reinterpret_cast<double *>(Wc);     // Wc is dead by now
         const double s = block_sum(reward, red64, NW);
         if (tid == 0) A.block_reward[bid] = s;
+    }
+#endif
+}
+
+// =====================================================================================================================
+// Column-group forms for small batches: k_actg<TM, NW, NS, RD>.
+//
+// A launch of <= 8 192 envs is one 32-env tile per CU or less, and k_act's 4-wave tile then pays its fixed phases (stage 0, layer 1,
+// layer 3, env tail) and the issue cost of its own LDS-DMA pieces in full.  Here the unit of work is the canonical COLUMN GROUP
+// (64 hidden-2 columns = two MFMA tiles, see act_col): a wave owns exactly one group, streams only that group's 256-byte row
+// segments of W2 through a private ring (free-running: it waits for nobody but itself), and
+//   NS = 1, NW = 8: one workgroup of 8 waves per env tile -- two waves per SIMD, so one wave's LDS-DMA issue slots, operand waits
+//                   and epilogue run under the other's MFMAs (4 096 < envs < 16 384);
+//   NS = 2, NW = 4: TWO workgroups per env tile, each with four of the eight groups (envs <= 4 096: every CU gets work down to
+//                   128 tiles; a 1-env tracking pass runs on two CUs).  Each half leaves its four group sums [4][BM][2] in a scratch
+//                   slab and takes a ticket (agent-scope acq_rel atomic); the half that arrives second reads the other's sums and
+//                   finishes b3 + g0 + .. + g7 in the canonical order, tanh / noise / step! / remember -- the same bits whichever
+//                   half that is, and the bits of every other form.  Nobody waits: the first half simply exits.  Placing both halves
+//                   on one XCD (workgroup ids b and b + 8) is for speed only; nothing depends on it.
+// Both halves run stage 0 and layer 1 for their env tile (layer 1 is 2 % of the FLOPs).
+constexpr int kGChunkFloats = kKC * 64;          // one wave's chunk: 16 rows x 64 columns = 4 KiB = 4 LDS-DMA pieces of 4 rows each
+constexpr int kGPieces = 4, kGLastPieces = 3;    // chunk 15: rows 240..251 (rows 250, 251 lie in b2 | W3: in bounds, never multiplied)
+constexpr int g_pieces(int ch) { return ch > kChunks - 1 ? 0 : ch == kChunks - 1 ? kGLastPieces : kGPieces; }
+template <int RD>
+constexpr int g_keep(int c)                      // pieces younger than chunk c + 1's that may stay in flight when the wave waits for it
+{
+    int n = 0;
+    for (int j = c + 2; j <= c + RD - 1; ++j) n += g_pieces(j);
+    return n;
+}
+
+struct ActSplit {                                // NS = 2 only
+    unsigned long long *slot;                    // [tiles][BM] one 8-byte exchange slot per env, kSplitEmpty between launches
+};
+constexpr unsigned long long kSplitEmpty = ~0ull;         // no pair of layer-3 sums has these bits (made sure of below)
+
+template <int TM, int NW, int RD>
+constexpr size_t actg_lds_bytes()
+{
+    return sizeof(float) * (NW * RD * kGChunkFloats + 16 + 256 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
+                            8 * 32 * TM * kOut + 32 * TM * kIn + 32 * TM * kPreDw + 4);
+}
+
+// Piece q (0..3) of a group chunk by asm LDS-DMA: the immediate (q - 2) KiB is added to the global AND the LDS address.
+__device__ __forceinline__ void g_piece(const char *sbase, uint32_t voff, uint32_t lds_base, int q)
+{
+    switch (q) {
+    case 0: glds16_asm<-2048>(sbase, voff, lds_base); break;
+    case 1: glds16_asm<-1024>(sbase, voff, lds_base); break;
+    case 2: glds16_asm<0>(sbase, voff, lds_base); break;
+    default: glds16_asm<1024>(sbase, voff, lds_base); break;
+    }
+}
+
+template <int TM, int NW, int NS, int RD>
+__global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
+{
+    static_assert(NW * NS == 8 && (NW == 4 || NW == 8), "8 column groups per env tile: 8 waves, or two workgroups of 4");
+#ifdef ABL_STAMP
+#define GSTAMP(i, cond) do { if (threadIdx.x == 0 && (cond)) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define GSTAMP(i, cond)
+#endif
+    GSTAMP(0, blockIdx.x == 0);
+    static_assert(RD >= 2 && RD <= 4 && TM >= 1 && TM <= 2, "ring of 2..4 chunks; relu(layer 1) fully resident (TM <= 2)");
+    constexpr int NT_ = 64 * NW, BM = 32 * TM, HR = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Wc = reinterpret_cast<float *>(smem);             // [NW][RD][16][64] private W2 rings
+    float *Hc = Wc + NW * RD * kGChunkFloats + 16;           // [256][BM] relu(layer 1)
+    float *xT = Hc + HR * BM;                                // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
+    float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
+    float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
+    float *red = tl + (kTailFloats + 2);                     // [8 groups][BM][2] layer-3 group sums
+    float *xR = red + 8 * BM * kOut;                         // [BM][9] raw observations
+    float *xP = xR + BM * kIn;                               // [BM][kPreDw] TailPre blocks
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // workgroup -> (env tile, column half).  NS = 2: ids b and b + 8 (same XCD under the round-robin dispatch) are the two halves of
+    // tile 8 (b / 16) + b % 8; the ragged end of the grid pairs neighbours.
+    int64_t tile = blockIdx.x;
+    int half = 0;
+    if constexpr (NS == 2) {
+        const unsigned b = blockIdx.x, T = gridDim.x >> 1, full = (T >> 3) << 4;
+        if (b < full) { tile = (int64_t)(b >> 4) * 8 + (b & 7); half = (b >> 3) & 1; }
+        else { tile = (int64_t)(T >> 3) * 8 + ((b - full) >> 1); half = (b - full) & 1; }
+    }
+    const int64_t env0 = tile * BM;
+    const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
+    const int64_t goff = learner * A.gstride;
+    const float *__restrict__ P = gsh(A.p.actor, goff);
+    const float *__restrict__ s_min = gsh(A.p.s_min, goff), *__restrict__ s_max = gsh(A.p.s_max, goff);
+    const int g = half * NW + wave;                          // this wave's column group
+    const int nbase = 64 * g;
+
+    // ---- stage 0: every global load issued before the first use, addresses clamped, never predicated ------------------------------
+    const char *W2g = reinterpret_cast<const char *>(P + kOffW2);
+    float *Wg = Wc + wave * (RD * kGChunkFloats);
+    const uint32_t ring_lds = lds_addr(Wg) + 2 * 1024;       // piece 2 of ring buffer 0
+    // piece q of a chunk = its rows 4 q .. 4 q + 3, 16 lanes (256 B) per row; LDS image linear.  One wave-uniform base per chunk, four
+    // constant lane offsets, the instruction's immediate (added to the global AND the LDS address) selects the LDS piece.
+    const char *gsbase = W2g + g * 256;
+    uint32_t gvoff[kGPieces];
+#pragma unroll
+    for (int q = 0; q < kGPieces; ++q) gvoff[q] = (uint32_t)((4 * q + (lane >> 4)) * (kH2 * 4) + (lane & 15) * 16 - (q - 2) * 1024);
+#define G_PIECE(chunk, q)                                                                         \
+    g_piece(gsbase + (size_t)(chunk) * (kKC * kH2 * 4), gvoff[q], ring_lds + ((chunk) % RD) * (kGChunkFloats * 4), (q))
+    // The env tail's inputs lead the burst (TailPre; every thread for env tid % BM): the table row idx + 1 hangs off idx, so idx is
+    // asked for first and the row right behind it -- the row then lands during stage 0 instead of holding up the layer-1 phase.
+    // One config for the whole batch (the usual case): its table_row0 / nrow come by scalar loads, not behind a per-env config index.
+    TailPre tp;
+    const bool view = A.do_step != 0, multi = view && A.v.n_cfg > 1;
+    {
+        const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
+        const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
+        const uint16_t *pci = multi ? A.v.cfg_of_env : reinterpret_cast<const uint16_t *>(P);
+        tp.idx = pidx[view ? pe : 0];
+        tp.ci = multi ? (int)pci[pe] : 0;
+        tp.step = pstep[view ? pe : 0];
+    }
+    constexpr int kIt = (BM * kIn + NT_ - 1) / NT_;
+    float sv[kIt], lo[kIt], hi[kIt], wv[kW1K], tv[6];
+    const int64_t last = A.m * kIn - 1;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = min(it * NT_ + tid, BM * kIn - 1), k = e % kIn;
+        sv[it] = A.obs[min(env0 * kIn + e, last)];
+        lo[it] = s_min[k];
+        hi[it] = s_max[k];
+    }
+    {
+        const int kc = min(tid & 255, kH1 - 1);
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) wv[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
+    tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));       // Philox + Box-Muller under the loads
+    f32x4 ra, rb;
+    {
+        const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
+        constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
+        const int32_t row0 = pc[o_row0], nrow = pc[o_nrow];
+        const float *tp_tables = view ? A.v.tables : P;
+        // row idx + 1 (1-based) of the env's table, clamped into the table: env_advance_rows rejects idx + 1 > nrow before it looks at it
+        const int64_t tp_row = view ? (int64_t)row0 + max(min(tp.idx + 1, nrow), 2) - 1 : 1;
+        const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
+        ra = rp[0]; rb = rp[1];                                                // row idx + 1
+        tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
+        const float x = (sv[it] - lo[it]) / ((hi[it] - lo[it]) + 1e-8f);      // MPS:56
+        if (e < BM * kIn) { xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f; xR[e] = sv[it]; }
+    }
+    for (int e = tid; e < BM; e += NT_) xT[kIn * BM + e] = 1.0f;                               // row 9 = 1: the bias input
+    if (tid < kW1C) {
+#pragma unroll
+        for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? wv[j] : 0.0f;
+    }
+    {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int e = tid < 256 ? it * 256 + tid : 1 << 20;   // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
+            if (e < kH2) tl[e] = tv[it];
+            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = tv[it];
+            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = tv[it];
+        }
+        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
+        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
+    }
+    tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+    tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT, w1 visible (LDS stores only)
+    GSTAMP(1, blockIdx.x == 0);
+    {
+        // the ring's first chunks go out only now: 256 workgroups x 64 KB of pieces would otherwise queue in front of the few KB
+        // every workgroup is waiting for
+#pragma unroll
+        for (int ch = 0; ch < RD - 1; ++ch)
+#pragma unroll
+            for (int q = 0; q < kGPieces; ++q) G_PIECE(ch, q);
+        // layer 1 on the matrix pipe: 8 row groups x TM env tiles over the NW waves (pairs interleaved where a wave has two)
+        constexpr int kL1Tiles = 8 * TM;
+        if constexpr (kL1Tiles / NW >= 2) {
+#pragma unroll
+            for (int u = 0; u < kL1Tiles / (2 * NW); ++u) {
+                const int t0 = wave + 2 * NW * u, g0 = t0 / TM, b0 = t0 % TM, t1 = t0 + NW, g1 = t1 / TM, b1 = t1 % TM;
+                L1_TILE2(g0, b0, Hc + (g0 * 32) * BM + TM * li + b0, g1, b1, Hc + (g1 * 32) * BM + TM * li + b1);
+            }
+        } else {
+            const int g0 = wave / TM, b0 = wave % TM;
+            L1_TILE(g0, b0, Hc + (g0 * 32) * BM + TM * li + b0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // h1 complete; every wave waits for its own ring below
+    GSTAMP(2, blockIdx.x == 0);
+
+    // ---- layer 2: this wave's group = 2 x TM tiles over 125 k-steps, no barrier ---------------------------------------------------
+    typedef typename FVec<TM>::type BVec;
+    f32x16 acc[2][TM];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bias = tl[act_col<2>(nbase, a, (r & 3) + 8 * (r >> 2) + 4 * lh)];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b][r] = bias;
+        }
+    constexpr int kGKsteps = (kChunks - 1) * (kKC / 2) + (kH1 - (kChunks - 1) * kKC) / 2;      // 125 k-steps of two rows
+    f32x2 af_[3];
+    BVec bf_[3];
+    /* k-step K = 8 c + ks: operands in register buffer K % 3, requested two k-steps ago.  One scheduling region per k-step:        */
+    /* [TM MFMAs] [A read of K + 2] [TM MFMAs] [B read of K + 2]; one LDS-DMA piece (asm) of chunk c + RD - 1 closes k-steps 0..3.   */
+#define G_KSTEP(c, ks)                                                                                          \
+    do {                                                                                                        \
+        const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
+        if (K2_ < kGKsteps) {                                                                                   \
+            const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
+            af_[K2_ % 3] = *reinterpret_cast<const f32x2 *>(Wg + (c2_ % RD) * kGChunkFloats + kr_ * 64 + 2 * li); \
+            bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + (c2_ * kKC + kr_) * BM + TM * li);              \
+        }                                                                                                       \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
+            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][0], fvec_get<TM>(bf_[K_ % 3], b), acc[0][b], 0, 0, 0); \
+        _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
+            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][1], fvec_get<TM>(bf_[K_ % 3], b), acc[1][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if ((ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
+    } while (0)
+#define G_CHUNK(c, NKS)                                                                                         \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < ((NKS) < 6 ? (NKS) : 6); ++ks) G_KSTEP(c, ks);                  \
+        if ((c) + 1 < kChunks) {                                                                                \
+            constexpr int keep_ = g_keep<RD>(c);                                                                \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep_) : "memory");      /* this wave's chunk c + 1 has landed */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+        _Pragma("unroll") for (int ks = 6; ks < (NKS); ++ks) G_KSTEP(c, ks);                                    \
+    } while (0)
+    {
+        constexpr int keep0_ = g_keep<RD>(-1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep0_) : "memory");          // this wave's chunk 0 has landed
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef ABL_STAMP
+    if (lane == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(A.block_reward)[48 + wave] = __builtin_amdgcn_s_memtime();    // every wave's loop start
+#endif
+#pragma unroll
+    for (int k0 = 0; k0 < 2; ++k0) {
+        af_[k0] = *reinterpret_cast<const f32x2 *>(Wg + (2 * k0 + lh) * 64 + 2 * li);
+        bf_[k0] = *reinterpret_cast<const BVec *>(Hc + (2 * k0 + lh) * BM + TM * li);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    G_CHUNK(0, kKC / 2);  GSTAMP(3, blockIdx.x == 0); G_CHUNK(1, kKC / 2);  G_CHUNK(2, kKC / 2);  G_CHUNK(3, kKC / 2);
+    G_CHUNK(4, kKC / 2);  G_CHUNK(5, kKC / 2);  G_CHUNK(6, kKC / 2);  G_CHUNK(7, kKC / 2);
+    G_CHUNK(8, kKC / 2);  G_CHUNK(9, kKC / 2);  G_CHUNK(10, kKC / 2); G_CHUNK(11, kKC / 2);
+    G_CHUNK(12, kKC / 2); G_CHUNK(13, kKC / 2); G_CHUNK(14, kKC / 2);
+    GSTAMP(4, blockIdx.x == 0);
+    G_CHUNK(15, (kH1 - (kChunks - 1) * kKC) / 2);                              // rows 240..249 only = 5 k-steps
+
+    GSTAMP(10, blockIdx.x == 0);
+#ifdef ABL_STAMP
+    if (lane == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(A.block_reward)[32 + wave] = __builtin_amdgcn_s_memtime();    // every wave's loop end
+#endif
+    // ---- layer 3 of this group, canonical order (see act_col) ---------------------------------------------------------------------
+    {
+        const float *w3s = tl + kH2P;
+        float u0[TM], u1[TM];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float o0[TM], o1[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = act_col<2>(nbase, t, (r & 3) + 8 * (r >> 2) + 4 * lh);
+                const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const float h = fmaxf(acc[t][b][r], 0.0f);
+                    o0[b] = fmaf(h, w3.x, o0[b]);
+                    o1[b] = fmaf(h, w3.y, o1[b]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                u0[b] = t == 0 ? o0[b] : u0[b] + o0[b];
+                u1[b] = t == 0 ? o1[b] : u1[b] + o1[b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const float g0 = u0[b] + __shfl_xor(u0[b], 32, 64), g1 = u1[b] + __shfl_xor(u1[b], 32, 64);
+            if (lh == 0) *reinterpret_cast<float2 *>(red + (g * BM + TM * li + b) * 2) = make_float2(g0, g1);
+        }
+    }
+    __syncthreads();
+    GSTAMP(8, blockIdx.x == 0);
+
+    // ---- one thread per env: b3 + (H0 + H1), tanh, noise, clamp, scale_action, step!, remember -----------------------------------
+    double reward = 0.0;
+    const int64_t i = env0 + tid;
+    bool fin = tid < BM && i < A.m;
+    float p0 = 0.0f, p1 = 0.0f;
+    if (fin) {
+        // sums of a column half, groups in canonical order (NS = 2: this workgroup holds only its own half's groups)
+        auto half_sum = [&](int hf, int j) {
+            return ((red[((4 * hf) * BM + tid) * 2 + j] + red[((4 * hf + 1) * BM + tid) * 2 + j]) + red[((4 * hf + 2) * BM + tid) * 2 + j]) +
+                   red[((4 * hf + 3) * BM + tid) * 2 + j];
+        };
+        float h00, h01, h10, h11;                                                  // H0 (outputs 0, 1), H1 (outputs 0, 1)
+        if constexpr (NS == 1) {
+            h00 = half_sum(0, 0); h01 = half_sum(0, 1); h10 = half_sum(1, 0); h11 = half_sum(1, 1);
+        } else {
+            // The data is the hand-off: ONE 8-byte exchange per env on its slot (agent scope, performed at the memory side, so the two
+            // halves meet there whatever XCDs they run on).  Whoever finds the slot empty leaves its sums and is done with this env;
+            // whoever finds the other half's sums finishes the env and empties the slot for the next launch.  Nothing is waited for.
+            float m0 = half_sum(half, 0), m1 = half_sum(half, 1);
+            unsigned long long mine = ((unsigned long long)__float_as_uint(m1) << 32) | __float_as_uint(m0);
+            if (mine == kSplitEmpty) { mine = 0x7FC000007FC00000ull; m0 = m1 = __uint_as_float(0x7FC00000u); }   // a NaN pair never takes the empty pattern
+            unsigned long long *slot = X.slot + tile * BM + tid;
+            const unsigned long long got = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got == kSplitEmpty) fin = false;
+            else __hip_atomic_store(slot, kSplitEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float o0 = __uint_as_float((uint32_t)got), o1 = __uint_as_float((uint32_t)(got >> 32));
+            h00 = half == 0 ? m0 : o0; h01 = half == 0 ? m1 : o1;
+            h10 = half == 0 ? o0 : m0; h11 = half == 0 ? o1 : m1;
+        }
+        p0 = tl[kH2P + kH2P * kOut + 0] + (h00 + h10);                              // b3 + (H0 + H1)
+        p1 = tl[kH2P + kH2P * kOut + 1] + (h01 + h11);
+    }
+    GSTAMP(9, blockIdx.x == 0);
+    GSTAMP(11, tile == 0 && fin);
+    if (fin) reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, xP + tid * kPreDw);
+    GSTAMP(12, tile == 0 && fin);
+#ifndef ABL_STAMP
+    if (NS == 1 && A.block_reward) {
+        __syncthreads();
+        double *red64 = reinterpret_cast<double *>(Wc);     // the rings are dead by now
+        const double s = block_sum(reward, red64, NW);
+        if (tid == 0) A.block_reward[tile] = s;
     }
 #endif
 }
@@ -884,17 +1287,82 @@ static int launch_act(const ActArgs &a, hipStream_t st)
     return hip_ok(hipGetLastError(), "k_act launch");
 }
 
+// Exchange slots of the column-split form, one slab per (device, stream): two streams may run the kernel at once and must not share
+// slots.  Allocated and set to "empty" on first use (a synchronous hipMalloc + hipMemset, once), never freed: 256 KB per slab.
+constexpr int kSplitMaxTiles = 512;
+static int split_scratch(hipStream_t st, ActSplit *out)
+{
+    struct Slot { int dev; hipStream_t st; ActSplit x; };
+    static Slot slots[32];
+    static int nslots = 0;
+    static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    int dev = 0;
+    if (int rc = hip_ok(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    while (lock.test_and_set(std::memory_order_acquire)) {}
+    int rc = SHEMS_OK;
+    int found = -1;
+    for (int i = 0; i < nslots; ++i)
+        if (slots[i].dev == dev && slots[i].st == st) { found = i; break; }
+    if (found < 0) {
+        if (nslots == 32) rc = set_error(SHEMS_ERR_ARG, "k_actg: more than 32 (device, stream) pairs use the column-split form");
+        else {
+            ActSplit x = {nullptr};
+            const size_t bytes = (size_t)kSplitMaxTiles * 64 * sizeof(unsigned long long);
+            rc = hip_ok(hipMalloc((void **)&x.slot, bytes), "hipMalloc(split slots)");
+            if (!rc) rc = hip_ok(hipMemset(x.slot, 0xFF, bytes), "hipMemset(split slots)");       // synchronous: every slot empty before any launch
+            if (!rc) { slots[nslots] = Slot{dev, st, x}; found = nslots++; }
+        }
+    }
+    if (!rc) *out = slots[found].x;
+    lock.clear(std::memory_order_release);
+    return rc;
+}
+
+template <int TM, int NW, int NS, int RD>
+static int launch_actg(const ActArgs &a, hipStream_t st)
+{
+    constexpr int BM = 32 * TM;
+    constexpr size_t lds = actg_lds_bytes<TM, NW, RD>();
+    static_assert(lds <= 160 * 1024, "k_actg: LDS image exceeds 160 KB");
+    static std::atomic<uint64_t> optin{0};                   // per device: see lds_optin
+    if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_actg<TM, NW, NS, RD>), (int)lds, "hipFuncSetAttribute(k_actg)")) return rc;
+    const int64_t tiles = (a.m + BM - 1) / BM;
+    ActSplit x = {nullptr};
+    if (NS == 2) {
+        if (tiles > kSplitMaxTiles) return set_error(SHEMS_ERR_ARG, "k_actg: %lld env tiles exceed the split form's scratch", (long long)tiles);
+        if (int rc = split_scratch(st, &x)) return rc;
+    }
+    hipLaunchKernelGGL((k_actg<TM, NW, NS, RD>), dim3((unsigned)(tiles * NS)), dim3(64 * NW), lds, st, a, x);
+    return hip_ok(hipGetLastError(), "k_actg launch");
+}
+
+// Which form runs a launch of m envs (SHEMS_ACT_FORM overrides the small-batch choice, tests and A/B runs):
+//   m >= 32 768          k_act<4, 4, 2>   128-env tiles, free-running waves (SHEMS_ACT_FORM4=0: shared stream)
+//   16 384 <= m < 32 768 k_act<2, 4, 2>   64-env tiles
+//   4 096 < m < 16 384   k_actg<1, 8, 1>  32-env tiles, 8 waves = 8 column groups
+//   m <= 4 096           k_actg<1, 4, 2>  32-env tiles, two workgroups (4 groups each) per tile
 static int dispatch_act(const ActArgs &a, hipStream_t st)
 {
     static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
-    // small tiles (TM <= 2): 0 = shared W2 stream (as TM = 4), 2 / 3 = free-running waves with a private ring of 2 / 3 chunks
-    static const int form = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : 3; }();
+    // small tiles: -1 = column-group forms (default); 0 = shared W2 stream (as TM = 4's old form), 2 / 3 = k_act's free-running waves with a
+    // private ring of 2 / 3 chunks; 8 = always the 8-wave group form, 9 = always the split form
+    static const int form = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : -1; }();
     // 128-env tiles: 0 = shared W2 stream, 1 = free-running waves (ring of 2 chunks, layer 1 resident one half at a time)
     static const int form4 = []() { const char *e = getenv("SHEMS_ACT_FORM4"); return e ? atoi(e) : 1; }();
     switch (pick_tm(a.m)) {
     case 4: return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
     case 2: return form == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
-    default: return form == 0 ? launch_act<1, 4>(a, st) : form == 2 ? launch_act<1, 4, 2>(a, st) : launch_act<1, 4, 3>(a, st);
+    default:
+        if (form == 0) return launch_act<1, 4>(a, st);
+        if (form == 2) return launch_act<1, 4, 2>(a, st);
+        if (form == 3) return launch_act<1, 4, 3>(a, st);
+#ifdef ABL_STAMP
+        const bool want_sum = false;                          // stamp builds: block_reward is the stamp buffer
+#else
+        const bool want_sum = a.block_reward != nullptr;      // per-tile reward sums: the form whose one workgroup finishes the whole tile
+#endif
+        if (form == 8 || (form != 9 && (a.m > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
+        return launch_actg<1, 4, 2, 3>(a, st);
     }
 }
 

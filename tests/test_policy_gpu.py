@@ -188,7 +188,8 @@ import util as U
 S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg"); R = importlib.import_module(U.PKG_NAME + ".replay")
 import torch
 out = []
-for n, mixed in ((2048 + 13, False), (20000, False), (40000, False), (3000, True), (40000 + 7, True)):   # 32-, 64- and 128-env tiles
+for n, mixed in ((1, False), (2048 + 13, False), (6000 + 5, False), (20000, False), (40000, False), (3000, True), (12000, True),
+                 (40000 + 7, True)):                       # 32-, 64- and 128-env tiles; one tile, odd tile counts, ragged last tiles
     if mixed:                                            # ten charger profiles x weight sweep: a config index per env
         tabs, cfgs, co = S.mixed_profile_setup(n)
         env = S.ShemsBatch(n, 72, tabs, cfgs, co).use_torch_stream()
@@ -209,15 +210,19 @@ print("FORMS", *out)
 
 def test_every_form_of_the_act_kernel_writes_the_same_bytes():
     """k_act exists in several forms (shared W2 stream / free-running waves with private rings, ring depth 2 or 3, half-resident layer 1
-    for 128-env tiles), chosen by tile size; SHEMS_ACT_FORM / SHEMS_ACT_FORM4 force the others.  They accumulate in the same order, so
-    three fused steps (actions, next states, ring contents) must agree bit for bit -- run in child processes, the form is read once."""
+    for 128-env tiles; for small batches the column-group kernel k_actg with 8 waves per env tile, or with TWO workgroups per env tile
+    whose second arriver finishes the tile), chosen by batch size; SHEMS_ACT_FORM / SHEMS_ACT_FORM4 force the others.  All of them follow
+    the canonical column order (csrc/shems_policy.hip, act_col), so three fused steps (actions, next states, ring contents) must agree
+    bit for bit -- whichever half of a split tile arrives second.  Run in child processes, the form is read once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _FORM_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     got = {}
-    for name, env in {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "ring2": {"SHEMS_ACT_FORM": "2"}}.items():
+    forms = {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "ring2": {"SHEMS_ACT_FORM": "2"},
+             "ring3": {"SHEMS_ACT_FORM": "3"}, "group8": {"SHEMS_ACT_FORM": "8"}, "split": {"SHEMS_ACT_FORM": "9"}}
+    for name, env in forms.items():
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("FORMS")][-1]
-    assert got["default"] == got["shared"] == got["ring2"], got
+    assert len(set(got.values())) == 1, got
