@@ -173,6 +173,21 @@ __device__ __forceinline__ void glds16_asm(const char *sbase, uint32_t voff, uin
                  :: "v"(voff), "s"(sbase), "s"(lds_base), "i"(IMM) : "memory");
 }
 
+// Piece q (0..7) of a wave's 8-KiB stream (k_act's free-running forms), immediate (q - 4) KiB on both addresses.
+__device__ __forceinline__ void glds16_asm_piece8(const char *sbase, uint32_t voff, uint32_t lds_base, int q)
+{
+    switch (q) {
+    case 0: glds16_asm<-4096>(sbase, voff, lds_base); break;
+    case 1: glds16_asm<-3072>(sbase, voff, lds_base); break;
+    case 2: glds16_asm<-2048>(sbase, voff, lds_base); break;
+    case 3: glds16_asm<-1024>(sbase, voff, lds_base); break;
+    case 4: glds16_asm<0>(sbase, voff, lds_base); break;
+    case 5: glds16_asm<1024>(sbase, voff, lds_base); break;
+    case 6: glds16_asm<2048>(sbase, voff, lds_base); break;
+    default: glds16_asm<3072>(sbase, voff, lds_base); break;
+    }
+}
+
 // Standard-normal pair from one Philox block (Box-Muller, f32).
 __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64_t i)
 {
@@ -448,9 +463,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     uint32_t wvoff[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) wvoff[q] = (uint32_t)((lane >> 5) * (kH2 * 4) + (lane & 31) * 16 + q * (2 * kH2 * 4) - (q - 4) * 1024);
+    const uint32_t wf_lds = lds_addr(Wf) + 4 * 1024;          // piece 4 of ring buffer 0
+    // (asm LDS-DMA: see glds16_asm -- the compiler's LDS / VMEM waits stay exact)
 #define FREE_PIECE(chunk, q)                                                                      \
-    glds16_piece(wsbase + (size_t)(chunk) * (kKC * kH2 * 4) + wvoff[q],                            \
-                 reinterpret_cast<char *>(Wf + ((chunk) % (RD ? RD : 1)) * kFreeChunkFloats) + 4 * 1024, (q))
+    glds16_asm_piece8(wsbase + (size_t)(chunk) * (kKC * kH2 * 4), wvoff[q],                        \
+                      wf_lds + ((chunk) % (RD ? RD : 1)) * (kFreeChunkFloats * 4), (q))
 #define STAGE0_DMA()                                                                              \
     do {                                                                                          \
         if constexpr (RD == 0) W2_ISSUE(0, 0);                                                    \
@@ -762,22 +779,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             af_[K2_ % 3] = act_load_a<NA>(Wf + (c2_ % RD) * kFreeChunkFloats + kr_ * 128, li);                  \
             bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + ((c2_ * kKC) % HR + kr_) * BM + TM * li);       \
         }                                                                                                       \
-        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                          \
+        /* quarters of the k-step's MFMAs = the four tile rows a; the operand reads of k-step K + 2 go out between the first two, */ \
+        /* an LDS-DMA piece (asm) after the third and after the fourth */                                       \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                           \
             _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[K_ % 3], a), fvec_get<TM>(bf_[K_ % 3], b), acc[a][b], 0, 0, 0); \
-        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                        \
-            if (!ABL_NODMA && (ks) < kDmaKs && 2 * (ks) + h_ < FREE_NPIECES((c) + RD - 1)) FREE_PIECE((c) + RD - 1, 2 * (ks) + h_); \
         if (!ABL_NOSCHED) {                                                                                     \
-            /* at most one memory instruction between two MFMAs */                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, NA * TM / 4, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                      \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
+                acc[2 + h_][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[K_ % 3], 2 + h_), fvec_get<TM>(bf_[K_ % 3], b), acc[2 + h_][b], 0, 0, 0); \
+            if (!ABL_NOSCHED) __builtin_amdgcn_sched_barrier(0);                                                \
+            if (!ABL_NODMA && (ks) < kDmaKs && 2 * (ks) + h_ < FREE_NPIECES((c) + RD - 1)) {                    \
+                FREE_PIECE((c) + RD - 1, 2 * (ks) + h_);                                                        \
+                if (!ABL_NOSCHED) __builtin_amdgcn_sched_barrier(0);                                            \
+            }                                                                                                   \
         }                                                                                                       \
     } while (0)
     /* Chunk c: k-steps 0..5 read inside the chunk; before k-step 6 (whose reads open chunk c + 1) the wave waits for ITS OWN next   */ \
@@ -1088,9 +1109,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
         if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
     }
-    tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
-    tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT, w1 visible (LDS stores only)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT, w1 visible (LDS stores only; the row loads keep flying)
     GSTAMP(1, blockIdx.x == 0);
     {
         // the ring's first chunks go out only now: 256 workgroups x 64 KB of pieces would otherwise queue in front of the few KB
@@ -1111,6 +1130,10 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
             const int g0 = wave / TM, b0 = wave % TM;
             L1_TILE(g0, b0, Hc + (g0 * 32) * BM + TM * li + b0);
         }
+        // the table row has had stage 0's tail and the layer-1 phase to arrive (the compiler's wait for it also covers the ring's
+        // first pieces, which it cannot see: they were issued later and the counter retires in order)
+        tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+        tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // h1 complete; every wave waits for its own ring below
     GSTAMP(2, blockIdx.x == 0);
@@ -1150,6 +1173,10 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         if ((ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
     } while (0)
+    /* Two waves per SIMD (NW = 8; waves w and w + 4 share one): the issue arbiter serves the older wave first -- waves 0..3 finish the  */
+    /* layer after 19.7 k cycles, waves 4..7 after 35.3 k (32 k of matrix work per SIMD).  Swapping s_setprio between the two every    */
+    /* chunk was measured: the early waves slow down (24.5 k), the late ones end at the same 35.4 k -- the 10 % are not arbitration but  */
+    /* the SIMD's 8 LDS-DMA pieces per 2048 MFMA cycles (the split form, half the pieces per CU, runs its layer at 94 %).               */
 #define G_CHUNK(c, NKS)                                                                                         \
     do {                                                                                                        \
         _Pragma("unroll") for (int ks = 0; ks < ((NKS) < 6 ? (NKS) : 6); ++ks) G_KSTEP(c, ks);                  \
