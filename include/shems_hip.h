@@ -231,6 +231,19 @@ int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stre
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 
+/* inference(env; track != 0) (memory_plotting_saving.jl:62-89 -> episode!(env; train = false, track, rng_ep = -1), DDPG.jl:186-242;
+ * 80 such passes per job, DDPG_reinforce_charger_v1.jl:87-105) as ONE launch: every env of the view runs `nsteps` hours from
+ * its current state (reset it first: shems_reset_dev(rng_minus1 = 1)), one workgroup per env, no host round trip per hour:
+ *   track_mode > 0: a = scale_action(actor(normalize(s)))   -- the deterministic actor (act(...; train = false), DDPG.jl:148-184)
+ *   track_mode < 0: a = action(env, track)                  -- the rule-based controller (shems_LU1.jl:318-340)
+ * then step!(env, s, a; track) (shems_LU1.jl:343-485).  Env e uses the actor / s_min / s_max at p's pointers + e * actor_stride_bytes
+ * (0: one actor for every env; a learner-group slab stride: 40 seeds x {last, best} in one launch); p may be NULL for track < 0.
+ * d_results: the 23-column rows of shems_LU1.jl:476-478, [n_envs][nsteps][23] Float64 (results_env = -1) or [nsteps][23] of env
+ * `results_env` only, or NULL.  d_returns [n_envs]: sum of rewards (DDPG.jl:223), or NULL.  The layers are tolerance-class
+ * arithmetic (as shems_act_step_dev); step! is exact. */
+int shems_track_dev(const shems_view *v, const shems_act_params *p, int64_t actor_stride_bytes, int track_mode, int32_t nsteps,
+                    double *d_results, int64_t results_env, double *d_returns, void *stream);
+
 
 /* -------------------------------------------------------- DDPG update -- */
 /* replay() (DDPG.jl:121-145).  Batch <= 128 (BATCH_SIZE = 120 in the tuned config).  All pointers are device memory;

@@ -25,36 +25,59 @@ def inference(env, agent=None, track=1, num_steps=None, which=0):
     """inference(env; track != 0): one deterministic pass over the data set from reset!(rng = -1)
     (MPS:66-71 -> episode!(..., train=false, track, rng_ep=-1), DDPG.jl:186-242).  track > 0: the actor's
     actions (no noise); track < 0: the rule-based controller action(env, track).  Every env of the batch runs the
-    same pass; returns (sum of rewards [N], results [steps][23] float64 of env `which`)."""
+    same pass; returns (sum of rewards [N], results [steps][23] float64 of env `which`).
+
+    ONE launch (shems_track_dev: all hours inside the kernel, one workgroup per env) and ONE device-to-host copy of the
+    results rows -- no launch, synchronisation or copy per hour."""
+    if track > 0 and agent is None:
+        raise ValueError("track > 0 needs an agent")
+    total, res = _track(env, None if track < 0 else agent.actor, None if track < 0 else agent.s_min, None if track < 0 else agent.s_max,
+                        0, track, num_steps, which)
+    return total, res[0]
+
+
+def inference_many(env, actors, s_min, s_max, num_steps=None):
+    """The job's tracking passes in one launch (MAIN:87-105: 40 seeds x {last, best} actor, each a full pass over the data set):
+    env e of the batch (len(actors) envs on the same table) runs the pass with actors[e].  actors: [P][129002] float32 (numpy or a
+    CUDA tensor); s_min / s_max: [9] (shared) or [P][9].  Returns (sum of rewards [P], results [P][steps][23] float64)."""
     import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    A = torch.as_tensor(np.asarray(actors, np.float32) if not torch.is_tensor(actors) else actors, dtype=torch.float32, device=dev)
+    P = A.shape[0]
+    if A.dim() != 2 or A.shape[1] != 129002 or env.n != P:
+        raise ValueError("actors must be [P][129002] with one env of the batch per actor")
+    # one slab row per pass: actor | pad to 16 B | s_min[9] | s_max[9] | pad -- env e finds all three at the same byte stride
+    row = -(-129002 // 4) * 4 + 32
+    slab = torch.zeros((P, row), dtype=torch.float32, device=dev)
+    slab[:, :129002] = A
+    o_min, o_max = row - 32, row - 16
+    for off, val in ((o_min, s_min), (o_max, s_max)):
+        t = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val, dtype=torch.float32, device=dev)
+        slab[:, off:off + 9] = t if t.dim() == 2 else t[None, :]
+    return _track(env, slab[0, :129002], slab[0, o_min:o_min + 9], slab[0, o_max:o_max + 9], row * 4, 1, num_steps, -1, keep=slab)
+
+
+def _track(env, actor, s_min, s_max, stride, track, num_steps, which, keep=None):
+    import torch
+    from .ddpg import ActParams
     n = env.n
     num_steps = env.maxsteps if num_steps is None else int(num_steps)
     env.use_torch_stream()
     env.reset_(-1)
     L = _capi.lib()
     dev = torch.device("cuda", torch.cuda.current_device())
-    a = torch.empty((n, 2), dtype=torch.float32, device=dev)
-    scaled = torch.empty((n, 2), dtype=torch.float32, device=dev)
-    rew = torch.empty(n, dtype=torch.float64, device=dev)
-    res = torch.empty((n, _capi.NRESULT), dtype=torch.float64, device=dev)
-    total = torch.zeros(n, dtype=torch.float64, device=dev)
-    out = np.empty((num_steps, _capi.NRESULT), np.float64)
+    rows = n if which < 0 else 1
+    res = torch.empty((rows, num_steps, _capi.NRESULT), dtype=torch.float64, device=dev)
+    total = torch.empty(n, dtype=torch.float64, device=dev)
     v = env.view()
-    for t in range(num_steps):
-        if track > 0:
-            if agent is None:
-                raise ValueError("track > 0 needs an agent")
-            # act(normalize(s); train=false) on the resident observations, then scale_action, then step!(track = 1)
-            agent.act((int(v.obs), n), train=False, out=a)
-            _capi.check(L.shems_scale_action_dev(C.c_void_p(a.data_ptr()), n, C.c_void_p(scaled.data_ptr()), env._stream()))
-            env.step_dev(scaled, 1, rewards=rew, results=res)
-        else:
-            _capi.check(L.shems_action_dev(C.byref(v), None, 1, C.c_void_p(a.data_ptr()), env._stream()))
-            env.step_dev(a, -1, rewards=rew, results=res)
-        total += rew
-        out[t] = res[which].cpu().numpy()
+    p = None
+    if track > 0:
+        p = ActParams(actor.data_ptr(), s_min.data_ptr(), s_max.data_ptr(), 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0, None, None)
+    _capi.check(L.shems_track_dev(C.byref(v), C.byref(p) if p is not None else None, int(stride), 1 if track > 0 else -1, num_steps,
+                                  C.c_void_p(res.data_ptr()), int(which), C.c_void_p(total.data_ptr()), env._stream()))
+    out, tot = res.cpu().numpy(), total.cpu().numpy()           # the pass's one synchronisation
     env.check_error()
-    return total.cpu().numpy(), out
+    return tot, out
 
 
 def results_file_name(job_id, run, ep_len, num_ep, l1, l2, case, rng, idx, best=False, out_dir="out/tracker"):

@@ -256,6 +256,10 @@ def main(environ=os.environ, cwd=".", log=print):
               season=cfg.season, run=cfg.run, job_id=cfg.job_id, case=cfg.case)
     if cfg.track == 1 and cfg.seed_run == cfg.num_seeds:
         log(f"Evaluation/Testing for TASK_IDs of {cfg.job_id}.")
+        # every seed's last and best actor (MAIN:90-103) -> ONE launch: pass p of the batch runs the whole data set with actor p
+        # (harness.inference_many / shems_track_dev); the files are then written in the reference's order.  s_min / s_max are this
+        # process's, as in the reference (module globals of the evaluating task).
+        passes = []                                                      # (test_rng_run, best, idx, actor)
         for i in range(1, cfg.num_seeds + 1):
             test_rng_run = int(str(SEED_INI) + str(i))
             try:
@@ -263,15 +267,17 @@ def main(environ=os.environ, cwd=".", log=print):
             except FileNotFoundError:
                 log(f"  seed {i}: no snapshot of run {test_rng_run} (that task has not finished): skipped")
                 continue
-            for best in (False, True):
-                if best:
-                    ac = checkpoint.load(idx=best_i, rng=test_rng_run, path="temp", **ck)[0]
-                agent.set_params(actor=ac, sync_targets=False)
-                _, results = harness.inference(env_track, agent, track=1)
+            passes.append((test_rng_run, False, cfg.NUM_EP, ac))
+            passes.append((test_rng_run, True, best_i, checkpoint.load(idx=best_i, rng=test_rng_run, path="temp", **ck)[0]))
+        if passes:
+            env_many = mk(len(passes), EP_LENGTH[cfg.season, cfg.run], tabs[cfg.run])
+            _, results = harness.inference_many(env_many, np.stack([p[3] for p in passes]), agent.s_min, agent.s_max)
+            env_many.close()
+            for (test_rng_run, best, idx, _), res in zip(passes, results):
                 path = harness.results_file_name(cfg.job_id, cfg.run, EP_LENGTH["train"], cfg.NUM_EP, cfg.L1, cfg.L2, cfg.case, test_rng_run,
                                                  cfg.NUM_EP, best=best)
-                harness.write_to_results_file(results, path)
-                harness.write_to_tracker_file(path, seed=test_rng_run, best=best, idx=best_i if best else cfg.NUM_EP, **tk)
+                harness.write_to_results_file(res, path)
+                harness.write_to_tracker_file(path, seed=test_rng_run, best=best, idx=idx, **tk)
                 written.append(path)
         log(f"Evaluation/Testing for TASK_IDs of {cfg.job_id} is finished.")
     elif cfg.track < 0:                                                  # rule-based

@@ -71,6 +71,44 @@ def test_inference_rule_based_and_drl_tracking():
     env.close()
 
 
+@pytest.mark.gpu
+def test_tracking_passes_of_a_job_in_one_launch():
+    """MAIN:87-105 runs 2 x num_seeds tracking passes; harness.inference_many runs them as one launch, pass p with actor p.  Each pass
+    must equal the single-pass call with that actor bit for bit (same kernel, same arithmetic), differ from the others, and leave
+    results rows the oracle reproduces from the targets they hold."""
+    torch = pytest.importorskip("torch")
+    H = _H()
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    ev = S.tables.synthetic_table("eval", 98)
+    st = np.concatenate([ev[:, [1, 1, 0, 2, 3, 4, 5, 6, 7]]]); st[:, 0] = np.linspace(0, 6.75, len(st))
+    lo, hi = st.min(0), st.max(0)
+    actors = []
+    for seed in (4, 5, 6, 7, 8):
+        p = D.init_params(seed, 9, 2, 0); p[128000:129000] *= 50
+        actors.append(p)
+    steps = 300
+    many = S.ShemsBatch(len(actors), 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    tot, res = H.inference_many(many, np.stack(actors), lo, hi, num_steps=steps)
+    many.close()
+    assert res.shape == (len(actors), steps, 23) and tot.shape == (len(actors),)
+    one = S.ShemsBatch(1, 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    ag = D.Agent(seed=4)
+    ag.set_norm(lo, hi)
+    for k, p in enumerate(actors):
+        ag.set_params(actor=p)
+        t1, r1 = H.inference(one, ag, track=1, num_steps=steps)
+        assert (U.bits64(r1) == U.bits64(res[k])).all() and t1[0] == tot[k]
+        assert tot[k] == res[k][:, 5].sum() or abs(tot[k] - res[k][:, 5].sum()) < 1e-9
+    assert len({float(t) for t in tot}) == len(actors)                   # five different actors, five different passes
+    ref = oracle_c.Batch(1, 1439, ev, oracle_c.profile(98)); ref.reset(True)
+    for t in range(steps):
+        tgt = res[2][t, [21, 2]].astype(np.float32)[None]
+        rc, r, o, rr = ref.step(tgt, 1, want_results=True)
+        assert rc == 0 and (U.bits64(rr[0]) == U.bits64(res[2][t])).all()
+    one.close()
+
+
 def test_checkpoint_roundtrip_and_reference_file_stems(tmp_path):
     CK = importlib.import_module(U.PKG_NAME + ".checkpoint")
     import ddpg_oracle as DO
