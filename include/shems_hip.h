@@ -283,6 +283,10 @@ typedef struct shems_ddpg {
 enum { SHEMS_DDPG_DEFER_ACTOR_E = 1 };
 
 int shems_ddpg_workspace_floats(int64_t *out);
+/* shems_ddpg_update runs the last two of its five dependent steps (critic on [s; actor(s)] with its input gradient, then the actor's
+ * gradient + ADAM + soft update; DDPG.jl:137-144) as ONE launch whose second half waits, bounded, for the first.  *out = how many
+ * workgroups ever gave up that wait on this workspace (0 in every supported use; non-zero = that update's actor step is invalid). */
+int shems_ddpg_sync_timeouts(const struct shems_ddpg *d, int64_t *out, void *stream);
 /* The whole replay() for one replica.  grad_actor / grad_critic still receive the complete gradients.  excl_pos / excl_count:
  * as shems_ddpg_critic_grad_ex (0, 0 = none).  d_publish: optional second copy [129002] of the updated actor (see
  * shems_ddpg_actor_apply_pub), or NULL. */

@@ -96,7 +96,9 @@ constexpr int64_t SL_SIZE = SL_EP + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
 static_assert(WS_W1T % 4 == 0 && WS_SLOT0 % 4 == 0 && SL_SIZE % 4 == 0, "16-byte aligned blocks");
 __host__ __device__ inline float *w1t_of(float *ws, int net) { return ws + WS_W1T + (int64_t)net * 12 * 256; }   // net = SLOT_* < 4
-constexpr int64_t WS_FLOATS = WS_SLOT0 + N_SLOTS * SL_SIZE;
+constexpr int64_t WS_SYNC = WS_SLOT0 + N_SLOTS * SL_SIZE;      // sync words of the merged K4 + K5 launch (SY_*), each on a 128-byte line of its own
+constexpr int64_t WS_FLOATS = WS_SYNC + 96;                    // three 128-byte lines: the counter K4 adds to, the flag K5 polls, the timeout count
+constexpr int SY_ARRIVE = 0, SY_FLAG = 32, SY_TIMEOUT = 64;
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
 
@@ -118,6 +120,36 @@ __device__ __forceinline__ float wave_sum(float x)
     x = dpp_add<0x142, 0xA>(x);        // row_bcast15 into rows 1, 3
     x = dpp_add<0x143, 0xC>(x);        // row_bcast31 into rows 2, 3: lane 63 = total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// In-launch hand-off (the merged K4 + K5 launch): a value another workgroup of the SAME launch reads is stored write-through and read
+// past the caches -- relaxed agent-scope atomic store / load = global_store / global_load ... sc1 -- so that neither a release nor an
+// acquire fence is needed (a device-scope release writes the whole L2 back: measured in round 1, it costs more than a launch boundary).
+// Every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, then ONE lane adds to the arrival counter;
+// the consumer polls the counter with the same kind of load, bounded, and loads the payload only behind its own barrier.
+__device__ __forceinline__ void pub_store(float *p, float v, bool wt)
+{
+    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ float pub_load(const float *p, bool wt)
+{
+    return wt ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+constexpr unsigned kWaitSpins = 1u << 16;        // x (one sc1 load + s_sleep) ~ tens of ms: a launch that cannot make progress gives up, it never hangs
+// All threads call it.  Returns after `target` producers have arrived (or the bound ran out: counted in sync[1], results are then wrong
+// and shems_ddpg_sync_timeouts reports it).  The polled word sits on a cache line of its own: 207 pollers on the line the producers
+// add to would queue those adds behind their loads.
+__device__ __forceinline__ void wait_arrivals(unsigned *sync, unsigned target, unsigned *timeouts)
+{
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > kWaitSpins) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the payload loads below the barrier
 }
 
 // Where a network input [in][BP] comes from: rows 0..8 = a normalised-state block, rows 9..10 (critics) either the
@@ -222,7 +254,7 @@ __device__ __forceinline__ void xt_load(const XSrc &s, int mbase, XTRegs<IN> &R)
     }
 }
 template <int IN>
-__device__ __forceinline__ void xt_store(const XSrc &s, const XTRegs<IN> &R, int mbase, float *xs /*LDS [12][32]*/, bool publisher)
+__device__ __forceinline__ void xt_store(const XSrc &s, const XTRegs<IN> &R, int mbase, float *xs /*LDS [12][32]*/, bool publisher, bool wt = false)
 {
     const int tid = threadIdx.x;
     xs[tid] = R.v[0];
@@ -235,7 +267,7 @@ __device__ __forceinline__ void xt_store(const XSrc &s, const XTRegs<IN> &R, int
 #pragma unroll
             for (int q = 0; q < NT; ++q) acc += R.p[q];
             a = tanhf(acc);                                                       // Dense(500, 2, tanh)
-            if (publisher && s.publish) s.publish[(tid >> 5) * BP + mbase + (tid & 31)] = a;
+            if (publisher && s.publish) pub_store(s.publish + (tid >> 5) * BP + mbase + (tid & 31), a, wt);
         }
         xs[SIN * 32 + tid] = a;
     }
@@ -656,8 +688,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int QG16_WST = 20;                                   // W2 panel row stride: 16-B aligned rows, both operand reads conflict-free
 constexpr int QG16_LDS = (256 * QG16_WST + W1K * 32 + W1K * W1C + 256 + 4 * 2 * 4 * 64 + 4 * 64 + 16 * 32 + 4 * 2 * 2 * 64) * 4;
 
-__device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
+struct GradArgs;
+__device__ __forceinline__ void qg_last_arriver(const GradArgs &G, float *smem, unsigned *sync);
+__device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx, unsigned *sig = nullptr, const GradArgs *G = nullptr)
 {
+    const bool wt = sig != nullptr;            // merged K4 + K5 launch: outputs are read by workgroups of this same launch
     constexpr int WST = QG16_WST;
     float *Wc = smem;                          // [256][WST]  W2[k][n0 .. n0 + 15] (rows >= 250: copies of row 249, never effective)
     float *xs = Wc + 256 * WST;                // [12][32]
@@ -687,7 +722,7 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
         const int e = it * 256 + tid, k = e >> 2, c4 = e & 3;
         wv[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)min(k, H1N - 1) * H2N + n0 + 4 * c4);
     }
-    xt_store<CIN>(J.x, xr, mbase, xs, ntile == 0);            // (the four column tiles of n-tile 0 publish actor(s) between them)
+    xt_store<CIN>(J.x, xr, mbase, xs, ntile == 0, wt);        // (the four column tiles of n-tile 0 publish actor(s) between them)
     pack_w1m_store(pk, CIN, w1);
     ep[tid] = epv * ep_keep;
     STAMP(3, 1);
@@ -779,7 +814,7 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
         for (int wv_ = 0; wv_ < 2; ++wv_)
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) sres += pp[(2 * mb + wv_) * 64 + 16 * gg + cc];
-        J.P3[ntile * BP + mbase + tid] = sres;
+        pub_store(J.P3 + ntile * BP + mbase + tid, sres, wt);
     }
     // ---- backward through this n-tile: rows k of the wave's quarter (4 blocks) x 2 column halves, K = 16 = 4 steps ----
     {
@@ -828,9 +863,19 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
             const float *rq = red + ((q * 2 + j) * 2 + mb) * 64 + cc;
             sres += ((rq[0] + rq[16]) + rq[32]) + rq[48];
         }
-        J.DAP[(ntile * 2 + j) * BP + mbase + mm] = sres;
+        pub_store(J.DAP + (ntile * 2 + j) * BP + mbase + mm, sres, wt);
     }
     STAMP(3, 9);
+    if (wt) {                                                  // arrival: stores drained by every wave, barrier, one lane counts
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned *lds_u = reinterpret_cast<unsigned *>(smem);
+        if (tid == 0) lds_u[0] = __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool last = lds_u[0] == (unsigned)(NT16 * (BP / 32) - 1);
+        __syncthreads();
+        if (last) qg_last_arriver(*G, smem, sig);             // everybody else's partials are complete: evaluate the actor head ONCE
+    }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
@@ -1094,13 +1139,13 @@ __device__ __forceinline__ void head_loss_load(const shems_ddpg &d, HeadRegs &R)
     R.s[2] = ws[WS_R + m];
     R.s[3] = ws[WS_DONE + m];
 }
-__device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R)
+__device__ __forceinline__ void head_actor_load(const shems_ddpg &d, HeadRegs &R, bool wt = false)
 {
     const float *ws = d.ws;
     const int t = threadIdx.x, o = t >> 7, m = t & 127;
 #pragma unroll
-    for (int p = 0; p < NT16; ++p) R.v[p] = ws[WS_DAP + (int64_t)(p * 2 + o) * BP + m];
-    R.s[0] = ws[WS_API + t];
+    for (int p = 0; p < NT16; ++p) R.v[p] = pub_load(ws + WS_DAP + (int64_t)(p * 2 + o) * BP + m, wt);
+    R.s[0] = pub_load(ws + WS_API + t, wt);
     R.s[1] = R.s[2] = R.s[3] = 0.0f;
 }
 
@@ -1126,6 +1171,8 @@ __device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R
         __syncthreads();
         if (t == 0) {
             d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
+            reinterpret_cast<unsigned *>(ws + WS_SYNC)[0] = 0u;                                // merged K4 + K5 launch that follows: arrivals of K4's workgroups,
+            reinterpret_cast<unsigned *>(ws + WS_SYNC)[SY_FLAG] = 0u;                          // "actor head published" flag
             const float g = red[4] + red[5];
             d.grad_critic[off_b3(CIN, 1)] = g;
             if (fuse) adam_elem(*fuse, off_b3(CIN, 1), g);
@@ -1136,7 +1183,7 @@ __device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R
 // ---- actor head backward, evaluated in the prologue of every K5 workgroup ------------------------------------
 // d3[o][m] = (sum of the NT partial d loss / d a_pi) * (1 - a_pi^2); workgroup 0 publishes d3, the actor loss and gb3.
 __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &R, float *d3 /*LDS [2][BP]*/, float *red /*LDS [8]*/, bool publisher,
-                                           const AdamCtx *fuse)
+                                           const AdamCtx *fuse, bool wt = false)
 {
     float *ws = d.ws;
     const int t = threadIdx.x, o = t >> 7, m = t & 127;
@@ -1147,13 +1194,13 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
     const float g = da * (1.0f - a * a);                       // through tanh
     d3[t] = g;
     if (publisher) {
-        ws[WS_D3A + t] = g;
+        pub_store(ws + WS_D3A + t, g, wt);
         float q = 0.0f;
         if (o == 0 && m < d.batch) {
             const float *Pq = slot(ws, SLOT_CRITIC2) + SL_P3;
             q = d.critic[off_b3(CIN, 1)];
 #pragma unroll
-            for (int i = 0; i < NT16; ++i) q += Pq[i * BP + m];                  // K4's 32 tiles of 16 hidden units
+            for (int i = 0; i < NT16; ++i) q += pub_load(Pq + i * BP + m, wt);     // K4's 32 tiles of 16 hidden units
         }
         const float sg = wave_sum(g), sq = wave_sum(q);
         if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
@@ -1166,6 +1213,25 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
             if (fuse) { adam_elem(*fuse, off_b3(SIN, 2), g0); adam_elem(*fuse, off_b3(SIN, 2) + 1, g1); }
         }
     }
+}
+
+// Merged K4 + K5 launch: the workgroup of K4 that arrives last (all 128 sets of partials are complete and were stored write-through)
+// evaluates the actor head once -- the same head_actor, so the same bits as the separate launches, where every K5 workgroup evaluates
+// it for itself from 33 KB of partials -- and publishes d3 (1 KB, write-through), the loss, gb3 and b3's ADAM step; then it raises
+// the flag K5's workgroups poll.  (K5's 207 workgroups each reading the 33 KB past the caches was measured first: 41 us per update
+// against 35.7 -- the reads of one small region from everywhere queue at the memory side.)
+struct GradArgs;
+__device__ __forceinline__ void qg_last_arriver_impl(const shems_ddpg &dd, const AdamCtx *fz, float *smem, unsigned *sync)
+{
+    float *d3 = smem, *red = smem + AIN * BP;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    HeadRegs hr;
+    head_actor_load(dd, hr, true);
+    head_actor(dd, hr, d3, red, true, fz, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(sync + SY_FLAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    STAMP(3, 11);
 }
 
 // ---- K3 / K5: every gradient block of one network, by batch contractions only -------------------------------------------
@@ -1195,6 +1261,10 @@ __device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
 {
     B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.w3f = gsh(B.w3f, off);
     B.grad = gsh(B.grad, off); B.E0 = gsh(B.E0, off); B.E1 = gsh(B.E1, off); gshift(B.dd, off); gshift(B.c, off);
+}
+__device__ __forceinline__ void qg_last_arriver(const GradArgs &G, float *smem, unsigned *sync)
+{
+    qg_last_arriver_impl(G.dd, G.fuse ? &G.c : nullptr, smem, sync);
 }
 enum { GR_NW = KT * NT, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };   // G: 32 rows of gb2 / gW3 each, 8 per wave
 
@@ -1256,8 +1326,13 @@ __device__ __forceinline__ void l1row_wave(const L1Row<IN, OUT> &R, const float 
 }
 
 template <int IN, int OUT>
-__device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
+__device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const int bx, unsigned *wait_sync = nullptr, unsigned wait_n = 0)
 {
+    // bx: this workgroup's index within the gradient grid.  wait_sync (merged K4 + K5 launch, actor head only): everything that does
+    // not depend on K4 -- the H2 panel, the ADAM state, the input block, the layer-1 image, the E slabs of the R rows -- is requested
+    // and staged first; then the workgroup waits for the wait_n workgroups of K4 and only then reads what they published.
+    const bool wt = wait_sync != nullptr;
+    (void)wait_n;
     float *Bt = smem;                          // W: [32 n][GR_PS] D2 panel
     float *At = Bt + GR_BT;                    // W: [32 k][GR_PS] h1 panel
     float *xs = At + GR_AT;                    // [12][BP]
@@ -1267,24 +1342,30 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     float *red = w3s + 2 * 32;                 // [8]
     float *gbuf = red + 8;                     // G: [32 rows][3] sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const bool is_w = (int)blockIdx.x < GR_NW, is_g = !is_w && (int)blockIdx.x < GR_NW + GR_NG;
-    const int kt = (int)blockIdx.x >> 4, nt = (int)blockIdx.x & 15;                          // W: (k-tile of 32, n-tile of 32)
+    const bool is_w = bx < GR_NW, is_g = !is_w && bx < GR_NW + GR_NG;
+    const int kt = bx >> 4, nt = bx & 15;                          // W: (k-tile of 32, n-tile of 32)
     const int mcol = tid & 127, half = tid >> 7;
     const AdamCtx *fz = A.fuse ? &A.c : nullptr;
-    const bool publisher = blockIdx.x == 0;
+    const bool publisher = bx == 0;
     constexpr int kRegion = OUT == 1 ? 2 : 4;
     (void)kRegion;
     STAMP(kRegion, 0);
 
     if (!is_w && !is_g) {
         // ---- R: layer-1 rows ----
-        const int k = ((int)blockIdx.x - GR_NW - GR_NG) * 4 + wave;
+        const int k = (bx - GR_NW - GR_NG) * 4 + wave;
         HeadRegs hr;
         L1Row<IN, OUT> R;
         l1row_load<IN, OUT>(A, min(k, H1N - 1), lane, R);
-        if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
+        if (wt) {                                              // merged launch: the head was evaluated once, by K4's last workgroup
+            STAMP(kRegion, 10);
+            wait_arrivals(wait_sync + SY_FLAG, 1u, wait_sync + SY_TIMEOUT);
+            d3[tid] = pub_load(A.dd.ws + WS_D3A + tid, true);
+        } else {
+            if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
+        }
         STAMP(kRegion, 1);
-        if (A.head == 1) head_loss(A.dd, hr, d3, red, false, nullptr); else head_actor(A.dd, hr, d3, red, false, nullptr);
+        if (!wt) { if (A.head == 1) head_loss(A.dd, hr, d3, red, false, nullptr); else head_actor(A.dd, hr, d3, red, false, nullptr); }
         __syncthreads();
         STAMP(kRegion, 2);
         if (k >= H1N) return;
@@ -1321,7 +1402,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     XRegs<IN> xr;
     f32x4 wq = {0.f, 0.f, 0.f, 0.f};
     float w3v = 0.0f;
-    const int nrow0 = is_w ? nt * 32 : ((int)blockIdx.x - GR_NW) * GR_GROWS;                  // first of the 32 W3 rows this workgroup needs
+    const int nrow0 = is_w ? nt * 32 : (bx - GR_NW) * GR_GROWS;                  // first of the 32 W3 rows this workgroup needs
     if (is_w) {
         build_x_load<IN>(A.x, xr);
         const int t = min(tid, 95);                                                           // 12 rows x 8 float4: the k-tile's 32 image columns
@@ -1332,12 +1413,16 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
         w3v = A.w3f[(nrow0 + (t >> 1)) * OUT + min(o, OUT - 1)];                              // frozen copy: 512 rows, zero padded
     }
     HeadRegs hr;
-    if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
+    if (!wt) { if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr); }
     if (is_w) {
         build_x_store<IN>(A.x, xr, xs, false);
         if (tid < 96) *reinterpret_cast<f32x4 *>(w1 + (tid >> 3) * 32 + 4 * (tid & 7)) = wq;
     }
-    if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
+    if (wt) {                                                  // merged launch: the head (and the publisher's work) was done by K4's last workgroup
+        STAMP(kRegion, 10);
+        wait_arrivals(wait_sync + SY_FLAG, 1u, wait_sync + SY_TIMEOUT);
+        d3[tid] = pub_load(A.dd.ws + WS_D3A + tid, true);
+    } else if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
     if (tid < 64) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
     STAMP(kRegion, 1);
     __syncthreads();
@@ -1403,7 +1488,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem)
     } else {
         // gb2[n] = sum_m D2[n][m]; gW3[n][o] = sum_m h2[n][m] d3[o][m]: GR_NG workgroups x GR_GROWS rows, one wave per row, all of a
         // wave's rows in flight
-        const int g = blockIdx.x - GR_NW;
+        const int g = bx - GR_NW;
         const float e0a = d3[lane], e0b = d3[64 + lane], e1a = d3[BP + lane], e1b = d3[BP + 64 + lane];
         {
             float h0[GR_GU], h1[GR_GU];
@@ -1442,7 +1527,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
-    if (A.in == SIN) grad_body<SIN, 2>(A, smem); else grad_body<CIN, 1>(A, smem);
+    if (A.in == SIN) grad_body<SIN, 2>(A, smem, (int)blockIdx.x); else grad_body<CIN, 1>(A, smem, (int)blockIdx.x);
+}
+
+// ---- K4 + K5 in ONE launch (single learner, fused ADAM): workgroups [0, 128) are K4's tiles, the rest K5's gradient workgroups.
+// K5's workgroups are resident from the start (335 workgroups, two fit a CU: checked on the host before this kernel is ever used),
+// so their first burst -- 45 of the 57 KB a W tile stages -- and its exposed latency run UNDER K4, and the K4 -> K5 launch boundary
+// (1.8 us) disappears; what K4 hands over is small (d loss / d a partials 32 KB, a_pi 1 KB, q partials 16 KB) and travels write-through
+// (pub_store / pub_load), so no fence is involved.  Nothing K5 writes (the actor, its target, its moments) is read by K4 except the
+// actor's b3 -- and every K5 workgroup waits for ALL of K4 before it computes, let alone writes, anything.
+constexpr int QG_NWG = NT16 * (BP / 32);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_qg_grad(FwdArgs F, GradArgs G, unsigned *sync)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < QG_NWG) { qg16_body(F.job[0], smem, (int)blockIdx.x, sync, &G); return; }
+    grad_body<SIN, 2>(G, smem, (int)blockIdx.x - QG_NWG, sync, (unsigned)QG_NWG);
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -1526,6 +1625,38 @@ static int set_lds_attrs()
     if (int rc = lds_optin(m_mid, reinterpret_cast<const void *>(&k_mid), MID_LDS, "attr k_mid")) return rc;
     if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), GR_LDS, "attr k_grad")) return rc;
     return SHEMS_OK;
+}
+
+// The merged K4 + K5 launch (SHEMS_DDPG_MERGE=1; NOT the default) needs every one of its workgroups resident at once (K5's wait for
+// K4's).  Per device, once: the occupancy the runtime reports for k_qg_grad, capped at the two workgroups per CU its waves_per_eu
+// attribute allows, times the CU count must cover the grid with a margin -- otherwise the two launches stay separate.  Even then the
+// wait is bounded.  Round-3 measurement (profiles/r03_update_merge.txt): correct (every update test green, bit-identical to the
+// separate launches) but 37.0 us per update against 35.6: K5's first burst does run under K4 (3.8 k cycles staged before the wait), but
+// between K4's last tile and K5's resumption lie a write-through drain, the arrival add, the last arriver's 33 KB of past-the-cache
+// loads, its head, another drain, the flag and the poll -- 5 us where the launch boundary it replaces costs 1.8 us + 2 us of staging.
+constexpr int QGG_LDS = QG16_LDS > GR_LDS ? QG16_LDS : GR_LDS;
+constexpr int QGG_GRID = QG_NWG + GR_NW + GR_NG + GR_NR;
+static bool merge_ok()
+{
+    static std::atomic<uint64_t> known{0}, good{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(known.load(std::memory_order_acquire) & bit)) {
+        bool ok = false;
+        const char *e = getenv("SHEMS_DDPG_MERGE");
+        if (e && atoi(e) == 1) {                  // opt-in: measured SLOWER than the two launches (37.0 against 35.6 us per update), see below
+            static std::atomic<uint64_t> optin{0};
+            int nb = 0, cus = 0;
+            if (lds_optin(optin, reinterpret_cast<const void *>(&k_qg_grad), QGG_LDS, "attr k_qg_grad") == SHEMS_OK &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_qg_grad), 256, QGG_LDS) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+                ok = (int64_t)(nb < 2 ? nb : 2) * cus >= QGG_GRID + QGG_GRID / 4;          // 335 workgroups + 25 % margin
+        }
+        if (ok) good.fetch_or(bit, std::memory_order_release);
+        known.fetch_or(bit, std::memory_order_release);
+    }
+    return (good.load(std::memory_order_acquire) & bit) != 0;
 }
 
 }  // namespace shems
@@ -1645,12 +1776,17 @@ static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamSca
     const unsigned fgx = NT16 * (BP / 32);
     f.prep = 2;
     f.job[0] = FwdJob{nullptr, d->critic, CIN, 1, 0, x_spi, nullptr, C2 + SL_P3, ws + WS_D3Q, ws + WS_DAP};
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG16_LDS, st, f);
     GradArgs g;
     std::memset(&g, 0, sizeof g);
     g.w1t = w1t_of(ws, SLOT_ACTOR); g.P = d->actor; g.in = SIN; g.out = 2; g.x = x_s; g.H2 = SA + SL_H2; g.w3f = ws + WS_FW3A;
     g.grad = d->grad_actor; g.E0 = SA + SL_EP; g.E1 = ws + WS_EA1; g.head = 2; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, false, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
+    if (fuse && L == 1 && gs == 0 && merge_ok()) {
+        // one replica, ADAM inside the gradient launch: K4 and K5 as ONE launch (k_qg_grad); the arrival counter was zeroed by K3
+        hipLaunchKernelGGL(k_qg_grad, dim3(QGG_GRID), dim3(256), QGG_LDS, st, f, g, reinterpret_cast<unsigned *>(ws + WS_SYNC));
+        return hip_ok(hipGetLastError(), "ddpg actor-side launch (merged)");
+    }
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG16_LDS, st, f);
     hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg actor-side launches");
 }
@@ -1673,6 +1809,18 @@ int shems_debug_set_stamps(void *d_buf)
     return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p), "set stamps");
 }
 #endif
+
+/* Merged K4 + K5 launch: how many of its workgroups ever gave up waiting (0 unless the device could not keep the launch resident,
+ * e.g. two such launches on two streams at once): copies one word from the workspace, synchronising with `stream`. */
+int shems_ddpg_sync_timeouts(const shems_ddpg *d, int64_t *out, void *stream)
+{
+    if (!d || !d->ws || !out) return set_error(SHEMS_ERR_ARG, "shems_ddpg_sync_timeouts: NULL");
+    unsigned v = 0;
+    if (int rc = hip_ok(hipMemcpyAsync(&v, reinterpret_cast<const unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream), "memcpy sync")) return rc;
+    if (int rc = hip_ok(hipStreamSynchronize((hipStream_t)stream), "sync")) return rc;
+    *out = (int64_t)v;
+    return SHEMS_OK;
+}
 
 int shems_ddpg_workspace_floats(int64_t *out)
 {

@@ -73,6 +73,8 @@ def _declare():
     L.shems_act_step_grid.restype = C.c_int
     PD = C.POINTER(DdpgArgs)
     L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
+    L.shems_ddpg_sync_timeouts.argtypes = [PD, C.POINTER(i64), vp]
+    L.shems_ddpg_sync_timeouts.restype = C.c_int
     dbl = C.c_double
     L.shems_ddpg_update.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, dbl, dbl, dbl, dbl, dbl, dbl, vp, vp]
     L.shems_ddpg_update.restype = C.c_int
@@ -391,6 +393,14 @@ class Agent:
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
+    def sync_timeouts(self):
+        """Workgroups of the merged K4 + K5 launch that ever gave up their (bounded) wait on this learner's workspace: 0 in every
+        supported use (shems_ddpg_sync_timeouts).  Synchronises the stream."""
+        d = self._ddpg_args()
+        out = C.c_int64(0)
+        _capi.check(self.L.shems_ddpg_sync_timeouts(C.byref(d), C.byref(out), self._stream()))
+        return out.value
+
     def sample_indices(self, tick, ring_len):
         out = np.empty(self.batch, np.int64)
         _capi.check(self.L.shems_ddpg_sample_indices(self.rng_seed, int(tick) & 0xFFFFFFFF, self.batch, int(ring_len),
@@ -584,6 +594,8 @@ class TrainWorkload:
             self.torch.cuda.current_stream().wait_stream(self.upd_stream)
             self.torch.cuda.synchronize()
         self.env.check_error()
+        if self.agent.sync_timeouts():
+            raise RuntimeError("the merged K4 + K5 launch gave up a wait: its workgroups were not all resident")
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
             raise RuntimeError("non-finite network parameters after the timed steps")
 

@@ -79,6 +79,9 @@ def test_group_step_and_update_match_single_learner_calls_bitwise(L, E):
     assert np.array_equal(env.state, state_g)
     for name, (off, cnt) in grp.layout.items():
         # bit patterns, not float values: the workspace keeps int32 ring slots (-1 for the 8 pad columns reads as NaN)
+        if name == "ws":
+            cnt -= 96        # the workspace ends with the 96 bookkeeping words of the merged K4 + K5 launch (arrival counter, timeouts):
+                             # the single-learner update runs merged, a group's does not -- they are not results
         assert torch.equal(grp.slab[:, off:off + cnt].contiguous().view(torch.int32), slab_g[:, off:off + cnt].contiguous().view(torch.int32)), name
     env.check_error()
 

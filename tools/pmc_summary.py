@@ -29,17 +29,20 @@ def collect(d):
 
 def main():
     acc = {}
-    tag = "r02"
+    tag = "r03"
+    outdir = os.path.join(ROOT, "profiles")        # on the GPU box pass --outdir=gpurun_out/...: only gpurun_out/ travels back
     dirs = []
     for a in sys.argv[1:]:
         if a.startswith("--round="):
             tag = a.split("=", 1)[1]
+        elif a.startswith("--outdir="):
+            outdir = a.split("=", 1)[1]
         else:
             dirs.append(a)
     for d in dirs:
         acc.update(collect(d))
     rows = sorted(acc.items())
-    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_counters_train.csv"), "w", newline="") as f:
+    with open(os.path.join(outdir, f"{tag}_pmc_counters_train.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Kernel", "Counter", "Dispatches", "Mean_KB", "Min_KB", "Max_KB"])
         for (k, c), v in rows:
@@ -56,7 +59,7 @@ def main():
                          "width, so 2x is an upper bound for the read side.",
            "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline",
                         "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline"]}
-    json.dump({"train": rec, "policy": rec}, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    json.dump({"train": rec, "policy": rec}, open(os.path.join(outdir, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "dispatches": len(fetch)}))
 
 

@@ -38,8 +38,10 @@ for _ in range(nrep):
 S._capi.check(L.shems_debug_set_stamps(None))
 
 names = ["K1 k_fwd x3", "K2 k_mid", "K3 k_grad critic", "K4 k_fwd QG", "K5 k_grad actor"]
+MERGED = os.environ.get("SHEMS_DDPG_MERGE", "1") != "0"      # K4 + K5 in one launch: K5's workgroup ids start at 128
+k5 = (lambda w: w - 128) if MERGED else (lambda w: w)
 roles = {0: lambda w: "tile" if (w % 70) < 64 else "duty", 1: lambda w: "fwd" if w < 64 else "E", 2: lambda w: "W" if w < 128 else "G" if w < 144 else "R",
-         3: lambda w: "tile", 4: lambda w: "W" if w < 128 else "G" if w < 144 else "R"}
+         3: lambda w: "tile", 4: lambda w: "W" if k5(w) < 128 else "G" if k5(w) < 144 else "R"}
 out = {}
 a = np.stack(acc)                                  # [rep][launch][wg][stamp][2]
 for k in range(5):
@@ -61,6 +63,7 @@ for k in range(5):
         t = ak[:, wgs[sel]][:, :, :, 0].astype(np.float64)               # shader cycles
         valid = t[0, 0] != 0
         idx = np.where(valid)[0]
+        idx = idx[np.argsort(np.median(t[:, :, idx], (0, 1)))]             # in time order (stamp 10 = "first burst staged, now waiting" sits between 0 and 1)
         ph = []
         for i0, i1 in zip(idx[:-1], idx[1:]):
             dt = t[:, :, i1] - t[:, :, i0]
