@@ -86,10 +86,14 @@ class EnvWorkload:
     def finish(self):
         self.env.check_error()
 
+    def _reset_dev(self, episode):
+        v = self.env.view()
+        self.S._capi.check(self.S._capi.lib().shems_reset_seeded_dev(C.byref(v), self.seed, episode, self.env._stream()))
+
     def kernel_pass(self, reps):
         """HIP-event timing of the dominant kernel alone (events on the launch stream)."""
         T = importlib.import_module(PKG + ".timing")
-        reset = lambda g, i: self.env.reset_(self.seed, episode=1000 + i) if g % 8 == 0 else None      # 64 launches < one episode
+        reset = lambda g, i: self._reset_dev(1000 + i) if g % 8 == 0 else None      # 64 launches < one episode; enqueued, no host sync
         avg, med, reps = T.time_launches(self.torch, lambda i: self.env.step_dev(self.actions[i % 8], 0, rewards_f32=self.rew32),
                                          reps, before_group=reset)
         return dict(kernel="shems::k_step", avg_us=avg, median_us=med, launches=reps,
@@ -131,7 +135,7 @@ class PolicyWorkload(EnvWorkload):
 
     def kernel_pass(self, reps):
         T = importlib.import_module(PKG + ".timing")
-        reset = lambda g, i: self.env.reset_(self.seed, episode=1000 + i) if g % 8 == 0 else None
+        reset = lambda g, i: self._reset_dev(1000 + i) if g % 8 == 0 else None
         avg, med, reps = T.time_launches(self.torch, self._launch, min(reps, 200), before_group=reset)
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n       # 256 500 FLOP per env-step
         return dict(kernel="shems::k_act<TM>", avg_us=avg, median_us=med, launches=reps,
@@ -291,15 +295,37 @@ def cpu_baseline(n_envs, mode, updates, scale=1.0):
     def fused_step(ptr, n, learner_actor, s, lo, hi, k, a_out, rew, s2):
         return L.orc_policy_step_omp(ptr, n, learner_actor.ctypes.data, lo.ctypes.data, hi.ctypes.data, 0.1, 1, k & 0xFFFFFFFF, 1,
                                      s.ctypes.data, a_out.ctypes.data, rew.ctypes.data, s2.ctypes.data)
+    # Two ways to spend the cores, both timed, the faster one reported as `value`: (i) the fused C / OpenMP step above (hand-written
+    # AVX2 dense layers, W2 resident in each core's L2); (ii) the library route -- actor forward + noise on torch's CPU thread pool
+    # (its BLAS picks the widest vectors the host has: AVX-512 on the GPU boxes), then scale_action and the OpenMP env step.
+    import torch
+    torch.set_num_threads(cores)
+
+    def torch_policy(act_p, s, lo, hi, k):
+        with torch.no_grad():
+            W1, b1, W2, b2, W3, b3 = [torch.from_numpy(x) for x in DO.split(act_p, 9, 2)]
+            x = (torch.from_numpy(s) - torch.from_numpy(lo)) / ((torch.from_numpy(hi) - torch.from_numpy(lo)) + 1e-8)
+            h = torch.relu_(torch.addmm(b1, x, W1))
+            h = torch.relu_(torch.addmm(b2, h, W2))
+            a = torch.tanh_(torch.addmm(b3, h, W3))
+            a.add_(torch.randn_like(a), alpha=0.1).clamp_(-1.0, 1.0)
+            return a.numpy()
+    stepN = lambda ptr, n, a, tm, r, o: L.orc_batch_step_omp(ptr, n, a, tm, r, o)
     nN = n_envs
-    nstepN, dtN, _, _ = full_step_loop(nN, 6.0 * scale, None, None, best_blas, fused=fused_step)
-    all_cores = nN * nstepN / dtN
+    legs = {}
+    legs["fused C/OpenMP step (shems_policy_omp.c)"] = full_step_loop(nN, 3.5 * scale, None, None, best_blas, fused=fused_step)[:2]
+    legs["torch-CPU actor + OpenMP C env"] = full_step_loop(nN, 3.5 * scale, stepN, torch_policy, best_blas)[:2]
+    rate = {k: nN * v[0] / v[1] for k, v in legs.items()}
+    best = max(rate, key=rate.get)
+    nstepN, dtN = legs[best]
+    all_cores = rate[best]
     out.update({"value": all_cores, "unit": "env-steps/s", "cores": cores, "kind": "port",
                 "updates_per_sec": (updates * nstepN / dtN) if mode == "train" else None,
                 "one_thread_value": one_thread, "one_thread_updates_per_sec": (updates * nstep1 / dt1) if mode == "train" else None,
-                "visible_cpus": os.cpu_count(), "learner_blas_threads": best_blas,
-                "sample": f"CPU oracle, the same vector step (mode={mode}, {updates} update/step).  All {cores} usable host threads: the fused "
-                          f"C/OpenMP step (actor + noise + scale_action + step!, shems_policy_omp.c) + NumPy learner (BLAS x{best_blas}) on {nN} envs: {nstepN} vector "
+                "visible_cpus": os.cpu_count(), "learner_blas_threads": best_blas, "all_cores_route": best,
+                "all_cores_routes": {k: float(v) for k, v in rate.items()},
+                "sample": f"CPU oracle, the same vector step (mode={mode}, {updates} update/step).  All {cores} usable host threads, faster of two "
+                          f"routes = {best} + NumPy learner (BLAS x{best_blas}) on {nN} envs: {nstepN} vector "
                           f"steps = {nN * nstepN} env-steps in {dtN:.1f} s.  One thread: C env + NumPy actor/learner on a {n1}-env slice: "
                           f"{nstep1} vector steps = {n1 * nstep1} env-steps in {dt1:.1f} s.  No per-env foreign call in any timed loop."})
     return out

@@ -616,7 +616,10 @@ class TrainWorkload:
         torch = self.torch
         from .timing import time_launches
         reps = min(reps, 200)
-        reset = lambda g, i: self.env.reset_(self.env_seed, episode=100000 + i) if g % 8 == 0 else None     # 64 launches < one episode
+        def reset(g, i):                                     # 64 launches < one episode.  The device call of the train loop itself: enqueued,
+            if g % 8 == 0:                                   # no host synchronisation (ShemsBatch.reset_ is the host API and waits -- the GPU then
+                v = self.env.view()                          # idles, and the small-batch kernels of the next group read 2-3 us long)
+                _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, 100000 + i, self.env._stream()))
         snap = self.agent.snapshot()
         sync = self.agent.sync
         world = sync.world
