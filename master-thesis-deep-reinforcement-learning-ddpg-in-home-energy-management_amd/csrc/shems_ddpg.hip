@@ -870,7 +870,7 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned *lds_u = reinterpret_cast<unsigned *>(smem);
-        if (tid == 0) lds_u[0] = __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) lds_u[0] = __hip_atomic_fetch_add(sig + SY_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const bool last = lds_u[0] == (unsigned)(NT16 * (BP / 32) - 1);
         __syncthreads();
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R
         __syncthreads();
         if (t == 0) {
             d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
-            reinterpret_cast<unsigned *>(ws + WS_SYNC)[0] = 0u;                                // merged K4 + K5 launch that follows: arrivals of K4's workgroups,
+            reinterpret_cast<unsigned *>(ws + WS_SYNC)[SY_ARRIVE] = 0u;                                // merged K4 + K5 launch that follows: arrivals of K4's workgroups,
             reinterpret_cast<unsigned *>(ws + WS_SYNC)[SY_FLAG] = 0u;                          // "actor head published" flag
             const float g = red[4] + red[5];
             d.grad_critic[off_b3(CIN, 1)] = g;
@@ -1266,12 +1266,22 @@ __device__ __forceinline__ void qg_last_arriver(const GradArgs &G, float *smem, 
 {
     qg_last_arriver_impl(G.dd, G.fuse ? &G.c : nullptr, smem, sync);
 }
-enum { GR_NW = KT * NT, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };   // G: 32 rows of gb2 / gW3 each, 8 per wave
+// W tiles are 32 k x 32 n (128 workgroups), G workgroups take 32 rows (16 workgroups).  -DGR_WN=16 builds the finer tiling tried in
+// round 3: W tiles 32 k x 16 n (256 workgroups: two 16 x 16 blocks, waves (w >> 1) pick the block, (w & 1) the batch half, the halves
+// added through LDS in a fixed order), G workgroups of 16 rows (32) -- half the H2 / ADAM state staged per workgroup, half the MFMA
+// chain and half the ADAM work per tile.  Correct (every update test green) and measured SLOWER: 36.1-36.2 us per update against
+// 35.8-35.9 on the same box, alternating runs -- 351 workgroups on 256 CUs double up, and the head's 16 / 32 KB of partials every
+// workgroup re-reads do not shrink with the tile.
+#ifndef GR_WN
+#define GR_WN 32
+#endif
+static_assert(GR_WN == 16 || GR_WN == 32, "W tile width");
+enum { GR_NTW = 512 / GR_WN, GR_NW = KT * GR_NTW, GR_NG = GR_WN == 16 ? 32 : 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };
 
 constexpr int GR_PS = BP + 4;                                // W: row stride of the two operand panels (b128 reads of 16 rows: conflict free)
-constexpr int GR_BT = 32 * GR_PS;                            // W: [32 n][132] D2 panel
+constexpr int GR_BT = GR_WN * GR_PS;                         // W: [GR_WN n][132] D2 panel
 constexpr int GR_AT = 32 * GR_PS;                            // W: [32 k][132] h1 panel
-constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3) * 4;
+constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3 + (GR_WN == 16 ? 4 * 256 : 0)) * 4;
 
 // D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
 __device__ __forceinline__ float d2_val(float h2, float w3a, float w3b, float d3a, float d3b)
@@ -1340,10 +1350,11 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
     float *d3 = w1 + W1K * 32;                 // [2][BP]
     float *w3s = d3 + AIN * BP;                // W3 rows of the n-tile (W) / of the 32 rows (G), [32][2] (out == 1: [.][1] zero)
     float *red = w3s + 2 * 32;                 // [8]
-    float *gbuf = red + 8;                     // G: [32 rows][3] sums
+    float *gbuf = red + 8;                     // G: [GR_GROWS rows][3] sums
+    [[maybe_unused]] float *wx = gbuf + GR_GROWS * 3;      // W (16-wide tiles): [4 waves][4 r][64 lanes] block halves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const bool is_w = bx < GR_NW, is_g = !is_w && bx < GR_NW + GR_NG;
-    const int kt = bx >> 4, nt = bx & 15;                          // W: (k-tile of 32, n-tile of 32)
+    const int kt = bx / GR_NTW, nt = bx % GR_NTW;                  // W: (k-tile of 32, n-tile of GR_WN)
     const int mcol = tid & 127, half = tid >> 7;
     const AdamCtx *fz = A.fuse ? &A.c : nullptr;
     const bool publisher = bx == 0;
@@ -1386,30 +1397,37 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
 
     // The H2 panel does not depend on the error signal: its loads go out before the head is evaluated, so the two global latencies
     // overlap instead of following each other.
-    float hv[16];
-    int widx[4] = {-1, -1, -1, -1};             // W: the four elements of gW2 this lane finishes and owns (rows 4 wave .. 4 wave + 3 of the tile)
-    AdamRegs<4> ar;
+    constexpr int HVN = GR_WN / 2;              // H2 rows per thread
+    constexpr int WOWN = GR_WN == 16 ? 2 : 4;   // elements of gW2 a lane finishes and owns
+    float hv[HVN];
+    int widx[WOWN];
+#pragma unroll
+    for (int r = 0; r < WOWN; ++r) widx[r] = -1;
+    AdamRegs<WOWN> ar;
     if (is_w) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) hv[u] = A.H2[min(nt * 32 + 2 * u + half, H2N - 1) * BP + mcol];
+        for (int u = 0; u < HVN; ++u) hv[u] = A.H2[min(nt * GR_WN + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {            // wave w finishes the 16 x 16 block (k half w >> 1, n half w & 1): D[i = 4 g + r][j = c]
-            const int k = kt * 32 + 16 * (wave >> 1) + 4 * (lane >> 4) + r, n = nt * 32 + 16 * (wave & 1) + (lane & 15);
+        for (int r = 0; r < WOWN; ++r) {
+            // 32-wide tiles: wave w finishes the 16 x 16 block (k half w >> 1, n half w & 1), D[i = 4 g + r][j = c], r < 4.
+            // 16-wide tiles: waves 2 b, 2 b + 1 share block b (k half b); wave (w & 1) owns rows r' = 2 (w & 1) + r of every lane's four.
+            const int rr = GR_WN == 16 ? 2 * (wave & 1) + r : r;
+            const int k = kt * 32 + 16 * (wave >> 1) + 4 * (lane >> 4) + rr, n = nt * GR_WN + (GR_WN == 16 ? 0 : 16 * (wave & 1)) + (lane & 15);
             widx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
         }
-        adam_load<4>(A.c, widx, ar);            // moments, parameter, target: requested with the first burst, consumed after the tile
+        adam_load<WOWN>(A.c, widx, ar);         // moments, parameter, target: requested with the first burst, consumed after the tile
     }
     XRegs<IN> xr;
     f32x4 wq = {0.f, 0.f, 0.f, 0.f};
     float w3v = 0.0f;
-    const int nrow0 = is_w ? nt * 32 : (bx - GR_NW) * GR_GROWS;                  // first of the 32 W3 rows this workgroup needs
+    const int nrow0 = is_w ? nt * GR_WN : (bx - GR_NW) * GR_GROWS;               // first of the W3 rows this workgroup needs (GR_WN / GR_GROWS of them)
     if (is_w) {
         build_x_load<IN>(A.x, xr);
         const int t = min(tid, 95);                                                           // 12 rows x 8 float4: the k-tile's 32 image columns
         wq = *reinterpret_cast<const f32x4 *>(A.w1t + (t >> 3) * W1C + kt * 32 + 4 * (t & 7));
     }
     {
-        const int t = min(tid, 63), o = t & 1;
+        const int t = min(tid, 2 * (GR_WN == 16 ? 16 : 32) - 1), o = t & 1;                   // (W and G need the same number of rows in either tiling)
         w3v = A.w3f[(nrow0 + (t >> 1)) * OUT + min(o, OUT - 1)];                              // frozen copy: 512 rows, zero padded
     }
     HeadRegs hr;
@@ -1423,7 +1441,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         wait_arrivals(wait_sync + SY_FLAG, 1u, wait_sync + SY_TIMEOUT);
         d3[tid] = pub_load(A.dd.ws + WS_D3A + tid, true);
     } else if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
-    if (tid < 64) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
+    if (tid < 2 * (GR_WN == 16 ? 16 : 32)) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
     STAMP(kRegion, 1);
     __syncthreads();
     STAMP(kRegion, 2);
@@ -1437,7 +1455,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         // rows >= 500 meet the zero rows of its image)
         {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < HVN; ++u) {
                 const int nl = 2 * u + half;
                 const float2 w = *reinterpret_cast<const float2 *>(w3s + 2 * nl);
                 Bt[nl * GR_PS + mcol] = d2_val(hv[u], w.x, w.y, d3a, d3b);
@@ -1456,33 +1474,61 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         f32x4 blk;
         {
             const int g = lane >> 4, c = lane & 15;
-            const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g, *pb = Bt + (16 * (wave & 1) + c) * GR_PS + 4 * g;
-            f32x4 av[8], bv[8];
+            if constexpr (GR_WN == 32) {
+                const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g, *pb = Bt + (16 * (wave & 1) + c) * GR_PS + 4 * g;
+                f32x4 av[8], bv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
-                bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
+                for (int q = 0; q < 8; ++q) {
+                    av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
+                    bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
+                }
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
+                blk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            } else {
+                // block (k half w >> 1) x the tile's 16 columns, batch half (w & 1): q = 4 (w & 1) .. + 3; the halves meet in LDS and are
+                // added as (half 0) + (half 1) by both waves of the pair
+                const int bh = wave & 1;
+                const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g + 64 * bh, *pb = Bt + c * GR_PS + 4 * g + 64 * bh;
+                f32x4 av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
+                    bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
+                }
+                f32x4 acc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
+                const f32x4 part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wx[(wave * 4 + r) * 64 + lane] = part[r];
+                __syncthreads();
+                f32x4 p0, p1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p0[r] = wx[((wave & ~1) * 4 + r) * 64 + lane]; p1[r] = wx[((wave | 1) * 4 + r) * 64 + lane]; }
+                blk = p0 + p1;
             }
-            f32x4 acc[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
-            blk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         STAMP(kRegion, 5);
         {
             float *gW2 = A.grad + off_w2(IN);
-            float val[4];
+            float val[WOWN];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                val[r] = blk[r];
+            for (int r = 0; r < WOWN; ++r) {
+                val[r] = GR_WN == 16 ? blk[2 * (wave & 1) + r] : blk[r];
                 if (widx[r] >= 0) gW2[widx[r] - off_w2(IN)] = val[r];
             }
             STAMP(kRegion, 6);
-            if (fz) adam_apply<4>(*fz, widx, val, ar);
+            if (fz) adam_apply<WOWN>(*fz, widx, val, ar);
             STAMP(kRegion, 7);
         }
     } else {
