@@ -226,3 +226,49 @@ def test_every_form_of_the_act_kernel_writes_the_same_bytes():
         assert r.returncode == 0, r.stderr[-2000:]
         got[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("FORMS")][-1]
     assert len(set(got.values())) == 1, got
+
+
+_LOAD_SCRIPT = r"""
+import sys, zlib, importlib
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import util as U
+S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg"); R = importlib.import_module(U.PKG_NAME + ".replay")
+import torch
+n = 4096
+tab = S.tables.synthetic_table("train", 98)
+env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+ag = D.Agent(seed=7)
+env.reset_(3, episode=0)
+st = env.state; ag.set_norm(st.min(0), st.max(0))
+ring = R.ReplayRing(24000)
+ret = torch.zeros(n, dtype=torch.float64, device="cuda")
+crc = 0
+for t in range(216):                                   # three episodes, 256 workgroups per launch, no host sync in between
+    if t and t % 72 == 0:
+        env.reset_(3, episode=t // 72)
+    w = D.RingWindow(ring.pos, 333, (t * 333) % n)
+    ag.act_step(env, train=True, tick=t, ring=ring, window=w, returns_acc=ret)
+    ring.pushed += 333
+torch.cuda.synchronize()
+env.check_error()
+for a in (env.state, env.idx, ring.s2.cpu().numpy(), ring.a.cpu().numpy(), ring.r.cpu().numpy(), ret.cpu().numpy()):
+    crc = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc)
+print("LOAD", crc)
+"""
+
+
+def test_split_tiles_give_the_same_bytes_whichever_half_arrives_second():
+    """The column-split form (two workgroups per env tile, one 8-byte exchange per env, the finisher is whoever arrives second) over 216
+    back-to-back launches of 256 workgroups: arrival order varies from launch to launch and tile to tile, the result may not.  Three
+    runs of the split form and one of the 8-wave form (no hand-off at all) must end with identical env state, returns and ring."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _LOAD_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    got = []
+    for form in ("9", "9", "9", "8"):
+        e = dict(os.environ); e["SHEMS_ACT_FORM"] = form
+        r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append([ln for ln in r.stdout.splitlines() if ln.startswith("LOAD")][-1])
+    assert len(set(got)) == 1, got
