@@ -109,6 +109,24 @@ def test_tracking_passes_of_a_job_in_one_launch():
     one.close()
 
 
+@pytest.mark.gpu
+def test_tracking_pass_past_the_end_of_the_table_is_a_bounds_error():
+    """next_state! reads row idx + 1: one hour more than the table holds is Julia's BoundsError in the reference (LU1:265-279).  The
+    one-launch pass stops at that hour, raises the sticky error, and everything up to it is intact (bit-exact with the oracle)."""
+    H = _H()
+    S = U.pkg()
+    ev = S.tables.synthetic_table("eval", 98)                 # 1440 rows: 1439 hours are possible from row 1
+    env = S.ShemsBatch(2, 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    with pytest.raises(S._capi.BoundsError):
+        H.inference(env, track=-0.5, num_steps=1445)
+    assert (env.idx == 1440).all() and (env.step == 1439).all()      # stopped at the last row, 1439 hours done
+    total, res = H.inference(env, track=-0.5, num_steps=1439)         # the handle works on after the error was read
+    ref = oracle_c.Batch(1, 1439, ev, oracle_c.profile(98))
+    tot_ref, res_ref = ref.rule_episode(0, 1439, want_results=True)
+    assert (U.bits64(res) == U.bits64(res_ref)).all() and (total == tot_ref).all()
+    env.close()
+
+
 def test_checkpoint_roundtrip_and_reference_file_stems(tmp_path):
     CK = importlib.import_module(U.PKG_NAME + ".checkpoint")
     import ddpg_oracle as DO

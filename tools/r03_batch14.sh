@@ -1,4 +1,4 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 900 python3 -m pytest tests/test_policy_gpu.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 900 python3 -m pytest tests/test_harness.py -m gpu -x -q 2>&1 | tail -15
