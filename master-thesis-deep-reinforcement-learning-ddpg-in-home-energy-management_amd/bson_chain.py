@@ -146,7 +146,8 @@ def lower_dense(W_in_out, b, act):
             "data": [W, lower_array(np.asarray(b, np.float32)), _fn(*fpath)]}
 
 
-def lower_chain(flat, in_dim, out_dim, final_act):
+def lower_chain(flat, in_dim, out_dim, final_act, hidden=None):
+    L1, L2 = hidden if hidden is not None else (globals()["L1"], globals()["L2"])     # Dense widths of THIS chain (default: the tuned 250, 500)
     flat = np.asarray(flat, np.float32).reshape(-1)
     sizes = [in_dim * L1, L1, L1 * L2, L2, L2 * out_dim, out_dim]
     if flat.size != sum(sizes):
@@ -205,8 +206,10 @@ def read_file(path):
     return {k: _resolve(v, refs) for k, v in doc.items()}
 
 
-def load_chain(path, key="actor"):
-    """-> flat float32 parameter vector in Flux.params order (W1 b1 W2 b2 W3 b3), each W as this package's [in][out] block."""
+def load_chain(path, key="actor", hidden=None):
+    """-> flat float32 parameter vector in Flux.params order (W1 b1 W2 b2 W3 b3), each W as this package's [in][out] block.
+    hidden: the (L1, L2) the file must hold (default: the tuned 250, 500)."""
+    L1, L2 = hidden if hidden is not None else (globals()["L1"], globals()["L2"])
     doc = read_file(path)
     if key not in doc:
         raise KeyError(f"{path} holds {sorted(doc)}, not {key!r}")
@@ -220,9 +223,9 @@ def load_chain(path, key="actor"):
     return np.concatenate([a.astype(np.float32).ravel(order="F") for a in arrs])
 
 
-def save_chain(path, flat, in_dim=9, out_dim=2, final_act="tanh", key="actor"):
+def save_chain(path, flat, in_dim=9, out_dim=2, final_act="tanh", key="actor", hidden=None):
     with open(path, "wb") as fh:
-        fh.write(encode_document({key: lower_chain(flat, in_dim, out_dim, final_act)}))
+        fh.write(encode_document({key: lower_chain(flat, in_dim, out_dim, final_act, hidden)}))
     return path
 
 

@@ -27,10 +27,12 @@ def save(actor, total_reward, score_mean, best_run, noise_mean, *, idx, ep_len=7
     st = stem(ep_len, num_ep, l1, l2, case, rng, out_dir, path)
     os.makedirs(os.path.dirname(st), exist_ok=True)
     a = np.asarray(actor.detach().cpu().numpy() if hasattr(actor, "detach") else actor, np.float32).reshape(-1)
-    if a.size != N_ACTOR:
-        raise ValueError(f"actor must hold {N_ACTOR} parameters (Flux order W1 b1 W2 b2 W3 b3)")
+    want = 9 * l1 + l1 + l1 * l2 + l2 + l2 * 2 + 2              # the (9 -> l1 -> l2 -> 2) chain the file name announces
+    if a.size != want:
+        raise ValueError(f"actor must hold {want} parameters for (L1, L2) = ({l1}, {l2}) (Flux order W1 b1 W2 b2 W3 b3); got {a.size} "
+                         "(a learner of a smaller network exports its own size: Agent.export_actor)")
     if fmt == "bson":
-        bson_chain.save_chain(f"{st}_actor_{idx}.bson", a, 9, 2, "tanh", key="actor")
+        bson_chain.save_chain(f"{st}_actor_{idx}.bson", a, 9, 2, "tanh", key="actor", hidden=(l1, l2))
         bson_chain.save_scores(f"{st}_scores_{idx}.bson", total_reward, score_mean, best_run, noise_mean)
     else:
         np.savez(f"{st}_actor_{idx}.npz", actor=a, layout=np.array("Flux.params order; W = [in][out] C view of Julia out x in"))
@@ -47,7 +49,7 @@ def load(*, idx, scores_only=False, ep_len=72, num_ep=1001, l1=250, l2=500, case
         scores = (np.asarray(tr, np.float32), np.asarray(sm, np.float64), int(br), np.asarray(nm, np.float32))
         if scores_only:
             return scores
-        return (bson_chain.load_chain(f"{st}_actor_{idx}.bson", key="actor"),) + scores
+        return (bson_chain.load_chain(f"{st}_actor_{idx}.bson", key="actor", hidden=(l1, l2)),) + scores
     with np.load(f"{st}_scores_{idx}.npz", allow_pickle=False) as z:
         scores = (z["total_reward"], z["score_mean"], int(z["best_run"]), z["noise_mean"])
     if scores_only:

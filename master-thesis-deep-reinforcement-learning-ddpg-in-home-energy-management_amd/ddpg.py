@@ -130,12 +130,52 @@ def perturb_shift(seed, tick, mu, sigma):
     return float(f32(mu + sigma * z))
 
 
-def init_params(seed, in_dim, out_dim, which):
+def net_size(in_dim, out_dim, hidden=(L1, L2)):
+    h1, h2 = hidden
+    return in_dim * h1 + h1 + h1 * h2 + h2 + h2 * out_dim + out_dim
+
+
+def _blocks(flat, in_dim, out_dim, hidden):
+    h1, h2 = hidden
+    o = np.cumsum([0, in_dim * h1, h1, h1 * h2, h2, h2 * out_dim, out_dim])
+    shapes = [(in_dim, h1), (h1,), (h1, h2), (h2,), (h2, out_dim), (out_dim,)]
+    return [np.asarray(flat[o[i]:o[i + 1]]).reshape(sh) for i, sh in enumerate(shapes)]
+
+
+def pad_net(flat, in_dim, out_dim, hidden):
+    """A (in -> h1 -> h2 -> out) network, h1 <= 250, h2 <= 500, in the flat Flux layout -> the (250, 500) layout the kernels are built
+    for, the extra hidden units carrying ZERO weights and biases.  The padded network computes the same function, and it stays padded
+    under training: an extra unit's pre-activation is exactly 0, relu and its mask (pre > 0) give 0, so every gradient entry that
+    touches it is exactly 0 and ADAM (m = v = 0 -> step 0 / (0 + eps)) and the soft update leave the zeros in place.  This is how the
+    (200, 400) and (150, 300) points of the reference's grids (input09_08_on_01-09_eval.jl:62-66, input.jl:58-66) run on this build."""
+    h1, h2 = hidden
+    if (h1, h2) == (L1, L2):
+        return np.asarray(flat, f32).copy()
+    if not (1 <= h1 <= L1 and 1 <= h2 <= L2):
+        raise NotImplementedError(f"hidden sizes {hidden}: libshems_hip.so is built for at most ({L1}, {L2})")
+    W1, b1, W2, b2, W3, b3 = _blocks(np.asarray(flat, f32), in_dim, out_dim, hidden)
+    P1, q1, P2, q2, P3 = (np.zeros(sh, f32) for sh in ((in_dim, L1), (L1,), (L1, L2), (L2,), (L2, out_dim)))
+    P1[:, :h1], q1[:h1], P2[:h1, :h2], q2[:h2], P3[:h2] = W1, b1, W2, b2, W3
+    return np.concatenate([P1.ravel(), q1, P2.ravel(), q2, P3.ravel(), b3.astype(f32)])
+
+
+def unpad_net(flat, in_dim, out_dim, hidden):
+    """The inverse of pad_net (what a checkpoint of the smaller network holds)."""
+    h1, h2 = hidden
+    if (h1, h2) == (L1, L2):
+        return np.asarray(flat, f32).copy()
+    W1, b1, W2, b2, W3, b3 = _blocks(np.asarray(flat, f32), in_dim, out_dim, (L1, L2))
+    return np.concatenate([W1[:, :h1].ravel(), b1[:h1], W2[:h1, :h2].ravel(), b2[:h2], W3[:h2].ravel(), b3])
+
+
+def init_params(seed, in_dim, out_dim, which, hidden=(L1, L2)):
     """Network initialisation of DDPG.jl:21-46 in the flat Flux layout: glorot_uniform for the two
     hidden layers, U(-3e-3, 3e-3) for the last, zero biases.  The uniforms come from Philox (the
-    reference's shared MersenneTwister(rng_run) stream is not reproducible outside Julia)."""
+    reference's shared MersenneTwister(rng_run) stream is not reproducible outside Julia).  hidden != (250, 500): the network
+    of that size (true fan-in / fan-out in the glorot bound), returned in ITS OWN flat layout -- pad_net embeds it."""
     out = []
-    for li, (fan_in, fan_out) in enumerate([(in_dim, L1), (L1, L2), (L2, out_dim)]):
+    h1, h2 = hidden
+    for li, (fan_in, fan_out) in enumerate([(in_dim, h1), (h1, h2), (h2, out_dim)]):
         n = fan_in * fan_out
         q = np.arange((n + 3) // 4, dtype=np.uint64)
         xs = _philox(q, li, which, _STREAM_INIT, seed & 0xFFFFFFFF, seed >> 32)
@@ -152,7 +192,7 @@ class Agent:
     """The DDPG learner state on one GPU (one replica under data parallelism)."""
 
     def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None, noise_type="gn", theta=0.15,
-                 dt=1e-2, eps=0.5, tensors=None):
+                 dt=1e-2, eps=0.5, tensors=None, hidden=(L1, L2)):
         """tensors: dict of float32 device views (actor, critic, actor_t, critic_t, m_actor, v_actor, m_critic, v_critic,
         grad_actor, grad_critic, s_min, s_max, ws, losses) in memory the caller owns -- a learner group's slab -- instead
         of buffers allocated here."""
@@ -168,8 +208,11 @@ class Agent:
         # pn = ParamNoise(mu, sigma, noise_act, 1.01), input.jl:237
         self.pn_sigma, self.pn_target, self.pn_adoption, self.pn_shift = float(f32(sigma)), NOISE_ACT, 1.01, 0.0
         self.actor_perturb = None                  # actor_perturb = deepcopy(actor), DDPG.jl:39
-        a = init_params(self.seed, STATE, ACTION, 0)
-        c = init_params(self.seed, STATE + ACTION, 1, 1)
+        self.hidden = (int(hidden[0]), int(hidden[1]))        # Dense widths; smaller than (250, 500): zero-padded (pad_net)
+        if self.hidden != (L1, L2) and noise_type == "pn":
+            raise NotImplementedError("parameter noise adds one scalar to EVERY parameter (DDPG.jl:89-96): it would un-zero the padding of a smaller network")
+        a = pad_net(init_params(self.seed, STATE, ACTION, 0, self.hidden), STATE, ACTION, self.hidden)
+        c = pad_net(init_params(self.seed, STATE + ACTION, 1, 1, self.hidden), STATE + ACTION, 1, self.hidden)
         assert a.size == N_ACTOR and c.size == N_CRITIC
         nws = C.c_int64(0)
         _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
@@ -235,8 +278,23 @@ class Agent:
         for k, v in host.items():
             setattr(self, k, list(v) if isinstance(v, list) else v)
 
+    def export_actor(self, tensor=None):
+        """The actor (or `tensor`, e.g. the target) as the flat Flux-layout vector of ITS network size (what a checkpoint holds)."""
+        src = self.actor if tensor is None else tensor
+        return unpad_net(src.detach().cpu().numpy(), STATE, ACTION, self.hidden)
+
+    def export_critic(self, tensor=None):
+        src = self.critic if tensor is None else tensor
+        return unpad_net(src.detach().cpu().numpy(), STATE + ACTION, 1, self.hidden)
+
     def set_params(self, actor=None, critic=None, sync_targets=True):
+        """actor / critic: flat Flux-layout vectors, either of this learner's network size (padded here) or already in the (250, 500)
+        layout."""
         t = self.torch
+        if actor is not None and np.asarray(actor).size != N_ACTOR:
+            actor = pad_net(actor, STATE, ACTION, self.hidden)
+        if critic is not None and np.asarray(critic).size != N_CRITIC:
+            critic = pad_net(critic, STATE + ACTION, 1, self.hidden)
         if actor is not None:
             self.actor.copy_(t.as_tensor(np.asarray(actor, f32)))
             if sync_targets:
@@ -498,7 +556,7 @@ class Agent:
                 score_mean[idx - 1] = self.sync.mean_scalar(score.mean().item(), env_eval.n)
                 if score_mean[idx - 1] > best_score:
                     best_score, best_run = score_mean[idx - 1], i
-                    best_actor = self.actor.detach().cpu().numpy().copy()
+                    best_actor = self.export_actor()
                     if on_best:                                             # saveBSON(...; idx=i, path="temp"), DDPG.jl:282-286
                         on_best(i, best_actor, total_reward, score_mean)
                 if on_eval:

@@ -179,8 +179,9 @@ def config_from_env(environ=os.environ):
 
 
 def _check_supported(cfg):
-    if (cfg.L1, cfg.L2) != (250, 500):
-        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2}); libshems_hip.so is built for the tuned (250, 500)")
+    if not (1 <= cfg.L1 <= 250 and 1 <= cfg.L2 <= 500):
+        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2}); libshems_hip.so is built for the tuned (250, 500) "
+                                  "and runs smaller networks zero-padded into it (ddpg.pad_net), not larger ones")
     if not 1 <= cfg.BATCH_SIZE <= 128:
         raise NotImplementedError(f"JOB_ID {cfg.job_id} selects BATCH_SIZE = {cfg.BATCH_SIZE}; the update kernels hold at most 128 columns")
 
@@ -225,7 +226,8 @@ def main(environ=os.environ, cwd=".", log=print):
     env_track = mk(1, EP_LENGTH[cfg.season, cfg.run], tabs[cfg.run])
 
     D.GAMMA, D.TAU = cfg.gamma, cfg.tau
-    agent = D.Agent(seed=cfg.rng_run, sigma=cfg.noise_act if cfg.noise_type == "gn" else cfg.sigma, noise_type=cfg.noise_type, theta=cfg.theta)
+    agent = D.Agent(seed=cfg.rng_run, sigma=cfg.noise_act if cfg.noise_type == "gn" else cfg.sigma, noise_type=cfg.noise_type, theta=cfg.theta,
+                    hidden=(cfg.L1, cfg.L2))
     agent.gamma, agent.tau, agent.batch = float(np.float32(cfg.gamma)), float(np.float32(cfg.tau)), cfg.BATCH_SIZE
     agent.eta_act, agent.eta_crit = float(np.float32(cfg.eta_act)), float(np.float32(cfg.eta_crit))
     ring = D.ReplayRing(cfg.MEM_SIZE)
@@ -247,7 +249,7 @@ def main(environ=os.environ, cwd=".", log=print):
         total_reward, score_mean, best_eval, _ = agent.run_episodes(env_train, env_eval, ring, cfg.NUM_EP, test_every=cfg.test_every,
                                                                     test_runs=cfg.test_runs, seed=cfg.rng_run, on_best=on_best)
         noise_mean = agent.noise_mean
-        checkpoint.save(agent.actor, total_reward, score_mean, best_eval, noise_mean, idx=cfg.NUM_EP, rng=cfg.rng_run, **ck)   # MAIN:45-46
+        checkpoint.save(agent.export_actor(), total_reward, score_mean, best_eval, noise_mean, idx=cfg.NUM_EP, rng=cfg.rng_run, **ck)   # MAIN:45-46
         log(f"trained {cfg.NUM_EP} episodes in {time.time() - t0:.1f} s; best evaluation at episode {best_eval}")
 
     # ---- track evaluation (MAIN:87-110) ----
@@ -271,7 +273,8 @@ def main(environ=os.environ, cwd=".", log=print):
             passes.append((test_rng_run, True, best_i, checkpoint.load(idx=best_i, rng=test_rng_run, path="temp", **ck)[0]))
         if passes:
             env_many = mk(len(passes), EP_LENGTH[cfg.season, cfg.run], tabs[cfg.run])
-            _, results = harness.inference_many(env_many, np.stack([p[3] for p in passes]), agent.s_min, agent.s_max)
+            hid = (cfg.L1, cfg.L2)                                       # checkpoints hold the network's own size: pad into the kernels' layout
+            _, results = harness.inference_many(env_many, np.stack([D.pad_net(p[3], 9, 2, hid) for p in passes]), agent.s_min, agent.s_max)
             env_many.close()
             for (test_rng_run, best, idx, _), res in zip(passes, results):
                 path = harness.results_file_name(cfg.job_id, cfg.run, EP_LENGTH["train"], cfg.NUM_EP, cfg.L1, cfg.L2, cfg.case, test_rng_run,

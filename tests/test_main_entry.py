@@ -103,3 +103,24 @@ def test_entry_script_on_a_charger_with_real_series(tmp_path):
     assert any("padded with the rows 24 h earlier" in l for l in logs)
     rows = list(csv.reader(open(tmp_path / written[0])))
     assert len(rows) == 1 + 1439 and np.isfinite(np.array(rows[1:], float)).all()
+
+
+@pytest.mark.gpu
+def test_entry_script_on_the_200_400_grid_point(tmp_path):
+    """JOB_ID suffix 03 = ternary 0010 of the tuned template: (L1, L2) = (200, 400) (input09_08_on_01-09_eval.jl:62-66).  The learner runs
+    zero-padded on the (250, 500) kernels (ddpg.pad_net); the checkpoints hold the 200 x 400 chain and the file names say so."""
+    pytest.importorskip("torch")
+    env = {"JOB_ID": "1179803", "TASK_ID": "1", "GPU_ID": "0", "SHEMS_NUM_EP": "2", "SHEMS_NUM_SEEDS": "1", "SHEMS_NUM_ENVS": "64",
+           "SHEMS_SYNTHETIC_DATA": "1"}
+    cwd0 = os.getcwd()
+    try:
+        cfg, written = M.main(env, cwd=str(tmp_path), log=lambda *_: None)
+    finally:
+        os.chdir(cwd0)
+    assert (cfg.L1, cfg.L2) == (200, 400) and len(written) == 2 and all("_200_400_" in w for w in written)
+    B = importlib.import_module(U.PKG_NAME + ".bson_chain")
+    stem = f"DDPG_Shems_Charger_v1_72_2_200_400_{cfg.case}_1231"
+    a = B.load_chain(str(tmp_path / f"out/bson/{stem}_actor_2.bson"), hidden=(200, 400))
+    assert a.size == 9 * 200 + 200 + 200 * 400 + 400 + 400 * 2 + 2 and np.isfinite(a).all() and np.count_nonzero(a) > 80000
+    rows = list(csv.reader(open(tmp_path / written[0])))
+    assert len(rows) == 1 + 1439 and np.isfinite(np.array(rows[1:], float)).all()
