@@ -358,6 +358,13 @@ int shems_minmax_group_dev(const shems_replay *ring0, const shems_group *g, int6
  *   perturb:    d_perturbed[i] = d_params[i] + shift, i < n
  *   batch_obs:  the s rows of the minibatch the last shems_ddpg_critic_grad(_ex) sampled -> d_obs [batch][9]
  *   distance:   d_out[0] = sqrt(mean((d_a - d_b)^2)) over `count` floats */
+/* BATCH_SIZE above 128 (the tuned template's 150, input.jl's 200): one update pass holds 128 minibatch columns, so replay() runs the
+ * gradient calls once per SUB-BATCH (each on its own workspace and gradient buffer, `batch` = the sub-batch size: its gradient is
+ * the mean over the sub-batch) and combines them, acc = w_acc * acc + w_g * g with w_g = sub-batch size / BATCH_SIZE, before the one
+ * ADAM step -- Flux.mse / -mean(q) over the whole minibatch (DDPG.jl:134-140) is exactly that weighted mean of sub-batch means.
+ * w_acc == 0: acc is overwritten (never read). */
+int shems_ddpg_combine_dev(float *d_acc, const float *d_g, int64_t n, float w_acc, float w_g, void *stream);
+
 int shems_ddpg_perturb_dev(const float *d_params, float *d_perturbed, int64_t n, float shift, void *stream);
 int shems_ddpg_batch_obs_dev(const shems_ddpg *d, const shems_replay *ring, float *d_obs, void *stream);
 int shems_action_distance_dev(const float *d_a, const float *d_b, int64_t count, float *d_out, void *stream);

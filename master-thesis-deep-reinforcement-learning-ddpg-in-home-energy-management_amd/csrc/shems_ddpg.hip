@@ -1637,6 +1637,14 @@ __global__ __launch_bounds__(256) void k_perturb(const float *__restrict__ src, 
     if (i < n) dst[i] = src[i] + shift;
 }
 
+// acc = wa * acc + wg * g (wa == 0: acc is not read, so it may hold anything, NaNs included): gradients of the sub-batches of a minibatch
+// wider than the 128 columns one update pass holds, each the MEAN over its sub-batch, weighted by sub-batch size / batch size
+__global__ __launch_bounds__(256) void k_combine(float *__restrict__ acc, const float *__restrict__ g, int64_t n, float wa, float wg)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = wa == 0.0f ? wg * g[i] : fmaf(wa, acc[i], wg * g[i]);
+}
+
 // s of the minibatch the last update sampled (ring slots kept in the workspace) -> obs [batch][9]
 __global__ __launch_bounds__(256) void k_batch_obs(shems_replay ring, const float *__restrict__ ws, int batch, float *__restrict__ obs)
 {
@@ -1983,6 +1991,13 @@ int shems_ddpg_perturb_dev(const float *d_params, float *d_perturbed, int64_t n,
     if (!d_params || !d_perturbed || n < 1) return set_error(SHEMS_ERR_ARG, "shems_ddpg_perturb_dev: bad arguments");
     hipLaunchKernelGGL(k_perturb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_params, d_perturbed, n, shift);
     return hip_ok(hipGetLastError(), "k_perturb launch");
+}
+
+int shems_ddpg_combine_dev(float *d_acc, const float *d_g, int64_t n, float w_acc, float w_g, void *stream)
+{
+    if (!d_acc || !d_g || n < 1) return set_error(SHEMS_ERR_ARG, "shems_ddpg_combine_dev: bad arguments");
+    hipLaunchKernelGGL(k_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_acc, d_g, n, w_acc, w_g);
+    return hip_ok(hipGetLastError(), "k_combine launch");
 }
 
 int shems_ddpg_batch_obs_dev(const shems_ddpg *d, const shems_replay *ring, float *d_obs, void *stream)

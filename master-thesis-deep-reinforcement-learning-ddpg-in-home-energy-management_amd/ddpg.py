@@ -91,6 +91,8 @@ def _declare():
     L.shems_ddpg_sample_indices.argtypes = [C.c_uint64, C.c_uint32, C.c_int32, i64, vp]
     L.shems_minmax_dev.argtypes = [C.POINTER(_capi.Replay), i64, i64, C.c_uint64, vp, vp, vp]
     L.shems_ddpg_perturb_dev.argtypes = [vp, vp, i64, C.c_float, vp]
+    L.shems_ddpg_combine_dev.argtypes = [vp, vp, i64, C.c_float, C.c_float, vp]
+    L.shems_ddpg_combine_dev.restype = C.c_int
     L.shems_ddpg_batch_obs_dev.argtypes = [PD, C.POINTER(_capi.Replay), vp, vp]
     L.shems_action_distance_dev.argtypes = [vp, vp, i64, vp, vp]
     for fn in ("shems_ddpg_perturb_dev", "shems_ddpg_batch_obs_dev", "shems_action_distance_dev"):
@@ -393,12 +395,63 @@ class Agent:
                                               C.byref(window) if window is not None else None, self._stream()))
 
     # ---------------------------------------------------------------- learner
-    def _ddpg_args(self):
+    MAX_PASS_BATCH = 128                           # minibatch columns one update pass holds (csrc/shems_ddpg.hip: BP)
+
+    def _ddpg_args(self, sub=None):
+        """sub: a sub-batch record (its own workspace, gradient buffers, losses, size) of a minibatch wider than one pass."""
+        ga, gc, ws, ls, b = ((self.grad_actor, self.grad_critic, self.ws, self.losses, self.batch) if sub is None else
+                             (sub["ga"], sub["gc"], sub["ws"], sub["losses"], sub["batch"]))
+        defer = self.sync.world > 1 and self.dp_overlap and sub is None and self.batch <= self.MAX_PASS_BATCH
         return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
                         self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
-                        self.grad_actor.data_ptr(), self.grad_critic.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
-                        self.ws.data_ptr(), self.losses.data_ptr(), self.gamma, self.tau, self.batch,
-                        1 if (self.sync.world > 1 and self.dp_overlap) else 0)                # SHEMS_DDPG_DEFER_ACTOR_E
+                        ga.data_ptr(), gc.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
+                        ws.data_ptr(), ls.data_ptr(), self.gamma, self.tau, b,
+                        1 if defer else 0)                                                    # SHEMS_DDPG_DEFER_ACTOR_E
+
+    def sub_batches(self):
+        """BATCH_SIZE > 128: the near-equal sub-batch sizes replay() runs (150 -> 75 + 75, 200 -> 100 + 100), each with its own
+        workspace and gradient buffers (allocated on first use)."""
+        k = -(-self.batch // self.MAX_PASS_BATCH)
+        sizes = [self.batch // k + (1 if i < self.batch % k else 0) for i in range(k)]
+        cur = getattr(self, "_subs", None)
+        if cur is None or [x["batch"] for x in cur] != sizes:
+            t = self.torch
+            z = lambda n: t.zeros(n, dtype=t.float32, device=self.device)
+            self._subs = [dict(batch=b, ws=z(self.ws.numel()), gc=z(N_CRITIC), ga=z(N_ACTOR), losses=z(2)) for b in sizes]
+        return self._subs
+
+    def _replay_wide(self, ring, tick, ex_pos, ex_cnt, publish):
+        """replay() for BATCH_SIZE > 128: the loss is a mean over the minibatch, so its gradient is the size-weighted mean of the
+        sub-batches' gradients (shems_ddpg_combine_dev); ONE ADAM step per network, in the reference's order (critic first, the actor
+        through the updated critic, DDPG.jl:134-140).  Sub-batch i draws its indices with sampler tick `tick * 8 + i`."""
+        st = self._stream()
+        rs = ring.struct()
+        subs = self.sub_batches()
+        vp = lambda x: C.c_void_p(x.data_ptr())
+        for i, sb in enumerate(subs):
+            d = self._ddpg_args(sb)
+            _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, (int(tick) * 8 + i) & 0xFFFFFFFF,
+                                                         ex_pos, ex_cnt, st))
+            w = sb["batch"] / self.batch
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_critic), vp(sb["gc"]), N_CRITIC, 0.0 if i == 0 else 1.0, w, st))
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.losses), vp(sb["losses"]), 1, 0.0 if i == 0 else 1.0, w, st))
+        self._allreduce(self.grad_critic)
+        gs = self.sync.grad_scale
+        # the ADAM / soft-update sweeps work on the learner's own (combined) gradient buffers; they do not look at `batch`
+        dm = self._ddpg_args(dict(ga=self.grad_actor, gc=self.grad_critic, ws=self.ws, losses=self.losses, batch=subs[0]["batch"]))
+        _capi.check(self.L.shems_ddpg_critic_apply(C.byref(dm), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+        self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
+        for i, sb in enumerate(subs):
+            d = self._ddpg_args(sb)
+            _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
+            w = sb["batch"] / self.batch
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_actor), vp(sb["ga"]), N_ACTOR, 0.0 if i == 0 else 1.0, w, st))
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.losses[1:]), vp(sb["losses"][1:]), 1, 0.0 if i == 0 else 1.0, w, st))
+        self._allreduce(self.grad_actor)
+        _capi.check(self.L.shems_ddpg_actor_apply_pub(C.byref(dm), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs,
+                                                      C.c_void_p(publish.data_ptr()) if publish is not None else None, st))
+        self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
+        self.updates += 1
 
     def enable_data_parallel(self, dist):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
@@ -417,6 +470,10 @@ class Agent:
         rs = ring.struct()
         tick = self.updates if tick is None else tick
         ex_pos, ex_cnt = (0, 0) if exclude is None else (int(exclude[0]) % ring.capacity, int(exclude[1]))
+        if self.batch > self.MAX_PASS_BATCH:
+            if self.noise_type == "pn":
+                raise NotImplementedError("parameter-noise adaptation with BATCH_SIZE > 128")
+            return self._replay_wide(ring, tick, ex_pos, ex_cnt, publish)
         if self.fused and self.sync.world == 1 and self.noise_type != "pn":
             # one replica, nothing to exchange and no parameter-noise adaptation between getData and the updates: the whole
             # replay() is one call (K1..K5, csrc/shems_ddpg.hip)
@@ -459,9 +516,10 @@ class Agent:
         _capi.check(self.L.shems_ddpg_sync_timeouts(C.byref(d), C.byref(out), self._stream()))
         return out.value
 
-    def sample_indices(self, tick, ring_len):
-        out = np.empty(self.batch, np.int64)
-        _capi.check(self.L.shems_ddpg_sample_indices(self.rng_seed, int(tick) & 0xFFFFFFFF, self.batch, int(ring_len),
+    def sample_indices(self, tick, ring_len, batch=None):
+        batch = self.batch if batch is None else int(batch)
+        out = np.empty(batch, np.int64)
+        _capi.check(self.L.shems_ddpg_sample_indices(self.rng_seed, int(tick) & 0xFFFFFFFF, batch, int(ring_len),
                                                      out.ctypes.data_as(C.c_void_p)))
         return out
 

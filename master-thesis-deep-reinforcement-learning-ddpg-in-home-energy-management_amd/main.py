@@ -182,8 +182,8 @@ def _check_supported(cfg):
     if not (1 <= cfg.L1 <= 250 and 1 <= cfg.L2 <= 500):
         raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2}); libshems_hip.so is built for the tuned (250, 500) "
                                   "and runs smaller networks zero-padded into it (ddpg.pad_net), not larger ones")
-    if not 1 <= cfg.BATCH_SIZE <= 128:
-        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects BATCH_SIZE = {cfg.BATCH_SIZE}; the update kernels hold at most 128 columns")
+    if not 1 <= cfg.BATCH_SIZE <= 1024:             # above 128: replay() runs the gradient passes per sub-batch (ddpg.Agent._replay_wide)
+        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects BATCH_SIZE = {cfg.BATCH_SIZE}")
 
 
 def data_path(cfg, split, data_dir="data", charger=None):

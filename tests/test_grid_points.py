@@ -1,5 +1,6 @@
-"""Smaller networks on the (250, 500) kernels by exact zero padding (ddpg.pad_net): the (200, 400) and (150, 300) points of the
-reference's hyper-parameter grids (input09_08_on_01-09_eval.jl:62-66, input.jl:58-66).  "Parity unpinned" like the rest of the learner:
+"""The other points of the reference's hyper-parameter grids (input09_08_on_01-09_eval.jl:62-66, input.jl:58-66) that run on this build:
+smaller networks -- (200, 400), (150, 300) -- on the (250, 500) kernels by exact zero padding (ddpg.pad_net), and BATCH_SIZE above the
+128 columns of one update pass -- 150, 200 -- as size-weighted sub-batches with ONE ADAM step (ddpg.Agent._replay_wide).  "Parity unpinned" like the rest of the learner:
 the oracle here is the NumPy restatement run at the smaller size."""
 import importlib
 import os
@@ -157,3 +158,57 @@ def test_small_network_on_the_gpu(small_oracle):
     env.check_error()
     env.close()
     assert ag.sync_timeouts() == 0
+
+
+def test_job_ids_of_wide_batches_are_accepted():
+    M = importlib.import_module(U.PKG_NAME + ".main")
+    cfg = M.config_from_env({"JOB_ID": "11709862", "TASK_ID": "1", "GPU_ID": "0"})      # 62 = 2022 (base 3): BATCH 150, (250, 500)
+    assert cfg.BATCH_SIZE == 150 and (cfg.L1, cfg.L2) == (250, 500)
+    M._check_supported(cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [150, 200])
+def test_wide_minibatch_update_matches_the_oracle_on_the_whole_batch(batch):
+    """BATCH_SIZE = 150 (tuned template) / 200 (input.jl): replay() runs two gradient passes of 75 / 100 columns and combines them
+    before ONE ADAM step per network.  The oracle takes the SAME transitions as one minibatch of 150 / 200 (Flux.mse and -mean(q) over
+    all of them, DDPG.jl:134-140): parameters, targets and moments must agree as for the one-pass update."""
+    torch = pytest.importorskip("torch")
+    S = U.pkg()
+    D = _D()
+    rng = np.random.default_rng(8)
+    ag = D.Agent(seed=31)
+    ag.batch = batch
+    pa, pc = D.init_params(31, 9, 2, 0), D.init_params(31, 11, 1, 1)
+    pa[128000:129000] *= 30; pc[128250:128750] *= 30
+    ag.set_params(actor=pa, critic=pc)
+    cap = 24000
+    tab = S.tables.synthetic_table("train", 98)
+    ring = D.ReplayRing(cap)
+    rows = tab[rng.integers(0, tab.shape[0] - 1, cap)]
+    s = np.empty((cap, 9), np.float32); s[:, 0] = rng.random(cap) * 6.75; s[:, 1:] = rows[:, [1, 0, 2, 3, 4, 5, 6, 7]]
+    s2 = s.copy(); s2[:, 0] = np.clip(s[:, 0] + rng.normal(0, 1, cap), 0, 6.75)
+    a = (rng.random((cap, 2)) * 2 - 1).astype(np.float32)
+    r = rng.normal(-1, 2, cap).astype(np.float32)
+    for t, v in ((ring.s, s), (ring.a, a), (ring.r, r), (ring.s2, s2)):
+        t.copy_(torch.from_numpy(v))
+    ring.pushed = cap
+    lo, hi = s.min(0), s.max(0)
+    ag.set_norm(lo, hi)
+    sizes = [sb["batch"] for sb in ag.sub_batches()]
+    assert sizes == [batch // 2, batch // 2]
+    L = DO.Learner(pa, pc, lo, hi)
+    for tick in (5, 6):                                                     # two updates: the second with advanced beta powers
+        idx = np.concatenate([ag.sample_indices(tick * 8 + i, len(ring), batch=b) for i, b in enumerate(sizes)])
+        assert idx.shape == (batch,)
+        lc, la = L.replay(s[idx], a[idx], r[idx], s2[idx], np.zeros(batch, bool))
+        ag.replay(ring, tick=tick)
+        torch.cuda.synchronize()
+        for name, got, want in (("critic", ag.critic, L.critic), ("actor", ag.actor, L.actor), ("critic_t", ag.critic_t, L.critic_t),
+                                ("actor_t", ag.actor_t, L.actor_t)):
+            assert np.abs(got.cpu().numpy() - want).max() < 3e-6, (name, tick)
+        np.testing.assert_allclose(ag.m_critic.cpu().numpy(), L.opt_c.m, rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(ag.m_actor.cpu().numpy(), L.opt_a.m, rtol=2e-4, atol=1e-10)
+        losses = ag.losses.cpu().numpy()
+        assert abs(losses[0] - lc) < 1e-4 * max(1.0, abs(lc)) and abs(losses[1] - la) < 1e-4 * max(1.0, abs(la))
+    assert np.abs(ag.critic.cpu().numpy() - pc).max() > 1e-4
