@@ -1293,6 +1293,316 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
 #endif
 }
 
+// =====================================================================================================================
+// k_act2: the fused step for large batches with TWO workgroups resident per CU.
+//
+// k_act's 128-env tile fills a CU's LDS (161 KB), so a CU holds one workgroup at a time and everything outside the MFMA loop -- stage
+// 0, the two layer-1 phases, layer 3, the env tail: 12.5 % of a workgroup's cycles at 65 536 envs, most of it exposed latency -- leaves
+// the matrix pipe idle (the loop itself runs at 99.5 %).  Here a workgroup is a 64-env tile that needs < 80 KB of LDS and <= 256
+// registers per lane, so TWO of them share a CU: while one is in its latency-bound phases the other's waves own the matrix pipe.
+// What makes it fit:
+//   * W2 ring of 4 chunks x 4 rows per wave (8 KB instead of 32): the same 3-chunk prefetch distance in k-steps, a quarter of the bytes;
+//   * relu(layer 1) resident one half at a time (32 KB), as k_act's 128-env tile does;
+//   * no layer-1 operand image in LDS: the 10 weights a lane needs per layer-1 tile come straight from the parameter block (L2) --
+//     their latency is what the other workgroup's MFMAs are for;
+//   * the env tail reads its observations from global memory, not from an LDS copy.
+// Same canonical column order, same arithmetic: the bytes of every other form.
+constexpr int k2CR = 4, k2RD = 4, k2CF = k2CR * 128;                       // chunk rows, ring depth, floats per wave chunk
+constexpr int k2NCH = (kH1 + k2CR - 1) / k2CR;                             // 63 chunks hold rows 0 .. 251 (250, 251: in bounds, never multiplied)
+constexpr int k2_pieces(int ch) { return ch < 0 || ch >= k2NCH ? 0 : ch == k2NCH - 1 ? (kH1 - (k2NCH - 1) * k2CR + 1) / 2 : k2CR / 2; }
+constexpr size_t act2_lds_bytes()
+{
+    return sizeof(float) * (4 * k2RD * k2CF + 16 + 128 * 64 + kW1K * 64 + (kTailFloats + 2) + 64 * kPreDw + 4);
+}
+
+__device__ __forceinline__ void k2_piece(const char *sbase, uint32_t voff, uint32_t lds_base, int q)
+{
+    if (q == 0) glds16_asm<-1024>(sbase, voff, lds_base); else glds16_asm<0>(sbase, voff, lds_base);
+}
+
+__global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
+{
+    constexpr int TM = 2, BM = 64, NA = 4, NT_ = 256, HR = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Wc = reinterpret_cast<float *>(smem);             // [4 waves][RD][4 rows][128] private W2 rings
+    float *Hc = Wc + 4 * k2RD * k2CF + 16;                   // [128][BM] relu(layer 1), one half at a time
+    float *xT = Hc + HR * BM;                                // [10][BM]
+    float *tl = xT + kW1K * BM;                              // b2 [512], W3 [512][2], b3 [2]
+    float *xP = tl + (kTailFloats + 2);                      // [BM][kPreDw] TailPre blocks
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int64_t bid = blockIdx.x;
+    if (A.gcount > 1 && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // a learner's tiles share an XCD
+    const int64_t env0 = bid * BM;
+    const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
+    const int64_t goff = learner * A.gstride;
+    const float *__restrict__ P = gsh(A.p.actor, goff);
+    const float *__restrict__ s_min = gsh(A.p.s_min, goff), *__restrict__ s_max = gsh(A.p.s_max, goff);
+    const int nbase = 128 * wave;                            // this wave's two column groups
+
+    // ---- stage 0 --------------------------------------------------------------------------------------------------------------
+    const char *W2g = reinterpret_cast<const char *>(P + kOffW2);
+    float *Wf = Wc + wave * (k2RD * k2CF);
+    const uint32_t ring_lds = lds_addr(Wf) + 1024;           // piece 1 of ring buffer 0
+    const char *wsbase = W2g + wave * 512;
+    uint32_t wvoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wvoff[q] = (uint32_t)((lane >> 5) * (kH2 * 4) + (lane & 31) * 16 + q * (2 * kH2 * 4) - (q - 1) * 1024);
+#define K2_PIECE(chunk, q) k2_piece(wsbase + (size_t)(chunk) * (k2CR * kH2 * 4), wvoff[q], ring_lds + ((chunk) % k2RD) * (k2CF * 4), (q))
+    TailPre tp;
+    const bool view = A.do_step != 0, multi = view && A.v.n_cfg > 1;
+    {
+        const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
+        const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
+        const uint16_t *pci = multi ? A.v.cfg_of_env : reinterpret_cast<const uint16_t *>(P);
+        tp.idx = pidx[view ? pe : 0];
+        tp.ci = multi ? (int)pci[pe] : 0;
+        tp.step = pstep[view ? pe : 0];
+    }
+    constexpr int kIt = (BM * kIn + NT_ - 1) / NT_;          // 3
+    float sv[kIt], lo[kIt], hi[kIt], tv[6];
+    const int64_t last = A.m * kIn - 1;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = min(it * NT_ + tid, BM * kIn - 1), k = e % kIn;
+        sv[it] = A.obs[min(env0 * kIn + e, last)];
+        lo[it] = s_min[k];
+        hi[it] = s_max[k];
+    }
+#pragma unroll
+    for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + tid, kH2 + kH2 * kOut + kOut - 1)];
+    // layer-1 weights of this wave's two tiles of the FIRST half, straight from the parameter block: tile t = wave + 4 u (u = 0, 1) of the
+    // 8 (row group, env tile) pairs; W1[j][k] and b1[k] are contiguous (row 9 of the "image" is b1), columns >= 250 are zero
+#define K2_L1_LOAD(gbase, a0_, a1_, kA_, kB_)                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                                     \
+        const int j_ = 2 * s_ + lh;                                                               \
+        a0_[s_] = P[j_ * kH1 + min(kA_, kH1 - 1)];                                                \
+        a1_[s_] = P[j_ * kH1 + min(kB_, kH1 - 1)];                                                \
+    }
+    const int t0 = wave, t1 = wave + 4;                      // tiles of a phase: (g, b) = (t / 2, t % 2)
+    const int kA0 = 32 * (t0 >> 1) + li, kB0 = 32 * (t1 >> 1) + li;
+    float wa0[kW1K / 2], wb0[kW1K / 2];
+    K2_L1_LOAD(0, wa0, wb0, kA0, kB0)
+    tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));
+    f32x4 ra, rb;
+    {
+        const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
+        constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
+        const int32_t row0 = pc[o_row0], nrow = pc[o_nrow];
+        const float *tp_tables = view ? A.v.tables : P;
+        const int64_t tp_row = view ? (int64_t)row0 + max(min(tp.idx + 1, nrow), 2) - 1 : 1;
+        const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
+        ra = rp[0]; rb = rp[1];
+        tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int e = it * NT_ + tid, m = e / kIn, k = e - m * kIn;
+        const float x = (sv[it] - lo[it]) / ((hi[it] - lo[it]) + 1e-8f);      // MPS:56
+        if (e < BM * kIn) xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f;
+    }
+    if (tid < BM) xT[kIn * BM + tid] = 1.0f;                                                   // row 9 = 1: the bias input
+    {
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int e = it * 256 + tid;                        // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
+            if (e < kH2) tl[e] = tv[it];
+            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = tv[it];
+            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = tv[it];
+        }
+        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;
+        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT visible
+    // the ring's first three chunks
+#pragma unroll
+    for (int ch = 0; ch < k2RD - 1; ++ch)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) K2_PIECE(ch, q);
+
+    // one phase of layer 1: row groups gbase .. gbase + 3 of the half, two tiles per wave interleaved (the chains of L1_TILE2)
+#define K2_L1_PHASE(gbase, a0_, a1_)                                                              \
+    do {                                                                                          \
+        const int gA_ = (gbase) + (t0 >> 1), bA_ = t0 & 1, gB_ = (gbase) + (t1 >> 1), bB_ = t1 & 1; \
+        float c0_[kW1K / 2], c1_[kW1K / 2], z0_[kW1K / 2], z1_[kW1K / 2];                         \
+        _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                                 \
+            const int j_ = 2 * s_ + lh;                                                           \
+            c0_[s_] = xT[j_ * BM + TM * li + bA_];                                                \
+            c1_[s_] = xT[j_ * BM + TM * li + bB_];                                                \
+            z0_[s_] = 32 * gA_ + li < kH1 ? a0_[s_] : 0.0f;                                       \
+            z1_[s_] = 32 * gB_ + li < kH1 ? a1_[s_] : 0.0f;                                       \
+        }                                                                                         \
+        f32x16 u0_, u1_;                                                                          \
+        asm volatile("s_nop 1\n\t"                                                                \
+                     "v_mfma_f32_32x32x2_f32 %0, %2, %7, 0\n\t"                                   \
+                     "v_mfma_f32_32x32x2_f32 %1, %12, %17, 0\n\t"                                 \
+                     "v_mfma_f32_32x32x2_f32 %0, %3, %8, %0\n\t"                                  \
+                     "v_mfma_f32_32x32x2_f32 %1, %13, %18, %1\n\t"                                \
+                     "v_mfma_f32_32x32x2_f32 %0, %4, %9, %0\n\t"                                  \
+                     "v_mfma_f32_32x32x2_f32 %1, %14, %19, %1\n\t"                                \
+                     "v_mfma_f32_32x32x2_f32 %0, %5, %10, %0\n\t"                                 \
+                     "v_mfma_f32_32x32x2_f32 %1, %15, %20, %1\n\t"                                \
+                     "v_mfma_f32_32x32x2_f32 %0, %6, %11, %0\n\t"                                 \
+                     "v_mfma_f32_32x32x2_f32 %1, %16, %21, %1\n\t"                                \
+                     "s_nop 15\n\ts_nop 7"                                                        \
+                     : "=&v"(u0_), "=&v"(u1_)                                                     \
+                     : "v"(z0_[0]), "v"(z0_[1]), "v"(z0_[2]), "v"(z0_[3]), "v"(z0_[4]),           \
+                       "v"(c0_[0]), "v"(c0_[1]), "v"(c0_[2]), "v"(c0_[3]), "v"(c0_[4]),           \
+                       "v"(z1_[0]), "v"(z1_[1]), "v"(z1_[2]), "v"(z1_[3]), "v"(z1_[4]),           \
+                       "v"(c1_[0]), "v"(c1_[1]), "v"(c1_[2]), "v"(c1_[3]), "v"(c1_[4]));          \
+        float *d0_ = Hc + ((gA_ * 32) % HR) * BM + TM * li + bA_, *d1_ = Hc + ((gB_ * 32) % HR) * BM + TM * li + bB_; \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                       \
+            d0_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(u0_[r_], 0.0f);                 \
+            d1_[((r_ & 3) + 8 * (r_ >> 2) + 4 * lh) * BM] = fmaxf(u1_[r_], 0.0f);                 \
+        }                                                                                         \
+    } while (0)
+    K2_L1_PHASE(0, wa0, wb0);
+    // weights of the second half's two tiles: requested now, consumed after k-step 63
+    float wa1[kW1K / 2], wb1[kW1K / 2];
+    {
+        const int kA1 = 128 + kA0, kB1 = 128 + kB0;
+        K2_L1_LOAD(4, wa1, wb1, kA1, kB1)
+    }
+    tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
+    tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // first half of h1 complete
+
+    // ---- layer 2 ----------------------------------------------------------------------------------------------------------------
+    typedef FVec<NA>::type AVec;
+    typedef FVec<TM>::type BVec;
+    f32x16 acc[NA][TM];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bias = tl[act_col<NA>(nbase, a, (r & 3) + 8 * (r >> 2) + 4 * lh)];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b][r] = bias;
+        }
+    constexpr int kKsteps = kH1 / 2;                         // 125 k-steps of two rows; chunk c = k-steps 2 c, 2 c + 1
+    AVec af_[3];
+    BVec bf_[3];
+    /* k-step K: operands in register buffer K % 3, requested two k-steps ago.  Before the reads of K + 2 open a new chunk the wave waits  */
+    /* for that chunk (its own ring: vmcnt retires in order; the pieces of the chunk after it stay in flight).  The pieces of chunk          */
+    /* (K >> 1) + 3 go out one per k-step, after the k-step's MFMAs.  Nothing of h1's second half is requested before it is laid down.       */
+#define K2_KSTEP(K)                                                                                             \
+    do {                                                                                                        \
+        constexpr int K2_ = (K) + 2, c2_ = K2_ >> 1, klim_ = (K) < 64 ? 64 : kKsteps;                           \
+        if (K2_ < klim_) {                                                                                      \
+            if ((K2_ & 1) == 0) {                                                                               \
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k2_pieces(c2_ + 1)) : "memory");                       \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+            }                                                                                                   \
+            const int kr_ = 2 * (K2_ & 1) + lh;                                                                 \
+            af_[K2_ % 3] = act_load_a<NA>(Wf + (c2_ % k2RD) * k2CF + kr_ * 128, li);                            \
+            bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + ((2 * K2_) % HR + lh) * BM + TM * li);          \
+        }                                                                                                       \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                          \
+            _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[(K) % 3], a), fvec_get<TM>(bf_[(K) % 3], b), acc[a][b], 0, 0, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if (((K) & 1) < k2_pieces(((K) >> 1) + k2RD - 1)) { K2_PIECE(((K) >> 1) + k2RD - 1, (K) & 1); __builtin_amdgcn_sched_barrier(0); } \
+    } while (0)
+#define K2_K4(K) K2_KSTEP(K); K2_KSTEP((K) + 1); K2_KSTEP((K) + 2); K2_KSTEP((K) + 3)
+#define K2_K16(K) K2_K4(K); K2_K4((K) + 4); K2_K4((K) + 8); K2_K4((K) + 12)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k2_pieces(1) + k2_pieces(2)) : "memory");      // chunk 0 has landed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k0 = 0; k0 < 2; ++k0) {
+        af_[k0] = act_load_a<NA>(Wf + (2 * k0 + lh) * 128, li);
+        bf_[k0] = *reinterpret_cast<const BVec *>(Hc + (2 * k0 + lh) * BM + TM * li);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    K2_K16(0); K2_K16(16); K2_K16(32); K2_K16(48);
+    // every wave has read the first half of h1 to the end: rows 128..255 over it, then the operand ring restarts at k-step 64
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    K2_L1_PHASE(4, wa1, wb1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k2_pieces(33) + k2_pieces(34)) : "memory");    // chunk 32 has landed (33, 34 may fly)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k0 = 0; k0 < 2; ++k0) {
+        af_[(64 + k0) % 3] = act_load_a<NA>(Wf + ((32 + (k0 >> 1)) % k2RD) * k2CF + (2 * (k0 & 1) + lh) * 128, li);
+        bf_[(64 + k0) % 3] = *reinterpret_cast<const BVec *>(Hc + (2 * k0 + lh) * BM + TM * li);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    K2_K16(64); K2_K16(80); K2_K16(96); K2_K4(112); K2_K4(116); K2_K4(120); K2_KSTEP(124);
+
+    // ---- layer 3, canonical order; the group sums go to the start of this wave's own (dead) ring ---------------------------------
+    const float *w3s = tl + kH2P;
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl) {
+        float u0[TM], u1[TM];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int a = 2 * gl + t;
+            float o0[TM], o1[TM];
+#pragma unroll
+            for (int b = 0; b < TM; ++b) { o0[b] = 0.0f; o1[b] = 0.0f; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = act_col<NA>(nbase, a, (r & 3) + 8 * (r >> 2) + 4 * lh);
+                const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const float h = fmaxf(acc[a][b][r], 0.0f);
+                    o0[b] = fmaf(h, w3.x, o0[b]);
+                    o1[b] = fmaf(h, w3.y, o1[b]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                u0[b] = t == 0 ? o0[b] : u0[b] + o0[b];
+                u1[b] = t == 0 ? o1[b] : u1[b] + o1[b];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const float g0 = u0[b] + __shfl_xor(u0[b], 32, 64), g1 = u1[b] + __shfl_xor(u1[b], 32, 64);
+            if (lh == 0) *reinterpret_cast<float2 *>(Wf + gl * (BM * kOut) + (TM * li + b) * 2) = make_float2(g0, g1);
+        }
+    }
+    __syncthreads();
+    double reward = 0.0;
+    const int64_t i = env0 + tid;
+    if (tid < BM && i < A.m) {
+        float hs[2][2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // group g = 4 hf + q lives in wave g / 2's ring, slot g % 2
+                const float *r0 = Wc + (2 * hf) * (k2RD * k2CF), *r1 = Wc + (2 * hf + 1) * (k2RD * k2CF);
+                hs[hf][j] = ((r0[tid * 2 + j] + r0[BM * kOut + tid * 2 + j]) + r1[tid * 2 + j]) + r1[BM * kOut + tid * 2 + j];
+            }
+        const float p0 = tl[kH2P + kH2P * kOut + 0] + (hs[0][0] + hs[1][0]), p1 = tl[kH2P + kH2P * kOut + 1] + (hs[0][1] + hs[1][1]);
+        reward = act_env_tail(A, i, p0, p1, learner, goff, nullptr, xP + tid * kPreDw);
+    }
+#ifndef ABL_STAMP
+    if (A.block_reward) {
+        __syncthreads();
+        double *red64 = reinterpret_cast<double *>(Hc);      // h1 is dead by now
+        const double s = block_sum(reward, red64, 4);
+        if (tid == 0) A.block_reward[bid] = s;
+    }
+#endif
+}
+
+static int launch_act2(const ActArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = act2_lds_bytes();
+    static_assert(lds <= 80 * 1024, "k_act2: two workgroups must fit a CU's 160 KB");
+    static std::atomic<uint64_t> optin{0};
+    if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_act2), (int)lds, "hipFuncSetAttribute(k_act2)")) return rc;
+    hipLaunchKernelGGL(k_act2, dim3((unsigned)((a.m + 63) / 64)), dim3(256), lds, st, a);
+    return hip_ok(hipGetLastError(), "k_act2 launch");
+}
+
 // BM: as large as keeps >= 2 workgroups per CU's worth of tiles (256 CUs); smaller batches use smaller tiles.
 static int pick_tm(int64_t m)
 {
@@ -1363,34 +1673,39 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
     return hip_ok(hipGetLastError(), "k_actg launch");
 }
 
-// Which form runs a launch of m envs (SHEMS_ACT_FORM overrides the small-batch choice, tests and A/B runs):
-//   m >= 32 768          k_act<4, 4, 2>   128-env tiles, free-running waves (SHEMS_ACT_FORM4=0: shared stream)
-//   16 384 <= m < 32 768 k_act<2, 4, 2>   64-env tiles
-//   4 096 < m < 16 384   k_actg<1, 8, 1>  32-env tiles, 8 waves = 8 column groups
-//   m <= 4 096           k_actg<1, 4, 2>  32-env tiles, two workgroups (4 groups each) per tile
+// Which form runs a launch of m envs (the knobs exist for the all-forms test and for A/B runs):
+//   m > 8 192            k_act2           64-env tiles, two workgroups resident per CU            (SHEMS_ACT_FORM4 = 1 / 0: k_act, below)
+//   4 096 < m <= 8 192   k_actg<1, 8, 1>  32-env tiles, 8 waves = 8 column groups                 (SHEMS_ACT_FORM = 0 / 2 / 3: k_act<1, 4, .>)
+//   m <= 4 096           k_actg<1, 4, 2>  32-env tiles, two workgroups (4 groups each) per tile   (SHEMS_ACT_FORM = 8 / 9: force one of the two)
+// k_act (SHEMS_ACT_FORM4 = 1: free-running waves, 0: shared W2 stream): 128-env tiles from 32 768 envs, 64-env tiles from 16 384, 32 below.
+static int act_form() { static const int f = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : -1; }(); return f; }
+static int act_form4() { static const int f = []() { const char *e = getenv("SHEMS_ACT_FORM4"); return e ? atoi(e) : 2; }(); return f; }
+// envs per workgroup tile (= per entry of block_reward) of the form that runs m envs
+static int act_tile_envs(int64_t m)
+{
+    if (act_form4() == 2 && ((act_form() < 0 && m > 8192) || act_form() == 12)) return 64;
+    return 32 * pick_tm(m);
+}
+
 static int dispatch_act(const ActArgs &a, hipStream_t st)
 {
     static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
-    // small tiles: -1 = column-group forms (default); 0 = shared W2 stream (as TM = 4's old form), 2 / 3 = k_act's free-running waves with a
-    // private ring of 2 / 3 chunks; 8 = always the 8-wave group form, 9 = always the split form
-    static const int form = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : -1; }();
-    // 128-env tiles: 0 = shared W2 stream, 1 = free-running waves (ring of 2 chunks, layer 1 resident one half at a time)
-    static const int form4 = []() { const char *e = getenv("SHEMS_ACT_FORM4"); return e ? atoi(e) : 1; }();
-    switch (pick_tm(a.m)) {
-    case 4: return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
-    case 2: return form == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
-    default:
-        if (form == 0) return launch_act<1, 4>(a, st);
-        if (form == 2) return launch_act<1, 4, 2>(a, st);
-        if (form == 3) return launch_act<1, 4, 3>(a, st);
+    const int form = act_form(), form4 = act_form4();
 #ifdef ABL_STAMP
-        const bool want_sum = false;                          // stamp builds: block_reward is the stamp buffer
+    const bool want_sum = false;                              // stamp builds: block_reward is the stamp buffer
 #else
-        const bool want_sum = a.block_reward != nullptr;      // per-tile reward sums: the form whose one workgroup finishes the whole tile
+    const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
-        if (form == 8 || (form != 9 && (a.m > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
-        return launch_actg<1, 4, 2, 3>(a, st);
-    }
+    if (form4 == 2 && form < 0 && a.m > 8192) return launch_act2(a, st);
+    if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
+    const int tm = pick_tm(a.m);
+    if (tm == 4) return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
+    if (tm == 2) return form == 0 || form4 == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
+    if (form == 0) return launch_act<1, 4>(a, st);
+    if (form == 2) return launch_act<1, 4, 2>(a, st);
+    if (form == 3) return launch_act<1, 4, 3>(a, st);
+    if (form == 8 || (form != 9 && (a.m > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
+    return launch_actg<1, 4, 2, 3>(a, st);
 }
 
 }  // namespace shems
@@ -1402,7 +1717,7 @@ extern "C" {
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks)
 {
     if (n_envs <= 0 || !out_blocks) return set_error(SHEMS_ERR_ARG, "shems_act_step_grid: bad arguments");
-    const int bm = 32 * pick_tm(n_envs);
+    const int bm = act_tile_envs(n_envs);
     *out_blocks = (n_envs + bm - 1) / bm;
     return SHEMS_OK;
 }

@@ -282,9 +282,13 @@ def test_other_batch_sizes_match_oracle(B):
     assert _rel(ga, ga_ref) < 2e-4
     _assert_blocks(ga, L.actor_grad(s, dtype=np.float64)[0], 9, 2, f"actor gradient B={B}")
     assert abs(losses[1] - la_ref) < 1e-4 * max(1.0, abs(la_ref))
+    # one update pass holds at most 128 columns: the C ABI refuses more (Agent.replay splits wider minibatches into sub-batches,
+    # tests/test_grid_points.py)
+    import ctypes as C
+    d = ag._ddpg_args(dict(ga=ag.grad_actor, gc=ag.grad_critic, ws=ag.ws, losses=ag.losses, batch=129))
+    rs = ring.struct()
     with pytest.raises(S.ShemsError):
-        ag.batch = 129
-        ag.replay(ring, tick=5)
+        S._capi.check(ag.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), 1, 5, 0, 0, ag._stream()))
 
 
 def test_merged_actor_side_launch_is_bit_identical_to_the_two_launches():

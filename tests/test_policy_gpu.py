@@ -210,16 +210,19 @@ print("FORMS", *out)
 
 def test_every_form_of_the_act_kernel_writes_the_same_bytes():
     """k_act exists in several forms (shared W2 stream / free-running waves with private rings, ring depth 2 or 3, half-resident layer 1
-    for 128-env tiles; for small batches the column-group kernel k_actg with 8 waves per env tile, or with TWO workgroups per env tile
-    whose second arriver finishes the tile), chosen by batch size; SHEMS_ACT_FORM / SHEMS_ACT_FORM4 force the others.  All of them follow
+    for 128-env tiles; the two-workgroups-per-CU kernel k_act2 on 64-env tiles; for small batches the column-group kernel k_actg with 8
+    waves per env tile, or with TWO workgroups per env tile whose second arriver finishes the tile), chosen by batch size;
+    SHEMS_ACT_FORM / SHEMS_ACT_FORM4 force the others.  All of them follow
     the canonical column order (csrc/shems_policy.hip, act_col), so three fused steps (actions, next states, ring contents) must agree
     bit for bit -- whichever half of a split tile arrives second.  Run in child processes, the form is read once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _FORM_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     got = {}
-    forms = {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "ring2": {"SHEMS_ACT_FORM": "2"},
-             "ring3": {"SHEMS_ACT_FORM": "3"}, "group8": {"SHEMS_ACT_FORM": "8"}, "split": {"SHEMS_ACT_FORM": "9"}}
+    # default: k_act2 (two workgroups per CU) above 8 192 envs, the column-group forms below
+    forms = {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "free": {"SHEMS_ACT_FORM": "2", "SHEMS_ACT_FORM4": "1"},
+             "ring3": {"SHEMS_ACT_FORM": "3", "SHEMS_ACT_FORM4": "1"}, "group8": {"SHEMS_ACT_FORM": "8"}, "split": {"SHEMS_ACT_FORM": "9"},
+             "two_per_cu_everywhere": {"SHEMS_ACT_FORM": "12"}}
     for name, env in forms.items():
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
