@@ -720,9 +720,11 @@ class TrainWorkload:
 
         The train loop alternates k_act with the launches of replay(), and the clock the chip holds in that mix is not the clock of
         k_act launched back to back: one rocprofv3 trace of `bench.py` shows 133.3 us per k_act inside the loop and 139.6 us for the
-        same kernel in a back-to-back pass.  So the pass times groups of 8 whole vector steps [act, replay x updates] and, separately,
-        groups of 8 x replay() alone; the difference per step is the act launch together with the gap in front of it.  A pair of events
-        around every single launch would add the command processor's hand-off (3-5 us) to each reading (timing.py).
+        same kernel in a back-to-back pass.  So the pass times groups of 8 whole vector steps -- the timed region's own step(), episode
+        boundaries included -- and, separately, groups of 8 x replay() alone; the difference per step is the act launch together with the
+        gap in front of it.  A pair of events around every single launch would add the command processor's hand-off (3-5 us) to each
+        reading (timing.py).  (Round 3: the pass used to call its own [act, replay] pair with small tick numbers; groups of that pair read
+        171 us where groups of the real step() read 167.5 us = the main loop's 167.2 us, tools/pass_probe.py.)
 
         Data parallel (world > 1): EVERY rank runs this pass, with the gradient exchange in place (the same number of collectives on
         every rank: the group counts below do not depend on the rank), and it additionally times (i) replay() with its two all-reduces
@@ -732,19 +734,14 @@ class TrainWorkload:
         torch = self.torch
         from .timing import time_launches
         reps = min(reps, 200)
-        def reset(g, i):                                     # 64 launches < one episode.  The device call of the train loop itself: enqueued,
-            if g % 8 == 0:                                   # no host synchronisation (ShemsBatch.reset_ is the host API and waits -- the GPU then
-                v = self.env.view()                          # idles, and the small-batch kernels of the next group read 2-3 us long)
-                _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, 100000 + i, self.env._stream()))
         snap = self.agent.snapshot()
+        t_saved, ep_saved, pushed_saved = self.t, self.episode, self.ring.pushed
         sync = self.agent.sync
         world = sync.world
         self.agent.fused = world == 1                   # the launch structure the benchmarked world size runs
 
-        def vector_step(i):
-            self._act(i)
-            for _ in range(self.updates):
-                self.agent.replay(self.ring)
+        def vector_step(i):                              # the timed region's own step (episode boundaries and their device reset included)
+            self.step()
 
         def updates_only(i):
             for _ in range(self.updates):
@@ -752,10 +749,9 @@ class TrainWorkload:
 
         self.dp = None
         try:
-            reset(0, 0)
             for i in range(16):                          # settle into the loop's regime before the first timed group
                 vector_step(i)
-            step_avg, step_med, n = time_launches(torch, vector_step, reps, before_group=reset)
+            step_avg, step_med, n = time_launches(torch, vector_step, reps)
             if self.updates:
                 upd_avg, upd_med, _ = time_launches(torch, updates_only, reps)
             else:
@@ -781,6 +777,7 @@ class TrainWorkload:
         finally:
             self.agent.sync = sync
             self.agent.restore(snap)
+            self.t, self.episode, self.ring.pushed = t_saved, ep_saved, pushed_saved
         self.update_us = upd_avg / self.updates if self.updates else None
         self.step_us_in_pass = step_avg
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
