@@ -1681,9 +1681,11 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
 static int act_form() { static const int f = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : -1; }(); return f; }
 static int act_form4() { static const int f = []() { const char *e = getenv("SHEMS_ACT_FORM4"); return e ? atoi(e) : 2; }(); return f; }
 // envs per workgroup tile (= per entry of block_reward) of the form that runs m envs
-static int act_tile_envs(int64_t m)
+// (learner groups keep k_act's 128-env tiles: with 32 weight sets in flight two co-resident workgroups of different learners cost more
+// in L2 than they win -- 151.9 against 145.7 us at 32 x 2 048 envs)
+static int act_tile_envs(int64_t m, bool grouped = false)
 {
-    if (act_form4() == 2 && ((act_form() < 0 && m > 8192) || act_form() == 12)) return 64;
+    if (act_form4() == 2 && ((act_form() < 0 && m > 8192 && !grouped) || act_form() == 12)) return 64;
     return 32 * pick_tm(m);
 }
 
@@ -1696,7 +1698,7 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
 #else
     const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
-    if (form4 == 2 && form < 0 && a.m > 8192) return launch_act2(a, st);
+    if (form4 == 2 && form < 0 && a.m > 8192 && a.gcount <= 1) return launch_act2(a, st);
     if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
     const int tm = pick_tm(a.m);
     if (tm == 4) return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);

@@ -48,11 +48,11 @@ def main():
         for (k, c), v in rows:
             if k.startswith("shems::") or "shems::" in k:
                 w.writerow([k, c, len(v), sum(v) / len(v), min(v), max(v)])
-    act = {c: v for (k, c), v in rows if "k_act<4" in k}
+    act = {c: v for (k, c), v in rows if "k_act2" in k or "k_act<4" in k}
     # only the train-loop launches at 65 536 envs (populate / smoke launches of other sizes are other template instances)
     fetch, write = act["FETCH_SIZE"], act["WRITE_SIZE"]
     fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
-    rec = {"envs_per_gpu": 65536, "round": tag, "kernel": "shems::k_act<4, 4, 2> (128-env tiles, free-running form)", "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+    rec = {"envs_per_gpu": 65536, "round": tag, "kernel": "shems::k_act2 (64-env tiles, two workgroups per CU)", "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
            "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
            "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports 1/2 of a wide (16 B/lane) "
                          "coalesced read stream -> doubled; WRITE_SIZE exact. The 4-byte-per-lane obs reads of this kernel are an uncalibrated "
