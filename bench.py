@@ -138,7 +138,7 @@ class PolicyWorkload(EnvWorkload):
         reset = lambda g, i: self._reset_dev(1000 + i) if g % 8 == 0 else None
         avg, med, reps = T.time_launches(self.torch, self._launch, min(reps, 200), before_group=reset)
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n       # 256 500 FLOP per env-step
-        return dict(kernel="shems::k_act<TM>", avg_us=avg, median_us=med, launches=reps,
+        return dict(kernel="shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)", avg_us=avg, median_us=med, launches=reps,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
 
 

@@ -741,7 +741,11 @@ class TrainWorkload:
         self.agent.fused = world == 1                   # the launch structure the benchmarked world size runs
 
         def vector_step(i):                              # the timed region's own step (episode boundaries and their device reset included)
-            self.step()
+            if not self.overlap:
+                return self.step()
+            self._act(i)                                 # pipelined mode keeps its second stream out of this pass: act + replay in order
+            for _ in range(self.updates):
+                self.agent.replay(self.ring)
 
         def updates_only(i):
             for _ in range(self.updates):
@@ -781,7 +785,7 @@ class TrainWorkload:
         self.update_us = upd_avg / self.updates if self.updates else None
         self.step_us_in_pass = step_avg
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
-        return dict(kernel="shems::k_act<TM>", avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
+        return dict(kernel="shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)", avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
                     method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
                            + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))
