@@ -6,7 +6,17 @@
 //     r, s' = step!(env, s, scaled); remember(s, a, r, s', finished(env, s'))
 // which there costs one H2D copy, ~8 tiny kernels at batch 1, one D2H sync and a CSV parse per step.
 //
-// Decomposition (gfx950, wave64, 4 waves per workgroup, one workgroup per CU):
+// Three kernels share the arithmetic and one CANONICAL COLUMN ORDER (act_col below), so they write the same bytes, and the batch size
+// picks one (dispatch_act):
+//   k_act2  > 8 192 envs: 64-env tiles, < 80 KB of LDS and <= 256 registers, so TWO workgroups are resident per CU and one's
+//           latency-bound phases (stage 0, layer 1, layer 3, env tail) run under the other's MFMAs -- the default for large batches;
+//   k_actg  <= 8 192 envs: 32-env tiles, one wave per 64-column group; 8 waves per tile, or two workgroups per tile (<= 4 096 envs)
+//           joined by one 8-byte exchange per env;
+//   k_act   the round-1/2 kernel described next: learner groups, and the forms the all-forms test and A/B runs select by knob.
+// (In the description below "tile (a, b) holds the columns n = 128w + 4i + a" is round 2's layout; round 3 interleaves within
+// 64-column groups, see act_col.)
+//
+// k_act -- decomposition (gfx950, wave64, 4 waves per workgroup, one workgroup per CU):
 //   * a workgroup owns BM = 32*TM envs.  Everything is kept FEATURE-major ("[k][m]", env index
 //     contiguous) so that layer outputs come out of the MFMA in exactly the layout the next layer
 //     consumes: D'[n][m] = sum_k W[k][n] * H[k][m] with the weights as the MFMA A operand
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 // (64 hidden-2 columns = two MFMA tiles, see act_col): a wave owns exactly one group, streams only that group's 256-byte row
 // segments of W2 through a private ring (free-running: it waits for nobody but itself), and
 //   NS = 1, NW = 8: one workgroup of 8 waves per env tile -- two waves per SIMD, so one wave's LDS-DMA issue slots, operand waits
-//                   and epilogue run under the other's MFMAs (4 096 < envs < 16 384);
+//                   and epilogue run under the other's MFMAs (4 096 < envs <= 8 192; above that k_act2's 64-env tiles take over);
 //   NS = 2, NW = 4: TWO workgroups per env tile, each with four of the eight groups (envs <= 4 096: every CU gets work down to
 //                   128 tiles; a 1-env tracking pass runs on two CUs).  Each half leaves its four group sums [4][BM][2] in a scratch
 //                   slab and takes a ticket (agent-scope acq_rel atomic); the half that arrives second reads the other's sums and
