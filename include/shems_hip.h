@@ -112,6 +112,15 @@ int shems_rule_action(shems_env *env, float *out_b_ev);
 /* finished(env, s') (LU1:487-502): always false; done = [n] bytes. */
 int shems_finished(shems_env *env, uint8_t *done);
 
+/* inference(env; track != 0) (memory_plotting_saving.jl:62-89): the whole tracking pass -- `nsteps` hours from the envs' current
+ * state (call shems_reset(env, 1, NULL, NULL) first, as episode!(...; rng_ep = -1) does) -- in ONE launch, host arrays in and out:
+ * track_mode > 0: the deterministic actor (`actor` = the 129002 parameters in Flux.params order, s_min / s_max [9]); track_mode < 0:
+ * the rule-based controller (actor / s_min / s_max may be NULL).  results [nsteps][23] Float64 receives the rows of env 0
+ * (shems_LU1.jl:476-478), returns [n_envs] the summed rewards (DDPG.jl:223); either may be NULL.  SHEMS_ERR_INDEX if the pass
+ * runs off the table (Julia: BoundsError).  The device-pointer form, with one actor per env, is shems_track_dev. */
+int shems_track(shems_env *env, const float *actor, const float *s_min, const float *s_max, int track_mode, int32_t nsteps,
+                double *results, double *returns);
+
 /* env.state / env.idx / env.step accessors (LU1:169-177).  Any pointer may be NULL. */
 int shems_get_state(shems_env *env, float *obs, int32_t *idx, int32_t *step);
 int shems_set_state(shems_env *env, const float *obs, const int32_t *idx, const int32_t *step);

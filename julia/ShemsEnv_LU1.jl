@@ -26,7 +26,7 @@ using Distributions: Uniform
 using Random
 using CSV, DataFrames
 
-export Shems, reset!, step!, action, finished, state
+export Shems, reset!, step!, action, finished, state, track_pass
 
 const LIB = get(ENV, "SHEMS_HIP_LIB", joinpath(@__DIR__, "..", "master-thesis-deep-reinforcement-learning-ddpg-in-home-energy-management_amd", "libshems_hip.so"))
 
@@ -155,6 +155,25 @@ function action(env::Shems, track::Real=-1)      # LU1:318-340: rule-based contr
     out = zeros(Float32, 2)
     check(ccall((:shems_rule_action, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}), env.handle, out))
     return out
+end
+
+# inference(env; track != 0) (memory_plotting_saving.jl:62-89) without a Julia-side loop: the whole pass over the data set -- reset!(rng = -1),
+# then EP_LENGTH hours of { a = actor(normalize(s)) or action(env, track); step!(env, s, a; track) } -- is ONE call.  `actor_params` = the
+# actor's parameters in Flux.params order, each weight matrix flattened column-major (vcat(vec.(Flux.params(actor))...) on the CPU copy of
+# the Chain); for track < 0 (rule-based) pass nothing.  Returns (reward_eps::Float64, results::Matrix{Float64} nsteps x 23), what
+# episode!(...; track) returns to inference, ready for write_to_results_file.
+function track_pass(env::Shems, nsteps::Integer; track=1, actor_params::Vector{Float32}=Float32[], s_min::Vector{Float32}=Float32[],
+                    s_max::Vector{Float32}=Float32[])
+    reset!(env; rng=-1)
+    res = Matrix{Float64}(undef, 23, nsteps)                  # column-major 23 x nsteps == C [nsteps][23]
+    ret = Float64[0.0]
+    mode = track > 0 ? 1 : -1
+    check(ccall((:shems_track, LIB), Cint,
+                (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint, Int32, Ptr{Float64}, Ptr{Float64}),
+                env.handle, track > 0 ? actor_params : C_NULL, track > 0 ? s_min : C_NULL, track > 0 ? s_max : C_NULL, mode, nsteps, res, ret))
+    pull!(env)
+    env.reward = ret[1]
+    return ret[1], permutedims(res)
 end
 
 finished(env::Shems, s′) = false                 # LU1:487-502

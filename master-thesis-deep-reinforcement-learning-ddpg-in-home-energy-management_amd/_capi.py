@@ -80,6 +80,7 @@ def _declare(L):
         "shems_scale_action_dev": ([vp, i64, vp, vp], C.c_int),
         "shems_rollout_dev": ([PV, C.c_int, i32, u64, vp, C.POINTER(Replay), i64, i64, vp], C.c_int),
         "shems_track_dev": ([PV, vp, i64, C.c_int, i32, vp, i64, vp, vp], C.c_int),
+        "shems_track": ([vp, vp, vp, vp, C.c_int, i32, vp, vp], C.c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly

@@ -47,6 +47,9 @@ struct shems_env {
     float *d_out2 = nullptr;       // [n][2]
     double *d_rew = nullptr;       // [n]
     double *d_res = nullptr;       // [n][23] (lazily allocated)
+    float *d_track_par = nullptr;  // shems_track: actor [129002] | pad | s_min [9] | pad | s_max [9] (lazily allocated)
+    double *d_track_res = nullptr; // shems_track: [nsteps][23] of env 0, + [n] returns behind it (lazily allocated, grown on demand)
+    int64_t track_res_steps = 0;
     int32_t *d_idx0 = nullptr;     // [n]
     float *d_soc0 = nullptr;       // [n]
     bool have_tables = false, have_cfgs = false;
@@ -134,6 +137,7 @@ int shems_destroy(shems_env *e)
     hipFree(e->v.obs); hipFree(e->v.idx); hipFree(e->v.step); hipFree((void *)e->v.cfg_of_env);
     hipFree((void *)e->v.cfgs); hipFree((void *)e->v.tables); hipFree(e->v.err);
     hipFree(e->d_act); hipFree(e->d_out2); hipFree(e->d_rew); hipFree(e->d_res); hipFree(e->d_idx0); hipFree(e->d_soc0);
+    hipFree(e->d_track_par); hipFree(e->d_track_res);
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
     return SHEMS_OK;
@@ -268,6 +272,40 @@ int shems_step(shems_env *e, const float *actions, int track_mode, double *rewar
     if (obs) HIP_TRY(hipMemcpyAsync(obs, e->v.obs, n * SHEMS_NSTATE * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (results) HIP_TRY(hipMemcpyAsync(results, e->d_res, n * SHEMS_NRESULT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     return shems_check_error(e);                // synchronises
+}
+
+// inference(env; track != 0) for the handle's envs with HOST arrays (the N = 1 drop-in: what julia/ShemsEnv_LU1.jl binds): uploads the
+// actor once, runs the whole pass as one launch (shems_track_dev), downloads env 0's results rows and every env's return.
+int shems_track(shems_env *e, const float *actor, const float *s_min, const float *s_max, int track_mode, int32_t nsteps,
+                double *results, double *returns)
+{
+    if (int rc = need_ready(e, "shems_track")) return rc;
+    if (track_mode == 0 || nsteps <= 0) return set_error(SHEMS_ERR_ARG, "shems_track: track_mode must be non-zero and nsteps positive");
+    if (track_mode > 0 && (!actor || !s_min || !s_max)) return set_error(SHEMS_ERR_ARG, "shems_track: actor / s_min / s_max required for track > 0");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->n;
+    constexpr size_t kOffMin = (SHEMS_ACTOR_PARAMS + 3) / 4 * 4, kOffMax = kOffMin + 12, kParFloats = kOffMax + 12;
+    shems_act_params p;
+    std::memset(&p, 0, sizeof p);
+    if (track_mode > 0) {
+        if (!e->d_track_par) HIP_TRY(hipMalloc((void **)&e->d_track_par, kParFloats * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(e->d_track_par, actor, SHEMS_ACTOR_PARAMS * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_track_par + kOffMin, s_min, SHEMS_NSTATE * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_track_par + kOffMax, s_max, SHEMS_NSTATE * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        p.actor = e->d_track_par; p.s_min = e->d_track_par + kOffMin; p.s_max = e->d_track_par + kOffMax;
+    }
+    if (nsteps > e->track_res_steps) {
+        if (e->d_track_res) HIP_TRY(hipFree(e->d_track_res));
+        e->d_track_res = nullptr; e->track_res_steps = 0;
+        HIP_TRY(hipMalloc((void **)&e->d_track_res, ((size_t)nsteps * SHEMS_NRESULT + n) * sizeof(double)));
+        e->track_res_steps = nsteps;
+    }
+    double *d_ret = e->d_track_res + (size_t)e->track_res_steps * SHEMS_NRESULT;
+    if (int rc = shems_track_dev(&e->v, track_mode > 0 ? &p : nullptr, 0, track_mode, nsteps, results ? e->d_track_res : nullptr, 0, d_ret, e->stream))
+        return rc;
+    if (results) HIP_TRY(hipMemcpyAsync(results, e->d_track_res, (size_t)nsteps * SHEMS_NRESULT * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (returns) HIP_TRY(hipMemcpyAsync(returns, d_ret, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    return shems_check_error(e);                // synchronises; SHEMS_ERR_INDEX if the pass ran off the table
 }
 
 static int action_common(shems_env *e, const float *targets, int rule, float *out, const char *fn)

@@ -110,6 +110,34 @@ def test_tracking_passes_of_a_job_in_one_launch():
 
 
 @pytest.mark.gpu
+def test_host_array_tracking_pass_of_the_handle_api():
+    """shems_track (what julia/ShemsEnv_LU1.jl's track_pass binds): host arrays in and out, the same launch underneath -- its rows and
+    returns must be the bytes of the device-pointer path, for the actor and for the rule-based controller."""
+    import ctypes as C
+    H = _H()
+    S = U.pkg()
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    ev = S.tables.synthetic_table("eval", 98)
+    env = S.ShemsBatch(2, 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    ag = D.Agent(seed=4)
+    p = D.init_params(4, 9, 2, 0); p[128000:129000] *= 50
+    ag.set_params(actor=p)
+    lo, hi = np.zeros(9, np.float32), np.linspace(1, 9, 9).astype(np.float32)
+    ag.set_norm(lo, hi)
+    L = S._capi.lib()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    for track, steps in ((1, 300), (-0.5, 1439)):
+        tot_dev, res_dev = H.inference(env, ag if track > 0 else None, track=track, num_steps=steps)
+        env.reset_(-1)
+        res = np.empty((steps, 23), np.float64)
+        ret = np.empty(2, np.float64)
+        S._capi.check(L.shems_track(env._h, ptr(p) if track > 0 else None, ptr(lo) if track > 0 else None, ptr(hi) if track > 0 else None,
+                                    1 if track > 0 else -1, steps, ptr(res), ptr(ret)))
+        assert (U.bits64(res) == U.bits64(res_dev)).all() and (ret == tot_dev).all()
+    env.close()
+
+
+@pytest.mark.gpu
 def test_tracking_pass_past_the_end_of_the_table_is_a_bounds_error():
     """next_state! reads row idx + 1: one hour more than the table holds is Julia's BoundsError in the reference (LU1:265-279).  The
     one-launch pass stops at that hour, raises the sticky error, and everything up to it is intact (bit-exact with the oracle)."""
