@@ -381,6 +381,41 @@ int shems_action_distance_dev(const float *d_a, const float *d_b, int64_t count,
 int shems_minmax_dev(const shems_replay *ring, int64_t ring_len, int64_t count, uint64_t seed,
                      float *d_s_min, float *d_s_max, void *stream);
 
+/* ------------------------------------------- networks wider than (250, 500) -- */
+/* The reference's grids hold one architecture larger than the tuned one: (L1, L2) = (300, 600) (input09_08_on_01-09_eval.jl:62-66,
+ * input.jl:58-66; Dense widths of DDPG.jl:30-46).  Smaller networks run on the entry points above zero-padded into the (250, 500)
+ * layout; a larger one runs through the entry points below (csrc/shems_wide.hip): the same functions, every layer one fp32-MFMA matrix
+ * product as in the reference's Flux / CUBLAS path, parameters in the flat Flux layout OF THAT SIZE
+ * (W1[in][l1] b1[l1] W2[l1][l2] b2[l2] W3[l2][out] b3[out]; shems_wide_params gives the counts), the same Philox streams (noise, minibatch
+ * slots) as the tuned path.  1 <= l1, l2 <= 4096.  Not the headline path: tolerance-class like the tuned kernels, an order of magnitude
+ * slower per update. */
+int shems_wide_params(int32_t l1, int32_t l2, int64_t *n_actor, int64_t *n_critic);
+/* floats of shems_ddpg.ws for the update entry points / of d_ws for the act entry points with m observations */
+int shems_wide_workspace_floats(int32_t l1, int32_t l2, int64_t *out);
+int shems_wide_act_workspace_floats(int32_t l1, int32_t l2, int64_t m, int64_t *out);
+/* act() (DDPG.jl:148-176) as shems_actor_forward_dev, and the fused vector step of episode! (DDPG.jl:195-234) as shems_act_step_dev
+ * (without the per-workgroup reward sums): normalize + three matrix products + one launch for tanh / noise / clamp / scale_action /
+ * step! / remember. */
+int shems_wide_actor_forward_dev(const shems_act_params *p, int32_t l1, int32_t l2, const float *d_obs, int64_t m, float *d_a, float *d_ws,
+                                 void *stream);
+int shems_wide_act_step_dev(const shems_view *v, const shems_act_params *p, int32_t l1, int32_t l2, float *d_ws, float *d_a, double *d_rewards,
+                            float *d_rewards_f32, double *d_returns_acc, const shems_replay *ring, const shems_ring_window *window,
+                            void *stream);
+/* replay() (DDPG.jl:121-145) in the split form of shems_ddpg_critic_grad_ex / _critic_apply / _actor_grad / _actor_apply_pub (the
+ * caller may all-reduce grad_critic / grad_actor in between); every buffer of shems_ddpg holds the wide network's parameter count. */
+int shems_wide_critic_grad_ex(const shems_ddpg *d, int32_t l1, int32_t l2, const shems_replay *ring, int64_t ring_len, uint64_t seed,
+                              uint32_t tick, int64_t excl_pos, int64_t excl_count, void *stream);
+int shems_wide_critic_apply(const shems_ddpg *d, int32_t l1, int32_t l2, double eta, double bp1, double bp2, double grad_scale, void *stream);
+int shems_wide_actor_grad(const shems_ddpg *d, int32_t l1, int32_t l2, void *stream);
+int shems_wide_actor_apply_pub(const shems_ddpg *d, int32_t l1, int32_t l2, double eta, double bp1, double bp2, double grad_scale,
+                               float *d_publish, void *stream);
+/* ring slots [batch] of the minibatch the last shems_wide_critic_grad_ex drew, to host memory (adapt_param_noise!, DDPG.jl:74-87);
+ * synchronises the stream */
+int shems_wide_batch_slots(const shems_ddpg *d, int32_t l1, int32_t l2, int32_t *out_slots, void *stream);
+/* inference(env; track > 0) (memory_plotting_saving.jl:62-89) as shems_track_dev, for actors of hidden sizes (l1, l2) */
+int shems_wide_track_dev(const shems_view *v, const shems_act_params *p, int32_t l1, int32_t l2, int64_t actor_stride_bytes,
+                         int32_t nsteps, double *d_results, int64_t results_env, double *d_returns, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1853,6 +1853,20 @@ static int adam_launch(const shems_ddpg *d, bool critic, const AdamScalars &s, h
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
+namespace shems {
+int adam_soft_sweep(float *p, const float *g, float *m, float *v, float *target, float *publish, int n, double eta, double bp1, double bp2,
+                    double gscale, float tau, hipStream_t st)
+{
+    if (int rc = check_adam(bp1, bp2, "adam_soft_sweep")) return rc;
+    if (!p || !g || !m || !v || !target || n < 1) return set_error(SHEMS_ERR_ARG, "adam_soft_sweep: bad buffers");
+    for (const void *q : {(const void *)p, (const void *)g, (const void *)m, (const void *)v, (const void *)target, (const void *)publish})
+        if (((uintptr_t)q & 15) != 0) return set_error(SHEMS_ERR_ARG, "adam_soft_sweep: buffers must be 16-byte aligned");
+    const AdamCtx c{p, g, m, v, target, publish, n, 0, eta, bp1, bp2, gscale, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), tau};
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 1023) / 1024, 1, 1), dim3(256), 0, st, c, (int64_t)0);
+    return hip_ok(hipGetLastError(), "k_adam_soft launch");
+}
+}  // namespace shems
+
 extern "C" {
 
 #ifdef SHEMS_STAMP

@@ -1720,6 +1720,24 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     return launch_actg<1, 4, 2, 3>(a, st);
 }
 
+// Wide networks (shems_wide.hip): the layers ran as matrix products and left the pre-activation outputs; this is the rest of the
+// fused step -- tanh, noise, clamp, scale_action, step!, remember -- one thread per env, the same act_env_tail as every form above
+// (the same draws for the same (seed, tick, env)).
+__global__ __launch_bounds__(256) void k_act_tail(ActArgs A, const float *__restrict__ pre)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < A.m) act_env_tail(A, i, pre[2 * i], pre[2 * i + 1], 0, 0, nullptr);
+}
+
+static int wide_act(const ActArgs &a, int l1, int l2, float *d_ws, hipStream_t st)
+{
+    if (!d_ws || ((uintptr_t)d_ws & 15) != 0) return set_error(SHEMS_ERR_ARG, "shems_wide_act: 16-byte aligned workspace required");
+    float *pre = d_ws + wide_act_ws_floats(l1, l2, a.m) - 2 * a.m;
+    if (int rc = wide_actor_pre(a.p.actor, a.p.s_min, a.p.s_max, l1, l2, a.obs, a.m, d_ws, pre, st)) return rc;
+    hipLaunchKernelGGL(k_act_tail, dim3((unsigned)((a.m + 255) / 256)), dim3(256), 0, st, a, pre);
+    return hip_ok(hipGetLastError(), "k_act_tail launch");
+}
+
 }  // namespace shems
 
 using namespace shems;
@@ -1776,6 +1794,38 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
         a.ring = *ring; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);
+}
+
+int shems_wide_actor_forward_dev(const shems_act_params *p, int32_t l1, int32_t l2, const float *d_obs, int64_t m, float *d_a, float *d_ws,
+                                 void *stream)
+{
+    if (int rc = check_act(p, "shems_wide_actor_forward_dev")) return rc;
+    if (!d_obs || !d_a || m <= 0) return set_error(SHEMS_ERR_ARG, "shems_wide_actor_forward_dev: bad buffers");
+    ActArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.p = *p; a.obs = d_obs; a.m = m; a.a_out = d_a;
+    return wide_act(a, l1, l2, d_ws, (hipStream_t)stream);
+}
+
+int shems_wide_act_step_dev(const shems_view *v, const shems_act_params *p, int32_t l1, int32_t l2, float *d_ws, float *d_a, double *d_rewards,
+                            float *d_rewards_f32, double *d_returns_acc, const shems_replay *ring, const shems_ring_window *window,
+                            void *stream)
+{
+    if (int rc = check_act(p, "shems_wide_act_step_dev")) return rc;
+    if (int rc = check_view(v, "shems_wide_act_step_dev")) return rc;
+    ActArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.v = *v; a.p = *p; a.obs = v->obs; a.m = v->n_envs; a.a_out = d_a;
+    a.rewards = d_rewards; a.rewards_f32 = d_rewards_f32; a.returns_acc = d_returns_acc;
+    a.do_step = 1;
+    if (ring && window && window->count > 0) {
+        if (ring->capacity <= 0 || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done)
+            return set_error(SHEMS_ERR_ARG, "shems_wide_act_step_dev: incomplete replay ring");
+        if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0 || window->offset < 0 || window->offset >= v->n_envs)
+            return set_error(SHEMS_ERR_ARG, "shems_wide_act_step_dev: ring window outside the ring or the batch");
+        a.ring = *ring; a.win = *window; a.use_ring = 1;
+    }
+    return wide_act(a, l1, l2, d_ws, (hipStream_t)stream);
 }
 
 int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,

@@ -52,6 +52,7 @@ struct TrackArgs {
     double *results;                         // [n or 1][nsteps][23] or null
     int64_t results_env;                     // -1: every env; else only this env's rows
     double *returns;                         // [n] or null
+    int l1, l2;                              // k_track<true> (any hidden sizes): the actor is 9 -> l1 -> l2 -> 2
 };
 
 template <class T>
@@ -60,8 +61,13 @@ __device__ __forceinline__ const T *tsh(const T *p, int64_t off)
     return reinterpret_cast<const T *>(reinterpret_cast<const char *>(p) + off);
 }
 
+// WIDE = false: the tuned (250, 500) actor, as described above.  WIDE = true (shems_wide_track_dev): an actor of any hidden sizes
+// (the reference grids' (300, 600) point) -- same pass, same env hour, the layers as plain loops over runtime sizes: layer 1 by
+// threads k, k + 512, ..., layer 2 + 3 by column n = tid, tid + 512, ... (W2 read row by row from L2, coalesced over the columns).
+template <bool WIDE>
 __global__ __launch_bounds__(kTThreads) void k_track(TrackArgs A)
 {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];                  // WIDE: relu(layer 1) [l1]
     __shared__ __attribute__((aligned(16))) float s_obs[12];
     __shared__ __attribute__((aligned(16))) float s_h1[kTParts * kTRows];          // 256 (rows >= 250 unused)
     __shared__ __attribute__((aligned(16))) float s_h1t[kTRows];                   // the last row block's view: 6 zeros, then h1[192..249]
@@ -84,16 +90,21 @@ __global__ __launch_bounds__(kTThreads) void k_track(TrackArgs A)
     const int n3 = min(tid, kTH2 - 1);                       // layer-3 row of this thread (threads >= 500: clamped, unused)
     float b2r = 0.0f, w30 = 0.0f, w31 = 0.0f;
     if (actor_mode) {
-#pragma unroll
-        for (int j = 0; j < kTIn; ++j) w1r[j] = P[j * kTH1 + k1];
         if (tid < kTIn) { s_lo[tid] = s_min[tid]; s_rng[tid] = (s_max[tid] - s_min[tid]) + 1e-8f; }
-        b1r = P[kTOffB1 + k1];
-        b2r = P[kTOffB2 + n3];
-        w30 = P[kTOffW3 + 2 * n3];
-        w31 = P[kTOffW3 + 2 * n3 + 1];
+        if constexpr (!WIDE) {
+#pragma unroll
+            for (int j = 0; j < kTIn; ++j) w1r[j] = P[j * kTH1 + k1];
+            b1r = P[kTOffB1 + k1];
+            b2r = P[kTOffB2 + n3];
+            w30 = P[kTOffW3 + 2 * n3];
+            w31 = P[kTOffW3 + 2 * n3 + 1];
+        }
     }
+    const int wl1 = A.l1, wl2 = A.l2;                         // WIDE: offsets of the flat Flux layout at the runtime sizes
+    const int64_t wOffB1 = (int64_t)kTIn * wl1, wOffW2 = wOffB1 + wl1, wOffB2 = wOffW2 + (int64_t)wl1 * wl2, wOffW3 = wOffB2 + wl2,
+                  wOffB3 = wOffW3 + (int64_t)wl2 * kTOut;
     const int q = tid % kTQuads, part = tid / kTQuads;       // layer 2: columns 4 q .. 4 q + 3, rows 64 part .. 64 part + 63
-    const bool l2 = tid < kTQuads * kTParts;
+    const bool l2 = !WIDE && tid < kTQuads * kTParts;
     // row segment r of this thread: W2[base + r][4 q ..], base = 0, 64, 128 and 186 for the last block -- 64 rows from 192 would run
     // past the matrix; its first 6 rows (186..191) belong to block 2 and meet zeros in s_h1t, the shifted copy of h1 the block reads.
     const int rbase = min(kTRows * min(part, kTParts - 1), kTH1 - kTRows);
@@ -142,7 +153,46 @@ __global__ __launch_bounds__(kTThreads) void k_track(TrackArgs A)
             pidx += 1;
         }
         float p0 = 0.0f, p1 = 0.0f;
-        if (actor_mode) {
+        if (WIDE && actor_mode) {
+            if constexpr (WIDE) {
+                float xr[kTIn];
+#pragma unroll
+                for (int j = 0; j < kTIn; ++j) xr[j] = (s_obs[j] - s_lo[j]) / s_rng[j];
+                for (int k = tid; k < wl1; k += kTThreads) {
+                    float z = P[wOffB1 + k];
+#pragma unroll
+                    for (int j = 0; j < kTIn; ++j) z = fmaf(xr[j], P[(int64_t)j * wl1 + k], z);
+                    s_dyn[k] = fmaxf(z, 0.0f);
+                }
+                __syncthreads();
+                float o0 = 0.0f, o1 = 0.0f;
+                for (int n = tid; n < wl2; n += kTThreads) {
+                    const float *w = P + wOffW2 + n;
+                    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+                    int k = 0;
+                    for (; k + 4 <= wl1; k += 4) {
+                        c0 = fmaf(s_dyn[k], w[(int64_t)k * wl2], c0);
+                        c1 = fmaf(s_dyn[k + 1], w[(int64_t)(k + 1) * wl2], c1);
+                        c2 = fmaf(s_dyn[k + 2], w[(int64_t)(k + 2) * wl2], c2);
+                        c3 = fmaf(s_dyn[k + 3], w[(int64_t)(k + 3) * wl2], c3);
+                    }
+                    for (; k < wl1; ++k) c0 = fmaf(s_dyn[k], w[(int64_t)k * wl2], c0);
+                    const float h2 = fmaxf(P[wOffB2 + n] + ((c0 + c1) + (c2 + c3)), 0.0f);
+                    o0 = fmaf(h2, P[wOffW3 + 2 * (int64_t)n], o0);
+                    o1 = fmaf(h2, P[wOffW3 + 2 * (int64_t)n + 1], o1);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { o0 += __shfl_down(o0, off, 64); o1 += __shfl_down(o1, off, 64); }
+                if (lane == 0) { s_red[wave][0] = o0; s_red[wave][1] = o1; }
+                __syncthreads();
+                if (tid == 0) {
+                    p0 = P[wOffB3];
+                    p1 = P[wOffB3 + 1];
+#pragma unroll
+                    for (int w = 0; w < kTThreads / 64; ++w) { p0 += s_red[w][0]; p1 += s_red[w][1]; }
+                }
+            }
+        } else if (actor_mode) {
             // layer 1: x = normalize(s) (MPS:55-57), every thread for itself from the 9 observations in LDS
             if (tid < kTH1) {
                 float z = b1r;
@@ -278,6 +328,32 @@ extern "C" int shems_track_dev(const shems_view *v, const shems_act_params *p, i
     a.results = d_results;
     a.results_env = results_env;
     a.returns = d_returns;
-    hipLaunchKernelGGL(k_track, dim3((unsigned)v->n_envs), dim3(kTThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_track<false>, dim3((unsigned)v->n_envs), dim3(kTThreads), 0, (hipStream_t)stream, a);
     return hip_ok(hipGetLastError(), "k_track launch");
+}
+
+/* shems_track_dev for an actor of any hidden sizes (9 -> l1 -> l2 -> 2 in the flat Flux layout of that size; 16-byte aligned block
+ * and stride as there). */
+extern "C" int shems_wide_track_dev(const shems_view *v, const shems_act_params *p, int32_t l1, int32_t l2, int64_t actor_stride_bytes,
+                                    int32_t nsteps, double *d_results, int64_t results_env, double *d_returns, void *stream)
+{
+    if (int rc = check_view(v, "shems_wide_track_dev")) return rc;
+    if (l1 < 1 || l2 < 1 || l1 > 4096 || l2 > 4096) return set_error(SHEMS_ERR_ARG, "shems_wide_track_dev: hidden sizes must be in 1..4096");
+    if (nsteps <= 0) return set_error(SHEMS_ERR_ARG, "shems_wide_track_dev: nsteps must be positive");
+    if (results_env >= v->n_envs) return set_error(SHEMS_ERR_ARG, "shems_wide_track_dev: results_env %lld outside the batch", (long long)results_env);
+    if (!p || !p->actor || !p->s_min || !p->s_max) return set_error(SHEMS_ERR_ARG, "shems_wide_track_dev: actor / s_min / s_max required");
+    if (((uintptr_t)p->actor & 15) != 0 || (actor_stride_bytes & 15) != 0 || actor_stride_bytes < 0)
+        return set_error(SHEMS_ERR_ARG, "shems_wide_track_dev: actor block and stride must be 16-byte aligned");
+    TrackArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.v = *v;
+    a.actor = p->actor; a.s_min = p->s_min; a.s_max = p->s_max; a.stride = actor_stride_bytes;
+    a.track_mode = SHEMS_TRACK_DRL;
+    a.nsteps = nsteps;
+    a.results = d_results;
+    a.results_env = results_env;
+    a.returns = d_returns;
+    a.l1 = l1; a.l2 = l2;
+    hipLaunchKernelGGL(k_track<true>, dim3((unsigned)v->n_envs), dim3(kTThreads), sizeof(float) * (size_t)((l1 + 3) / 4 * 4), (hipStream_t)stream, a);
+    return hip_ok(hipGetLastError(), "k_track (wide) launch");
 }

@@ -100,6 +100,22 @@ def _declare():
     for fn in ("shems_ddpg_workspace_floats", "shems_ddpg_critic_grad", "shems_ddpg_critic_apply", "shems_ddpg_actor_grad",
                "shems_ddpg_actor_apply", "shems_ddpg_sample_indices", "shems_minmax_dev"):
         getattr(L, fn).restype = C.c_int
+    i32 = C.c_int32
+    L.shems_wide_params.argtypes = [i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.shems_wide_workspace_floats.argtypes = [i32, i32, C.POINTER(i64)]
+    L.shems_wide_act_workspace_floats.argtypes = [i32, i32, i64, C.POINTER(i64)]
+    L.shems_wide_actor_forward_dev.argtypes = [C.POINTER(ActParams), i32, i32, vp, i64, vp, vp, vp]
+    L.shems_wide_act_step_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), i32, i32, vp, vp, vp, vp, vp,
+                                          C.POINTER(_capi.Replay), C.POINTER(RingWindow), vp]
+    L.shems_wide_critic_grad_ex.argtypes = [PD, i32, i32, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, vp]
+    L.shems_wide_critic_apply.argtypes = [PD, i32, i32, dbl, dbl, dbl, dbl, vp]
+    L.shems_wide_actor_grad.argtypes = [PD, i32, i32, vp]
+    L.shems_wide_actor_apply_pub.argtypes = [PD, i32, i32, dbl, dbl, dbl, dbl, vp, vp]
+    L.shems_wide_batch_slots.argtypes = [PD, i32, i32, vp, vp]
+    for fn in ("shems_wide_params", "shems_wide_workspace_floats", "shems_wide_act_workspace_floats", "shems_wide_actor_forward_dev",
+               "shems_wide_act_step_dev", "shems_wide_critic_grad_ex", "shems_wide_critic_apply", "shems_wide_actor_grad",
+               "shems_wide_actor_apply_pub", "shems_wide_batch_slots"):
+        getattr(L, fn).restype = C.c_int
     L._ddpg_declared = True
     return L
 
@@ -144,6 +160,12 @@ def _blocks(flat, in_dim, out_dim, hidden):
     return [np.asarray(flat[o[i]:o[i + 1]]).reshape(sh) for i, sh in enumerate(shapes)]
 
 
+def is_wide(hidden):
+    """Hidden sizes the (250, 500) tile maps cannot hold (the reference grids' (300, 600)): such a network keeps its own flat layout
+    and runs through the shems_wide_* entry points (csrc/shems_wide.hip), layer by layer."""
+    return int(hidden[0]) > L1 or int(hidden[1]) > L2
+
+
 def pad_net(flat, in_dim, out_dim, hidden):
     """A (in -> h1 -> h2 -> out) network, h1 <= 250, h2 <= 500, in the flat Flux layout -> the (250, 500) layout the kernels are built
     for, the extra hidden units carrying ZERO weights and biases.  The padded network computes the same function, and it stays padded
@@ -154,7 +176,8 @@ def pad_net(flat, in_dim, out_dim, hidden):
     if (h1, h2) == (L1, L2):
         return np.asarray(flat, f32).copy()
     if not (1 <= h1 <= L1 and 1 <= h2 <= L2):
-        raise NotImplementedError(f"hidden sizes {hidden}: libshems_hip.so is built for at most ({L1}, {L2})")
+        raise NotImplementedError(f"hidden sizes {hidden} do not fit the ({L1}, {L2}) layout: a wider network is not padded, it keeps its own "
+                                  "layout (is_wide / Agent(hidden=...) -> shems_wide_*)")
     W1, b1, W2, b2, W3, b3 = _blocks(np.asarray(flat, f32), in_dim, out_dim, hidden)
     P1, q1, P2, q2, P3 = (np.zeros(sh, f32) for sh in ((in_dim, L1), (L1,), (L1, L2), (L2,), (L2, out_dim)))
     P1[:, :h1], q1[:h1], P2[:h1, :h2], q2[:h2], P3[:h2] = W1, b1, W2, b2, W3
@@ -194,10 +217,11 @@ class Agent:
     """The DDPG learner state on one GPU (one replica under data parallelism)."""
 
     def __init__(self, seed=1231, device=None, sigma=NOISE_SIGMA, mu=0.0, rng_seed=None, noise_type="gn", theta=0.15,
-                 dt=1e-2, eps=0.5, tensors=None, hidden=(L1, L2)):
+                 dt=1e-2, eps=0.5, tensors=None, hidden=(L1, L2), wide=None):
         """tensors: dict of float32 device views (actor, critic, actor_t, critic_t, m_actor, v_actor, m_critic, v_critic,
         grad_actor, grad_critic, s_min, s_max, ws, losses) in memory the caller owns -- a learner group's slab -- instead
-        of buffers allocated here."""
+        of buffers allocated here.  wide: None = by size (is_wide); True = the layer-by-layer path whatever the size (tests hold the two
+        implementations against each other at (250, 500))."""
         import torch
         self.torch = torch
         self.L = _declare()
@@ -210,14 +234,27 @@ class Agent:
         # pn = ParamNoise(mu, sigma, noise_act, 1.01), input.jl:237
         self.pn_sigma, self.pn_target, self.pn_adoption, self.pn_shift = float(f32(sigma)), NOISE_ACT, 1.01, 0.0
         self.actor_perturb = None                  # actor_perturb = deepcopy(actor), DDPG.jl:39
-        self.hidden = (int(hidden[0]), int(hidden[1]))        # Dense widths; smaller than (250, 500): zero-padded (pad_net)
-        if self.hidden != (L1, L2) and noise_type == "pn":
+        self.hidden = (int(hidden[0]), int(hidden[1]))        # Dense widths; smaller than (250, 500): zero-padded (pad_net); larger: wide path
+        self.wide = is_wide(self.hidden) if wide is None else bool(wide)
+        if is_wide(self.hidden) and not self.wide:
+            raise NotImplementedError(f"hidden sizes {self.hidden} do not fit the ({L1}, {L2}) kernels")
+        if self.hidden != (L1, L2) and not self.wide and noise_type == "pn":
             raise NotImplementedError("parameter noise adds one scalar to EVERY parameter (DDPG.jl:89-96): it would un-zero the padding of a smaller network")
-        a = pad_net(init_params(self.seed, STATE, ACTION, 0, self.hidden), STATE, ACTION, self.hidden)
-        c = pad_net(init_params(self.seed, STATE + ACTION, 1, 1, self.hidden), STATE + ACTION, 1, self.hidden)
-        assert a.size == N_ACTOR and c.size == N_CRITIC
         nws = C.c_int64(0)
-        _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
+        if self.wide:
+            if tensors is not None:
+                raise NotImplementedError("learner groups run the (250, 500) kernels: no slabs of wide networks")
+            a = init_params(self.seed, STATE, ACTION, 0, self.hidden)
+            c = init_params(self.seed, STATE + ACTION, 1, 1, self.hidden)
+            _capi.check(self.L.shems_wide_workspace_floats(*self.hidden, C.byref(nws)))
+        else:
+            a = pad_net(init_params(self.seed, STATE, ACTION, 0, self.hidden), STATE, ACTION, self.hidden)
+            c = pad_net(init_params(self.seed, STATE + ACTION, 1, 1, self.hidden), STATE + ACTION, 1, self.hidden)
+            _capi.check(self.L.shems_ddpg_workspace_floats(C.byref(nws)))
+        N_ACTOR, N_CRITIC = a.size, c.size                    # (250, 500) layout: 129 002 / 129 001; a wide network: its own counts
+        self.n_actor, self.n_critic = N_ACTOR, N_CRITIC
+        assert self.wide or (N_ACTOR, N_CRITIC) == (globals()["N_ACTOR"], globals()["N_CRITIC"])
+        self._act_ws = None                                   # wide path: scratch of the layer-by-layer forward (normalised obs, hidden layers)
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
         if tensors is None:
             tensors = dict(actor=z(N_ACTOR), critic=z(N_CRITIC), actor_t=z(N_ACTOR), critic_t=z(N_CRITIC),
@@ -283,19 +320,23 @@ class Agent:
     def export_actor(self, tensor=None):
         """The actor (or `tensor`, e.g. the target) as the flat Flux-layout vector of ITS network size (what a checkpoint holds)."""
         src = self.actor if tensor is None else tensor
+        if self.wide:
+            return src.detach().cpu().numpy().copy()
         return unpad_net(src.detach().cpu().numpy(), STATE, ACTION, self.hidden)
 
     def export_critic(self, tensor=None):
         src = self.critic if tensor is None else tensor
+        if self.wide:
+            return src.detach().cpu().numpy().copy()
         return unpad_net(src.detach().cpu().numpy(), STATE + ACTION, 1, self.hidden)
 
     def set_params(self, actor=None, critic=None, sync_targets=True):
         """actor / critic: flat Flux-layout vectors, either of this learner's network size (padded here) or already in the (250, 500)
         layout."""
         t = self.torch
-        if actor is not None and np.asarray(actor).size != N_ACTOR:
+        if actor is not None and np.asarray(actor).size != self.n_actor:
             actor = pad_net(actor, STATE, ACTION, self.hidden)
-        if critic is not None and np.asarray(critic).size != N_CRITIC:
+        if critic is not None and np.asarray(critic).size != self.n_critic:
             critic = pad_net(critic, STATE + ACTION, 1, self.hidden)
         if actor is not None:
             self.actor.copy_(t.as_tensor(np.asarray(actor, f32)))
@@ -328,7 +369,7 @@ class Agent:
             self.actor_perturb = self.torch.empty_like(self.actor)
         self.pn_shift = perturb_shift(self.rng_seed, rng, self.mu, self.pn_sigma)
         _capi.check(self.L.shems_ddpg_perturb_dev(C.c_void_p(self.actor.data_ptr()), C.c_void_p(self.actor_perturb.data_ptr()),
-                                                  N_ACTOR, self.pn_shift, self._stream()))
+                                                  self.n_actor, self.pn_shift, self._stream()))
         return self.actor_perturb
 
     def adapt_param_noise_(self, ring, rng):
@@ -338,8 +379,13 @@ class Agent:
         d = self._ddpg_args()
         rs = ring.struct()
         st = self._stream()
-        obs = t.empty((self.batch, STATE), dtype=t.float32, device=self.device)
-        _capi.check(self.L.shems_ddpg_batch_obs_dev(C.byref(d), C.byref(rs), C.c_void_p(obs.data_ptr()), st))
+        if self.wide:
+            slots = np.empty(self.batch, np.int32)
+            _capi.check(self.L.shems_wide_batch_slots(C.byref(d), *self.hidden, slots.ctypes.data_as(C.c_void_p), st))
+            obs = ring.s[t.as_tensor(slots.astype(np.int64), device=self.device)].contiguous()
+        else:
+            obs = t.empty((self.batch, STATE), dtype=t.float32, device=self.device)
+            _capi.check(self.L.shems_ddpg_batch_obs_dev(C.byref(d), C.byref(rs), C.c_void_p(obs.data_ptr()), st))
         a = self.act(obs, train=False)
         self.add_perturb_(rng)
         a_p = self.act(obs, train=False, actor=self.actor_perturb)
@@ -374,9 +420,22 @@ class Agent:
         if actor is None:
             train, actor = self._explore(train, tick)
         p = self._act_params(train, tick, actor)
+        if self.wide:
+            _capi.check(self.L.shems_wide_actor_forward_dev(C.byref(p), *self.hidden, C.c_void_p(ptr), m, C.c_void_p(out.data_ptr()),
+                                                            C.c_void_p(self._wide_act_ws(m).data_ptr()), self._stream()))
+            return out
         _capi.check(self.L.shems_actor_forward_dev(C.byref(p), C.c_void_p(ptr), m,
                                                    C.c_void_p(out.data_ptr()), self._stream()))
         return out
+
+    def _wide_act_ws(self, m):
+        """Scratch of the wide path's forward for m observations (normalised observations, both hidden layers, pre-activation outputs):
+        m x (9 + l1 + l2 + 2) floats in HBM, kept between calls."""
+        need = C.c_int64(0)
+        _capi.check(self.L.shems_wide_act_workspace_floats(*self.hidden, int(m), C.byref(need)))
+        if self._act_ws is None or self._act_ws.numel() < need.value:
+            self._act_ws = self.torch.empty(need.value, dtype=self.torch.float32, device=self.device)
+        return self._act_ws
 
     def act_step(self, env, train=True, tick=None, a_out=None, rewards=None, rewards_f32=None, block_reward=None,
                  returns_acc=None, ring=None, window=None, noise_acc=None):
@@ -390,6 +449,14 @@ class Agent:
         p = self._act_params(train, tick, actor, noise_acc=noise_acc)
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         rs = ring.struct() if ring is not None else None
+        if self.wide:
+            if block_reward is not None:
+                raise NotImplementedError("per-workgroup reward sums are a by-product of the fused (250, 500) kernel")
+            _capi.check(self.L.shems_wide_act_step_dev(C.byref(v), C.byref(p), *self.hidden, C.c_void_p(self._wide_act_ws(env.n).data_ptr()),
+                                                       ptr(a_out), ptr(rewards), ptr(rewards_f32), ptr(returns_acc),
+                                                       C.byref(rs) if rs is not None else None,
+                                                       C.byref(window) if window is not None else None, self._stream()))
+            return
         _capi.check(self.L.shems_act_step_dev(C.byref(v), C.byref(p), ptr(a_out), ptr(rewards), ptr(rewards_f32),
                                               ptr(block_reward), ptr(returns_acc), C.byref(rs) if rs is not None else None,
                                               C.byref(window) if window is not None else None, self._stream()))
@@ -401,7 +468,7 @@ class Agent:
         """sub: a sub-batch record (its own workspace, gradient buffers, losses, size) of a minibatch wider than one pass."""
         ga, gc, ws, ls, b = ((self.grad_actor, self.grad_critic, self.ws, self.losses, self.batch) if sub is None else
                              (sub["ga"], sub["gc"], sub["ws"], sub["losses"], sub["batch"]))
-        defer = self.sync.world > 1 and self.dp_overlap and sub is None and self.batch <= self.MAX_PASS_BATCH
+        defer = self.sync.world > 1 and self.dp_overlap and sub is None and self.batch <= self.MAX_PASS_BATCH and not self.wide
         return DdpgArgs(self.actor.data_ptr(), self.critic.data_ptr(), self.actor_t.data_ptr(), self.critic_t.data_ptr(),
                         self.m_actor.data_ptr(), self.v_actor.data_ptr(), self.m_critic.data_ptr(), self.v_critic.data_ptr(),
                         ga.data_ptr(), gc.data_ptr(), self.s_min.data_ptr(), self.s_max.data_ptr(),
@@ -417,8 +484,31 @@ class Agent:
         if cur is None or [x["batch"] for x in cur] != sizes:
             t = self.torch
             z = lambda n: t.zeros(n, dtype=t.float32, device=self.device)
-            self._subs = [dict(batch=b, ws=z(self.ws.numel()), gc=z(N_CRITIC), ga=z(N_ACTOR), losses=z(2)) for b in sizes]
+            self._subs = [dict(batch=b, ws=z(self.ws.numel()), gc=z(self.n_critic), ga=z(self.n_actor), losses=z(2)) for b in sizes]
         return self._subs
+
+    # the four split-form calls of replay(), on the tuned kernels or -- a network wider than (250, 500) -- layer by layer (shems_wide_*)
+    def _critic_grad_ex(self, d, rs, ring_len, tick, ex_pos, ex_cnt, st):
+        if self.wide:
+            return _capi.check(self.L.shems_wide_critic_grad_ex(C.byref(d), *self.hidden, C.byref(rs), ring_len, self.rng_seed,
+                                                                int(tick) & 0xFFFFFFFF, ex_pos, ex_cnt, st))
+        _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), ring_len, self.rng_seed, int(tick) & 0xFFFFFFFF, ex_pos, ex_cnt, st))
+
+    def _critic_apply(self, d, gs, st):
+        if self.wide:
+            return _capi.check(self.L.shems_wide_critic_apply(C.byref(d), *self.hidden, self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+        _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+
+    def _actor_grad(self, d, st):
+        if self.wide:
+            return _capi.check(self.L.shems_wide_actor_grad(C.byref(d), *self.hidden, st))
+        _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
+
+    def _actor_apply_pub(self, d, gs, publish, st):
+        pub = C.c_void_p(publish.data_ptr()) if publish is not None else None
+        if self.wide:
+            return _capi.check(self.L.shems_wide_actor_apply_pub(C.byref(d), *self.hidden, self.eta_act, self.bp_actor[0], self.bp_actor[1], gs, pub, st))
+        _capi.check(self.L.shems_ddpg_actor_apply_pub(C.byref(d), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs, pub, st))
 
     def _replay_wide(self, ring, tick, ex_pos, ex_cnt, publish):
         """replay() for BATCH_SIZE > 128: the loss is a mean over the minibatch, so its gradient is the size-weighted mean of the
@@ -430,26 +520,24 @@ class Agent:
         vp = lambda x: C.c_void_p(x.data_ptr())
         for i, sb in enumerate(subs):
             d = self._ddpg_args(sb)
-            _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, (int(tick) * 8 + i) & 0xFFFFFFFF,
-                                                         ex_pos, ex_cnt, st))
+            self._critic_grad_ex(d, rs, len(ring), int(tick) * 8 + i, ex_pos, ex_cnt, st)
             w = sb["batch"] / self.batch
-            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_critic), vp(sb["gc"]), N_CRITIC, 0.0 if i == 0 else 1.0, w, st))
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_critic), vp(sb["gc"]), self.n_critic, 0.0 if i == 0 else 1.0, w, st))
             _capi.check(self.L.shems_ddpg_combine_dev(vp(self.losses), vp(sb["losses"]), 1, 0.0 if i == 0 else 1.0, w, st))
         self._allreduce(self.grad_critic)
         gs = self.sync.grad_scale
         # the ADAM / soft-update sweeps work on the learner's own (combined) gradient buffers; they do not look at `batch`
         dm = self._ddpg_args(dict(ga=self.grad_actor, gc=self.grad_critic, ws=self.ws, losses=self.losses, batch=subs[0]["batch"]))
-        _capi.check(self.L.shems_ddpg_critic_apply(C.byref(dm), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+        self._critic_apply(dm, gs, st)
         self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
         for i, sb in enumerate(subs):
             d = self._ddpg_args(sb)
-            _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
+            self._actor_grad(d, st)
             w = sb["batch"] / self.batch
-            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_actor), vp(sb["ga"]), N_ACTOR, 0.0 if i == 0 else 1.0, w, st))
+            _capi.check(self.L.shems_ddpg_combine_dev(vp(self.grad_actor), vp(sb["ga"]), self.n_actor, 0.0 if i == 0 else 1.0, w, st))
             _capi.check(self.L.shems_ddpg_combine_dev(vp(self.losses[1:]), vp(sb["losses"][1:]), 1, 0.0 if i == 0 else 1.0, w, st))
         self._allreduce(self.grad_actor)
-        _capi.check(self.L.shems_ddpg_actor_apply_pub(C.byref(dm), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs,
-                                                      C.c_void_p(publish.data_ptr()) if publish is not None else None, st))
+        self._actor_apply_pub(dm, gs, publish, st)
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
@@ -474,7 +562,7 @@ class Agent:
             if self.noise_type == "pn":
                 raise NotImplementedError("parameter-noise adaptation with BATCH_SIZE > 128")
             return self._replay_wide(ring, tick, ex_pos, ex_cnt, publish)
-        if self.fused and self.sync.world == 1 and self.noise_type != "pn":
+        if self.fused and self.sync.world == 1 and self.noise_type != "pn" and not self.wide:
             # one replica, nothing to exchange and no parameter-noise adaptation between getData and the updates: the whole
             # replay() is one call (K1..K5, csrc/shems_ddpg.hip)
             _capi.check(self.L.shems_ddpg_update(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF, ex_pos, ex_cnt,
@@ -484,8 +572,7 @@ class Agent:
             self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
             self.updates += 1
             return
-        _capi.check(self.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF,
-                                                     ex_pos, ex_cnt, st))
+        self._critic_grad_ex(d, rs, len(ring), tick, ex_pos, ex_cnt, st)
         if self.noise_type == "pn":                # DDPG.jl:126-128 (the actor is still the pre-update one here)
             self.adapt_param_noise_(ring, tick)
         if d.flags & 1:
@@ -499,18 +586,19 @@ class Agent:
         else:
             self._allreduce(self.grad_critic)
         gs = self.sync.grad_scale
-        _capi.check(self.L.shems_ddpg_critic_apply(C.byref(d), self.eta_crit, self.bp_critic[0], self.bp_critic[1], gs, st))
+        self._critic_apply(d, gs, st)
         self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
-        _capi.check(self.L.shems_ddpg_actor_grad(C.byref(d), st))
+        self._actor_grad(d, st)
         self._allreduce(self.grad_actor)
-        _capi.check(self.L.shems_ddpg_actor_apply_pub(C.byref(d), self.eta_act, self.bp_actor[0], self.bp_actor[1], gs,
-                                                      C.c_void_p(publish.data_ptr()) if publish is not None else None, st))
+        self._actor_apply_pub(d, gs, publish, st)
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
     def sync_timeouts(self):
         """Workgroups of the merged K4 + K5 launch that ever gave up their (bounded) wait on this learner's workspace: 0 in every
         supported use (shems_ddpg_sync_timeouts).  Synchronises the stream."""
+        if self.wide:
+            return 0                                   # the wide path has no in-launch wait
         d = self._ddpg_args()
         out = C.c_int64(0)
         _capi.check(self.L.shems_ddpg_sync_timeouts(C.byref(d), C.byref(out), self._stream()))

@@ -32,34 +32,40 @@ def inference(env, agent=None, track=1, num_steps=None, which=0):
     if track > 0 and agent is None:
         raise ValueError("track > 0 needs an agent")
     total, res = _track(env, None if track < 0 else agent.actor, None if track < 0 else agent.s_min, None if track < 0 else agent.s_max,
-                        0, track, num_steps, which)
+                        0, track, num_steps, which, hidden=agent.hidden if track > 0 and agent.wide else None)
     return total, res[0]
 
 
-def inference_many(env, actors, s_min, s_max, num_steps=None):
+def inference_many(env, actors, s_min, s_max, num_steps=None, hidden=None):
     """The job's tracking passes in one launch (MAIN:87-105: 40 seeds x {last, best} actor, each a full pass over the data set):
     env e of the batch (len(actors) envs on the same table) runs the pass with actors[e].  actors: [P][129002] float32 (numpy or a
-    CUDA tensor); s_min / s_max: [9] (shared) or [P][9].  Returns (sum of rewards [P], results [P][steps][23] float64)."""
+    CUDA tensor); s_min / s_max: [9] (shared) or [P][9].  Returns (sum of rewards [P], results [P][steps][23] float64).
+    hidden: (L1, L2) of a network wider than (250, 500) -- the actors then hold that network's own parameter count (ddpg.is_wide)."""
     import torch
+    from .ddpg import is_wide, net_size
+    wide = hidden is not None and is_wide(hidden)
+    na = net_size(9, 2, hidden) if wide else 129002
     dev = torch.device("cuda", torch.cuda.current_device())
     A = torch.as_tensor(np.asarray(actors, np.float32) if not torch.is_tensor(actors) else actors, dtype=torch.float32, device=dev)
     P = A.shape[0]
-    if A.dim() != 2 or A.shape[1] != 129002 or env.n != P:
-        raise ValueError("actors must be [P][129002] with one env of the batch per actor")
+    if A.dim() != 2 or A.shape[1] != na or env.n != P:
+        raise ValueError(f"actors must be [P][{na}] with one env of the batch per actor")
     # one slab row per pass: actor | pad to 16 B | s_min[9] | s_max[9] | pad -- env e finds all three at the same byte stride
-    row = -(-129002 // 4) * 4 + 32
+    row = -(-na // 4) * 4 + 32
     slab = torch.zeros((P, row), dtype=torch.float32, device=dev)
-    slab[:, :129002] = A
+    slab[:, :na] = A
     o_min, o_max = row - 32, row - 16
     for off, val in ((o_min, s_min), (o_max, s_max)):
         t = torch.as_tensor(np.asarray(val, np.float32) if not torch.is_tensor(val) else val, dtype=torch.float32, device=dev)
         slab[:, off:off + 9] = t if t.dim() == 2 else t[None, :]
-    return _track(env, slab[0, :129002], slab[0, o_min:o_min + 9], slab[0, o_max:o_max + 9], row * 4, 1, num_steps, -1, keep=slab)
+    return _track(env, slab[0, :na], slab[0, o_min:o_min + 9], slab[0, o_max:o_max + 9], row * 4, 1, num_steps, -1, keep=slab,
+                  hidden=hidden if wide else None)
 
 
-def _track(env, actor, s_min, s_max, stride, track, num_steps, which, keep=None):
+def _track(env, actor, s_min, s_max, stride, track, num_steps, which, keep=None, hidden=None):
     import torch
-    from .ddpg import ActParams
+    from .ddpg import ActParams, _declare, is_wide
+    _declare()
     n = env.n
     num_steps = env.maxsteps if num_steps is None else int(num_steps)
     env.use_torch_stream()
@@ -73,8 +79,15 @@ def _track(env, actor, s_min, s_max, stride, track, num_steps, which, keep=None)
     p = None
     if track > 0:
         p = ActParams(actor.data_ptr(), s_min.data_ptr(), s_max.data_ptr(), 0.0, 0.0, 0, 0, 0, 0, 0.0, 0.0, 0.0, None, None)
-    _capi.check(L.shems_track_dev(C.byref(v), C.byref(p) if p is not None else None, int(stride), 1 if track > 0 else -1, num_steps,
-                                  C.c_void_p(res.data_ptr()), int(which), C.c_void_p(total.data_ptr()), env._stream()))
+    if track > 0 and hidden is not None:                        # a wide actor (or one forced onto the wide path): its own flat layout
+        L.shems_wide_track_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.shems_wide_track_dev.restype = C.c_int
+        _capi.check(L.shems_wide_track_dev(C.byref(v), C.byref(p), int(hidden[0]), int(hidden[1]), int(stride), num_steps,
+                                           C.c_void_p(res.data_ptr()), int(which), C.c_void_p(total.data_ptr()), env._stream()))
+    else:
+        _capi.check(L.shems_track_dev(C.byref(v), C.byref(p) if p is not None else None, int(stride), 1 if track > 0 else -1, num_steps,
+                                      C.c_void_p(res.data_ptr()), int(which), C.c_void_p(total.data_ptr()), env._stream()))
     out, tot = res.cpu().numpy(), total.cpu().numpy()           # the pass's one synchronisation
     env.check_error()
     return tot, out

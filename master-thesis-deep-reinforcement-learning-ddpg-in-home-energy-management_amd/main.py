@@ -15,7 +15,8 @@ Order of MAIN:28-110: populate_memory -> min_max_buffer -> run_episodes (best-sc
 Differences that follow from the platform, all explicit:
   * the job's Julia input file (out/input/$JOB_ID--input.jl) cannot be executed; its decoding rules are restated here for the two
     templates the thesis used last (TUNED = input09_08_on_01-09_eval.jl and input.jl), selected with SHEMS_INPUT_TEMPLATE;
-  * the kernels are built for the tuned architecture (L1, L2) = (250, 500) and BATCH_SIZE <= 128: other codes raise;
+  * the kernels are built for the tuned architecture (L1, L2) = (250, 500) and 128 minibatch columns; the grids' other points run
+    too: smaller networks zero-padded, (300, 600) layer by layer (csrc/shems_wide.hip), BATCH_SIZE 150 / 200 as sub-batches;
   * snapshots are BSON files under the reference's names, laid out as BSON.jl lowers a Chain (bson_chain.py; parity unpinned:
     the reference ships no real .bson to compare with);
   * SHEMS_NUM_ENVS (default 1 = the reference's protocol) trains that many households at once;
@@ -179,9 +180,10 @@ def config_from_env(environ=os.environ):
 
 
 def _check_supported(cfg):
-    if not (1 <= cfg.L1 <= 250 and 1 <= cfg.L2 <= 500):
-        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2}); libshems_hip.so is built for the tuned (250, 500) "
-                                  "and runs smaller networks zero-padded into it (ddpg.pad_net), not larger ones")
+    # (250, 500): the tuned kernels; smaller: zero-padded into them (ddpg.pad_net); larger -- the grids' (300, 600) --: the layer-by-layer
+    # wide path (csrc/shems_wide.hip, ddpg.is_wide)
+    if not (1 <= cfg.L1 <= 4096 and 1 <= cfg.L2 <= 4096):
+        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2})")
     if not 1 <= cfg.BATCH_SIZE <= 1024:             # above 128: replay() runs the gradient passes per sub-batch (ddpg.Agent._replay_wide)
         raise NotImplementedError(f"JOB_ID {cfg.job_id} selects BATCH_SIZE = {cfg.BATCH_SIZE}")
 
@@ -274,7 +276,8 @@ def main(environ=os.environ, cwd=".", log=print):
         if passes:
             env_many = mk(len(passes), EP_LENGTH[cfg.season, cfg.run], tabs[cfg.run])
             hid = (cfg.L1, cfg.L2)                                       # checkpoints hold the network's own size: pad into the kernels' layout
-            _, results = harness.inference_many(env_many, np.stack([D.pad_net(p[3], 9, 2, hid) for p in passes]), agent.s_min, agent.s_max)
+            lay = (lambda a: np.asarray(a, np.float32)) if D.is_wide(hid) else (lambda a: D.pad_net(a, 9, 2, hid))      # (a wide one keeps its own)
+            _, results = harness.inference_many(env_many, np.stack([lay(p[3]) for p in passes]), agent.s_min, agent.s_max, hidden=hid)
             env_many.close()
             for (test_rng_run, best, idx, _), res in zip(passes, results):
                 path = harness.results_file_name(cfg.job_id, cfg.run, EP_LENGTH["train"], cfg.NUM_EP, cfg.L1, cfg.L2, cfg.case, test_rng_run,

@@ -92,10 +92,13 @@ def test_job_ids_of_smaller_networks_are_accepted():
     cfg = M.config_from_env({"JOB_ID": "11709803", "TASK_ID": "1", "GPU_ID": "0"})
     assert (cfg.L1, cfg.L2) == (200, 400)
     M._check_supported(cfg)
-    cfg = M.config_from_env({"JOB_ID": "11709800", "TASK_ID": "1", "GPU_ID": "0"})      # code 0 -> (300, 600): larger than the kernels
-    assert (cfg.L1, cfg.L2) == (300, 600)
-    with pytest.raises(NotImplementedError):
-        M._check_supported(cfg)
+    cfg = M.config_from_env({"JOB_ID": "11709800", "TASK_ID": "1", "GPU_ID": "0"})      # code 0 -> (300, 600): larger than the tuned kernels,
+    assert (cfg.L1, cfg.L2) == (300, 600)                                                # runs layer by layer (tests/test_wide_gpu.py)
+    M._check_supported(cfg)
+    D = _D()
+    assert D.is_wide((300, 600)) and not D.is_wide((250, 500)) and not D.is_wide((200, 400)) and D.is_wide((250, 501))
+    for code in range(81):                                                               # every code of the tuned template's grid is accepted
+        M._check_supported(M.config_from_env({"JOB_ID": "117098%02d" % code, "TASK_ID": "1", "GPU_ID": "0"}))
 
 
 @pytest.mark.gpu

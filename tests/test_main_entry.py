@@ -24,10 +24,9 @@ def test_job_id_decoding_and_case_string():
     c2 = M.config_from_env({"JOB_ID": "1170143", "TASK_ID": "12", "GPU_ID": "0"})      # 43 = 1121 (base 3)
     assert (c2.charger_id, c2.BATCH_SIZE, c2.noise_act, (c2.L1, c2.L2), (c2.eta_act, c2.eta_crit), c2.rng_run) == \
            (1, 100, 0.2, (250, 500), (5e-4, 5e-3), 12312)
-    c3 = M.config_from_env({"JOB_ID": "1170100", "TASK_ID": "1", "GPU_ID": "0"})       # 00 -> (300, 600): not what the kernels are built for
-    assert (c3.L1, c3.L2, c3.eta_act) == (300, 600, 1e-5)
-    with pytest.raises(NotImplementedError):
-        M._check_supported(c3)
+    c3 = M.config_from_env({"JOB_ID": "1170100", "TASK_ID": "1", "GPU_ID": "0"})       # 00 -> (300, 600): wider than the tuned kernels, runs
+    assert (c3.L1, c3.L2, c3.eta_act) == (300, 600, 1e-5)                               # layer by layer (csrc/shems_wide.hip)
+    M._check_supported(c3)
     with pytest.raises(KeyError):
         M.config_from_env({"JOB_ID": "1179808", "GPU_ID": "0"})
     # Julia's printing of the Float32 / Float64 values that go into file names
