@@ -29,7 +29,8 @@ typedef float wf32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WBP = 128;                 // minibatch rows one update pass holds (as shems_ddpg.hip's BP)
 constexpr int WSIN = 9, WAIN = 2, WCIN = 11;
-constexpr int GT = 64, GK = 16, GLD = GT + 4;
+constexpr int GT = 64, GK = 16, GKB = 4, GLD = GT + 4, GR = GT * GK / 256;   // tile, K per stage (2^GKB), LDS row stride, elements per thread and operand
+static_assert((1 << GKB) == GK, "GK");
 
 struct GemmArgs {
     const float *A, *B;
@@ -49,18 +50,21 @@ __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
     const int wi = wave >> 1, wj = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.x * GT, n0 = (int64_t)blockIdx.y * GT;
     const bool a_kfast = G.sak == 1, b_jfast = G.sbj == 1;
-    // element e = tid + 256 r of a 64 x 16 operand tile: (row, k) with the memory-contiguous index fastest across threads
-    int ai[4], ak[4], bj[4], bk[4];
+    // element e = tid + 256 r of a 64 x GK operand tile: (row, k) with the memory-contiguous index fastest across threads
+    int ai[GR], ak[GR], bj[GR], bk[GR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < GR; ++r) {
         const int e = tid + 256 * r;
-        ai[r] = a_kfast ? e >> 4 : e & 63;  ak[r] = a_kfast ? e & 15 : e >> 6;
-        bj[r] = b_jfast ? e & 63 : e >> 4;  bk[r] = b_jfast ? e >> 6 : e & 15;
+        ai[r] = a_kfast ? e >> GKB : e & 63;  ak[r] = a_kfast ? e & (GK - 1) : e >> 6;
+        bj[r] = b_jfast ? e & 63 : e >> GKB;  bk[r] = b_jfast ? e >> 6 : e & (GK - 1);
     }
-    float ra[4], rb[4];
+    // the global loads of stage s + 1 are in flight while stage s is multiplied; double-buffered LDS, one barrier per stage.  (With
+    // thousands of workgroups the latency is hidden by occupancy: a deeper register ring and unpredicated clamped loads, which pay off
+    // in the small-M kernel below, measured slower here -- 480-490 against 443 us for the vector step of 65 536 envs.)
+    float ra[GR], rb[GR];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < GR; ++r) {
             const int64_t i = m0 + ai[r], j = n0 + bj[r];
             const int ka = k0 + ak[r], kb = k0 + bk[r];
             ra[r] = (i < G.M && ka < G.K) ? G.A[i * G.sai + ka * G.sak] : 0.0f;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { As[buf][ak[r]][ai[r]] = ra[r]; Bs[buf][bk[r]][bj[r]] = rb[r]; }
+        for (int r = 0; r < GR; ++r) { As[buf][ak[r]][ai[r]] = ra[r]; Bs[buf][bk[r]][bj[r]] = rb[r]; }
     };
     wf32x16 acc;
 #pragma unroll
@@ -103,10 +107,97 @@ __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
     }
 }
 
+// The minibatch-sized products (M <= a few hundred rows): few tiles and a long K.  One wave's chain of 32x32x2 MFMAs costs 32 cycles
+// per k whatever the memory system does (K = 600: 9 us), and a 64 x 64 tile per workgroup leaves most CUs idle (N = 600: 20
+// workgroups).  So here a workgroup owns a 32 x 32 tile and its four waves split every 64-deep K stage four ways (16 k each); the
+// four partial tiles meet in LDS at the end and are added in wave order (a fixed order).  Same operands, strides and epilogue.
+constexpr int SK = 64, SKB = 6, SLD = 32 + 4, SR = 32 * SK / 256;
+__global__ __launch_bounds__(256) void k_wgemm_sk(GemmArgs G)
+{
+    __shared__ float As[2][SK][SLD], Bs[2][SK][SLD];
+    __shared__ float red[4][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 32, n0 = (int64_t)blockIdx.y * 32;
+    const bool a_kfast = G.sak == 1, b_jfast = G.sbj == 1;
+    int ai[SR], ak[SR], bj[SR], bk[SR];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const int e = tid + 256 * r;
+        ai[r] = a_kfast ? e >> SKB : e & 31;  ak[r] = a_kfast ? e & (SK - 1) : e >> 5;
+        bj[r] = b_jfast ? e & 31 : e >> SKB;  bk[r] = b_jfast ? e >> 5 : e & (SK - 1);
+    }
+    // global loads run GP stages ahead in a ring of register slots; every load is unconditional, from a clamped (always valid) address,
+    // and the zero of an out-of-range element is selected when the slot is stashed (a load under a lane predicate is sunk into a branch
+    // behind s_waitcnt vmcnt(0), which serialises the ring).  One barrier per stage: stash(s) -> barrier -> MFMAs(s); buffer s & 1 was
+    // last read in stage s - 2, which every thread left before anyone passed barrier s - 1.
+    constexpr int GP = 2;
+    float ra[GP][SR], rb[GP][SR];
+    unsigned oka[GP], okb[GP];
+    auto fetch = [&](int k0, float (&xa)[SR], float (&xb)[SR], unsigned &ma, unsigned &mb) {
+        ma = mb = 0u;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int64_t i = m0 + ai[r], j = n0 + bj[r];
+            const int ka = k0 + ak[r], kb = k0 + bk[r];
+            ma |= (i < G.M && ka < G.K) ? 1u << r : 0u;
+            mb |= (j < G.N && kb < G.K) ? 1u << r : 0u;
+            xa[r] = G.A[min(i, (int64_t)G.M - 1) * G.sai + min(ka, G.K - 1) * G.sak];
+            xb[r] = G.B[min(kb, G.K - 1) * G.sbk + min(j, (int64_t)G.N - 1) * G.sbj];
+        }
+    };
+    auto stash = [&](int buf, const float (&xa)[SR], const float (&xb)[SR], unsigned ma, unsigned mb) {
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            As[buf][ak[r]][ai[r]] = (ma >> r & 1u) ? xa[r] : 0.0f;
+            Bs[buf][bk[r]][bj[r]] = (mb >> r & 1u) ? xb[r] : 0.0f;
+        }
+    };
+    wf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nst = (G.K + SK - 1) / SK;
+#pragma unroll
+    for (int u = 0; u < GP; ++u) fetch(u * SK, ra[u], rb[u], oka[u], okb[u]);
+    for (int s0 = 0; s0 < nst; s0 += GP) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int s = s0 + u;
+            if (s < nst) {
+                const int buf = s & 1;
+                stash(buf, ra[u], rb[u], oka[u], okb[u]);
+                __syncthreads();
+                if (s + GP < nst) fetch((s + GP) * SK, ra[u], rb[u], oka[u], okb[u]);
+#pragma unroll
+                for (int kk = 0; kk < SK / 4; kk += 2)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][wave * (SK / 4) + kk + lh][li], Bs[buf][wave * (SK / 4) + kk + lh][li], acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q, r = e >> 6, l2 = e & 63;
+        const int64_t i = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l2 >> 5), j = n0 + (l2 & 31);
+        if (i < G.M && j < G.N) {
+            float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+            if (G.bias) v += G.bias[j];
+            if (G.relu) v = fmaxf(v, 0.0f);
+            if (G.gate) v = G.gate[i * G.ldg + j] > 0.0f ? v : 0.0f;
+            G.C[i * G.ldc + j] = v;
+        }
+    }
+}
+
 static int gemm(hipStream_t st, const float *A, int64_t sai, int64_t sak, const float *B, int64_t sbk, int64_t sbj, float *C, int64_t ldc,
                 int64_t M, int N, int K, const float *bias = nullptr, int relu = 0, const float *gate = nullptr, int64_t ldg = 0)
 {
     GemmArgs g{A, B, C, (int)M, N, K, sai, sak, sbk, sbj, ldc, bias, gate, ldg, relu};
+    if (M <= 512) {
+        hipLaunchKernelGGL(k_wgemm_sk, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, g);
+        return hip_ok(hipGetLastError(), "k_wgemm_sk launch");
+    }
     hipLaunchKernelGGL(k_wgemm, dim3((unsigned)((M + GT - 1) / GT), (unsigned)((N + GT - 1) / GT)), dim3(256), 0, st, g);
     return hip_ok(hipGetLastError(), "k_wgemm launch");
 }

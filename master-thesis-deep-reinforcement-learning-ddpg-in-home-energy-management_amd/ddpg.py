@@ -841,7 +841,11 @@ class TrainWorkload:
 
         self.dp = None
         try:
-            for i in range(16):                          # settle into the loop's regime before the first timed group
+            # settle into the loop's regime before the first timed group.  The pass starts after finish()'s synchronisation and host-side
+            # checks, i.e. from an idle device: tools/pass_dist.py shows groups of 8 steps reading 178, 174, 173, 171, 172, 170, 169, 168 us
+            # ... before they are back at the loop's 166 us after ~100 steps (clock / power state), which put the pass's average 3 % above its
+            # median and above rocprofv3's per-kernel average.  600 steps (0.1 s at 65 536 envs; the same count on every rank).
+            for i in range(600):
                 vector_step(i)
             step_avg, step_med, n = time_launches(torch, vector_step, reps)
             if self.updates:
