@@ -212,6 +212,56 @@ def test_wide_update_matches_the_oracle(wide_oracle, B):
     assert torch.equal(ag3.actor, ag2.actor) and torch.equal(ag3.critic_t, ag2.critic_t)
 
 
+def test_wide_path_on_sizes_that_divide_nothing(monkeypatch):
+    """(257, 513): one more than the tuned widths, odd, no multiple of any tile or vector width -- the matrix products' edge handling
+    (clamped loads, zero-filled stage tails, partial tiles), the column sums, the ADAM sweep's tail and the tracking kernel's loops."""
+    torch, S, D = _mods()
+    hid = (257, 513)
+    monkeypatch.setattr(DO, "L1", hid[0]); monkeypatch.setattr(DO, "L2", hid[1])
+    assert D.is_wide(hid)
+    ring, h = _ring(torch, S, D, np.random.default_rng(2))
+    pa, pc = _boosted(D, 13, hid)
+    ag = D.Agent(seed=13, hidden=hid)
+    ag.batch = 97
+    ag.set_params(actor=pa, critic=pc)
+    ag.set_norm(h["s_min"], h["s_max"])
+    obs = h["s"][:1001]
+    got = ag.act(torch.from_numpy(obs).cuda(), train=False).cpu().numpy()
+    want = DO.act(pa, obs, h["s_min"], h["s_max"], False, dtype=np.float64)
+    assert np.abs(got - want).max() < ATOL and np.abs(want).max() > 0.3
+    got1 = ag.act(torch.from_numpy(obs[:3]).cuda(), train=False).cpu().numpy()       # the small-M kernel on the same rows
+    assert np.abs(got1 - want[:3]).max() < ATOL
+    L = DO.Learner(pa, pc, h["s_min"], h["s_max"])
+    idx = ag.sample_indices(9, len(ring))
+    s, a, r, s2, done = (h[k][idx] for k in ("s", "a", "r", "s2", "done"))
+    y = L.targets(r, s2, done.astype(bool))
+    gc64, _ = L.critic_grad(s, a, y, dtype=np.float64)
+    ag.replay(ring, tick=9)
+    torch.cuda.synchronize()
+    _assert_blocks(ag.grad_critic.cpu().numpy(), gc64, 11, 1, "critic gradient at (257, 513)")
+    L.critic = ag.critic.cpu().numpy()
+    ga64, _ = L.actor_grad(s, dtype=np.float64)
+    _assert_blocks(ag.grad_actor.cpu().numpy(), ga64, 9, 2, "actor gradient at (257, 513)")
+    L3 = DO.Learner(pa, pc, h["s_min"], h["s_max"])
+    L3.replay(s, a, r, s2, done.astype(bool))
+    for name, got_t, want_v in (("critic", ag.critic, L3.critic), ("actor", ag.actor, L3.actor), ("critic_t", ag.critic_t, L3.critic_t),
+                                ("actor_t", ag.actor_t, L3.actor_t)):
+        assert np.abs(got_t.cpu().numpy() - want_v).max() < 3e-6, name
+    H = importlib.import_module(U.PKG_NAME + ".harness")
+    ev = S.tables.synthetic_table("eval", 98)
+    env = S.ShemsBatch(1, 1439, [ev], [S.make_config(98, 0, ev.shape[0])])
+    ag.set_params(actor=pa)
+    total, res = H.inference(env, ag, track=1, num_steps=50)
+    ref = oracle_c.Batch(1, 1439, ev, oracle_c.profile(98)); ref.reset(True)
+    for t in range(50):
+        act = DO.act(pa, ref.state(), h["s_min"], h["s_max"], False, dtype=np.float64)
+        tgt = res[t, [21, 2]].astype(np.float32)[None]
+        assert np.abs(oracle_c.scale_action(act) - tgt).max() < 1e-5
+        rc, r_, o_, rr = ref.step(tgt, 1, want_results=True)
+        assert rc == 0 and (U.bits64(rr[0]) == U.bits64(res[t])).all()
+    env.close()
+
+
 def test_wide_path_agrees_with_the_tuned_kernels_at_250_500():
     """Two independent implementations of the same functions: the layer-by-layer path forced onto the tuned size against the fused
     kernels -- actions, both gradients, and the learner after two updates."""
