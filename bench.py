@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
     ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
+    ap.add_argument("--scaled-replay", action="store_true", help="train mode: SURVEY 8(d)'s optional replay mode: ring capacity 72 x envs, every env's transition inserted each step (177 B per env-step) instead of MEM_SIZE = 24 000 with a rotating window of 333 envs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -411,7 +412,7 @@ def main():
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
-        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed)
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed, scaled_replay=args.scaled_replay)
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
 

@@ -719,8 +719,12 @@ class TrainWorkload:
     dtype = "f32"
     EP_LEN = EP_LENGTH_TRAIN
 
-    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False):
+    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False, scaled_replay=False):
         self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
+        # SURVEY.md 8(d), replay-capacity note: the default ring holds MEM_SIZE = 24 000 transitions and every vector step inserts a rotating
+        # window of 333 envs; the optional "scaled" mode holds one 72-step episode of EVERY env (capacity 72 N) and inserts all N each step
+        self.scaled_replay = bool(scaled_replay)
+        self.mem_size = self.EP_LEN * self.n if self.scaled_replay else MEM_SIZE
         self.overlap = bool(overlap)
         if mixed:                                            # BASELINE config 5: 10 profiles x discomfort-weight sweep
             tabs, cfgs, co = S.mixed_profile_setup(self.n)
@@ -736,10 +740,10 @@ class TrainWorkload:
             import os
             if os.environ.get("SHEMS_DP_OVERLAP") == "0":        # A/B knob of the rehearsal test: collectives in program order
                 self.agent.dp_overlap = False
-        self.ring = ReplayRing(MEM_SIZE)
+        self.ring = ReplayRing(self.mem_size)
         self.agent.populate_memory(self.env, self.ring, seed=self.env_seed)          # MAIN:28
-        self.agent.min_max_buffer(self.ring, MEM_SIZE, seed=self.env_seed)           # MAIN:30
-        self.win = min(self.n, MEM_SIZE // self.EP_LEN)
+        self.agent.min_max_buffer(self.ring, self.mem_size, seed=self.env_seed)      # MAIN:30
+        self.win = min(self.n, self.mem_size // self.EP_LEN)
         self.rew32 = torch.empty(self.n, dtype=torch.float32, device="cuda")
         self.t = 0
         self.episode = 1
@@ -885,7 +889,9 @@ class TrainWorkload:
     def extra(self):
         import zlib
         crc = zlib.crc32(self.agent.actor.detach().cpu().numpy().tobytes()) ^ zlib.crc32(self.agent.critic_t.detach().cpu().numpy().tobytes())
-        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "overlap": self.overlap,
+        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": self.mem_size,
+                "replay_mode": "scaled (capacity 72 N, every env inserts)" if self.scaled_replay else "window (MEM_SIZE = 24 000, 333 envs insert per step)",
+                "overlap": self.overlap,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8, "data_parallel": getattr(self, "dp", None)}

@@ -35,6 +35,15 @@ def test_bench_json_contract_small():
     assert d["value"] > 1e6 and d["updates_per_sec"] > 100
 
 
+def test_bench_scaled_replay_mode():
+    """SURVEY 8(d)'s optional replay mode: ring capacity 72 x envs, every env's transition inserted every step."""
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "4096", "--no-cpu-baseline", "--prewarm-s", "0.1", "--scaled-replay"])
+    assert d["mem_size"] == 72 * 4096 and d["replay_mode"].startswith("scaled") and d["replay_window_envs_per_step"] == 4096
+    assert d["value"] > 1e6 and d["updates_per_sec"] > 100
+    d0 = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "4096", "--no-cpu-baseline", "--prewarm-s", "0.1"])
+    assert d0["mem_size"] == 24000 and d0["replay_mode"].startswith("window") and d0["replay_window_envs_per_step"] == 333
+
+
 def test_bench_mixed_profiles():
     """BASELINE config 5: 10 charger profiles x 6 (discomfort weight, power) points, per-env configs."""
     d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline", "--mixed"])
