@@ -1,6 +1,8 @@
 """End-to-end demonstration run (not a benchmark): populate_memory -> min_max_buffer -> run_episodes on 4 096 households, with
 the deterministic evaluation sweep every `test_every` episodes, then the same for a learner group of 8 independent seeds.
-Writes one JSON document (learning curves, rule-based reference score) to the path given as argv[1]."""
+Writes one JSON document (learning curves, rule-based reference score) to the path given as argv[1].
+argv[3] = "L1xL2" (e.g. 300x600) trains the single learner with those hidden sizes (wider than (250, 500): the layer-by-layer path; the learner
+group, which runs the tuned kernels only, is skipped then)."""
 import importlib
 import json
 import os
@@ -18,13 +20,14 @@ G = importlib.import_module(PKG + ".group")
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else "learning_curve.json"
 num_ep = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+hidden = tuple(int(x) for x in sys.argv[3].split("x")) if len(sys.argv) > 3 else (250, 500)
 tab, ev = S.tables.synthetic_table("train", 98), S.tables.synthetic_table("eval", 98)
 env = S.ShemsBatch(4096, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
 env_eval = S.ShemsBatch(100, 1439, [ev], [S.make_config(98, 0, ev.shape[0])]).use_torch_stream()
 env_eval.reset_(123, episode=1)
 rule = env_eval.rollout("rule", 72).mean().item()
 
-ag = D.Agent(seed=1231)
+ag = D.Agent(seed=1231, hidden=hidden)
 ring = D.ReplayRing(D.MEM_SIZE)
 ag.populate_memory(env, ring)
 ag.min_max_buffer(ring)
@@ -33,9 +36,14 @@ t0 = time.perf_counter()
 tr, sm, best_run, _ = ag.run_episodes(env, env_eval, ring, num_ep=num_ep, test_every=25, test_runs=100,
                                       on_eval=lambda i, r, s: curve.append({"episode": i, "train_return": float(r), "eval_score": float(s)}))
 torch.cuda.synchronize()
-single = {"episodes": num_ep, "envs": 4096, "updates": ag.updates, "wall_s": time.perf_counter() - t0, "best_run": int(best_run),
+single = {"hidden": list(hidden), "episodes": num_ep, "envs": 4096, "updates": ag.updates, "wall_s": time.perf_counter() - t0, "best_run": int(best_run),
           "curve": curve, "train_return_first10": float(tr[:10].mean()), "train_return_last10": float(tr[-10:].mean())}
 
+if D.is_wide(hidden):
+    json.dump({"rule_based_eval_score": rule, "single_learner": single}, open(out_path, "w"), indent=1)
+    print(json.dumps({"rule": rule, "hidden": list(hidden), "eval_first": curve[0]["eval_score"], "eval_last": curve[-1]["eval_score"],
+                      "best": max(c["eval_score"] for c in curve), "wall_s": single["wall_s"], "updates": ag.updates}))
+    sys.exit(0)
 # learner group: 8 independent seeds x 512 households, same protocol, evaluation per learner at the end
 L, E = 8, 512
 envg = S.ShemsBatch(L * E, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
