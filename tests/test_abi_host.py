@@ -1,6 +1,7 @@
 """CPU tests: the C-ABI library loads and exports what include/shems_hip.h declares; host logic
 (tables, configs) behaves; without a GPU the product path fails loudly instead of falling back."""
 import ctypes as C
+import importlib
 import os
 import re
 import subprocess
@@ -98,14 +99,15 @@ def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
 
 _C_SCALARS = {"int": "Cint", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint32_t": "UInt32", "uint16_t": "UInt16",
               "uint8_t": "UInt8", "float": "Float32", "double": "Float64", "shems_config": "ShemsConfig", "void": "Cvoid",
-              "shems_env": "Cvoid"}
+              "shems_env": "Cvoid", "shems_view": "ShemsView", "shems_act_params": "ShemsActParams", "shems_replay": "ShemsReplay",
+              "shems_ring_window": "ShemsRingWindow", "shems_ddpg": "ShemsDdpg"}
 
 
 def _julia_types_for(c_arg):
     """The Julia ccall argument types that are ABI-identical to one C parameter declaration (name stripped).  `T *` accepts Ptr{T}
     and Ref{T}; an opaque `shems_env *` is Ptr{Cvoid}, `shems_env **` Ptr{Ptr{Cvoid}}."""
     import re
-    c = re.sub(r"/\*.*?\*/", "", c_arg).replace("const", " ").strip()
+    c = re.sub(r"\bstruct\b", " ", re.sub(r"/\*.*?\*/", "", c_arg, flags=re.S).replace("const", " ")).strip()
     m = re.match(r"^(\w+)\s*(\*{0,2})\s*(\w*)$", c)
     assert m, c_arg
     base, stars = _C_SCALARS[m.group(1)], len(m.group(2))
@@ -158,3 +160,72 @@ def test_julia_module_binds_only_declared_entry_points(built_lib):
     types = re.findall(r"::(\w+)", fields)
     assert types == ["Float32", "Float32", "Float64", "Float64", "Float64", "Float32", "Int32", "Int32", "Int32"]
     assert C.sizeof(S._capi.Config) == 48
+
+
+def _c_struct_fields(hdr, name):
+    """Julia types of the fields of `typedef struct <name> { ... } <name>;` in declaration order (`float *a, *b;` -> two Ptr{Float32})."""
+    import re
+    body = re.search(r"typedef struct " + name + r"\s*\{(.*?)\}\s*" + name + r"\s*;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.replace("const", " ").strip()
+        if not decl:
+            continue
+        m = re.match(r"^(\w+)\s+(.*)$", decl, re.S)
+        base = _C_SCALARS[m.group(1)]
+        for d in m.group(2).split(","):
+            out.append(f"Ptr{{{base}}}" if d.strip().startswith("*") else base)
+    return out
+
+
+def _julia_struct_fields(src, name):
+    import re
+    body = re.search(r"(?:^|\n)struct " + name + r"\b(.*?)\nend", src, re.S).group(1)
+    body = re.sub(r"#.*", "", body)
+    return re.findall(r"\w+::([\w{}]+)", body)
+
+
+def test_julia_learner_module_matches_the_header(built_lib):
+    """julia/DDPG_hip.jl -- the reference's DDPG.jl / memory_plotting_saving.jl functions over the device-pointer API -- cannot be executed
+    here either.  Statically: every `ccall((:symbol, LIB), ...)` names a declared, exported entry point with ABI-identical argument and
+    return types (position by position), every struct mirror has the field types of its C struct in order, and the functions the
+    reference's entry script calls (DDPG_reinforce_charger_v1.jl:27-105) are defined."""
+    import re
+    S = U.pkg()
+    src = open(os.path.join(U.ROOT, "julia", "DDPG_hip.jl")).read()
+    hdr = open(os.path.join(U.ROOT, "include", "shems_hip.h")).read()
+    L = S._capi.lib()
+    calls = re.findall(r"ccall\(\(:(\w+), LIB\), (\w+),\s*\(([^)]*)\)", src)
+    assert len(calls) >= 14 and {c[0] for c in calls} >= {"shems_act_step_dev", "shems_ddpg_update", "shems_rollout_dev", "shems_minmax_dev",
+                                                           "shems_track_dev", "shems_get_view", "shems_reset_seeded_dev"}
+    for name, ret, args in calls:
+        assert hasattr(L, name), name
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
+        assert m, f"{name} is not declared in include/shems_hip.h"
+        decl = [] if m.group(1).strip() in ("", "void") else [a.strip() for a in m.group(1).split(",")]
+        call = [a.strip() for a in args.split(",") if a.strip()]
+        assert len(decl) == len(call), (name, decl, call)
+        for pos, (c_arg, j_arg) in enumerate(zip(decl, call)):
+            assert j_arg in _julia_types_for(c_arg), (name, pos, c_arg, j_arg)
+        c_ret = re.search(r"(const char \*|int)\s*" + name + r"\s*\(", hdr).group(1).strip()
+        assert ret == {"int": "Cint", "const char *": "Cstring"}[c_ret], (name, c_ret, ret)
+    for cname, jname in (("shems_config", "ShemsConfig"), ("shems_view", "ShemsView"), ("shems_replay", "ShemsReplay"),
+                         ("shems_act_params", "ShemsActParams"), ("shems_ring_window", "ShemsRingWindow"), ("shems_ddpg", "ShemsDdpg")):
+        assert _julia_struct_fields(src, jname) == _c_struct_fields(hdr, cname), (cname, _julia_struct_fields(src, jname), _c_struct_fields(hdr, cname))
+    # the ctypes mirrors the tests drive have the same sizes as those field lists imply (8-byte pointers, natural alignment)
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    size = {"Float32": 4, "Int32": 4, "UInt32": 4, "Float64": 8, "Int64": 8, "UInt64": 8}
+    def c_size(types):
+        off = 0
+        for t in types:
+            n = 8 if t.startswith("Ptr{") else size[t]
+            off = (off + n - 1) // n * n + n
+        return (off + 7) // 8 * 8
+    assert c_size(_c_struct_fields(hdr, "shems_act_params")) == C.sizeof(D.ActParams)
+    assert c_size(_c_struct_fields(hdr, "shems_ddpg")) == C.sizeof(D.DdpgArgs)
+    assert c_size(_c_struct_fields(hdr, "shems_view")) == C.sizeof(S._capi.View) and c_size(_c_struct_fields(hdr, "shems_replay")) == C.sizeof(S._capi.Replay)
+    for needed in ("module DDPG_hip", "function act(ag::Agent", "function act_step!(ag::Agent", "function replay(ag::Agent", "function populate_memory(ag::Agent",
+                   "function min_max_buffer(ag::Agent", "function episode!(ag::Agent", "function run_episodes(ag::Agent", "function inference(env::EnvBatch",
+                   "flat_params(params)"):
+        assert needed in src, needed
