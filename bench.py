@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
     ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
     ap.add_argument("--scaled-replay", action="store_true", help="train mode: SURVEY 8(d)'s optional replay mode: ring capacity 72 x envs, every env's transition inserted each step (177 B per env-step) instead of MEM_SIZE = 24 000 with a rotating window of 333 envs")
+    ap.add_argument("--hidden", default="250x500", help="train mode: Dense widths L1xL2 of actor and critic; the headline is the tuned 250x500, 300x600 is the reference grids' wider point (layer-by-layer path, csrc/shems_wide.hip), smaller ones run zero-padded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -412,7 +413,8 @@ def main():
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
-        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed, scaled_replay=args.scaled_replay)
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed, scaled_replay=args.scaled_replay,
+                                     hidden=tuple(int(x) for x in args.hidden.lower().split("x")))
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
 
@@ -479,7 +481,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes, see profiles/README.md
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(mode, {})
-            if rec.get("envs_per_gpu") == args.envs:
+            if rec.get("envs_per_gpu") == args.envs and args.hidden.lower() == "250x500":      # counters of the headline kernel only
                 traffic = rec.get("hbm_bytes_per_launch")
                 # PMC counters cannot be read from inside this process: the figure is the committed result of separate
                 # `rocprofv3 --pmc` passes over this same command, not a measurement of the run that prints it
@@ -489,7 +491,7 @@ def main():
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
                 "algorithmic_per_launch": k["algorithmic"],
                 "timing": k.get("method", "HIP events over back-to-back groups of 8 launches")}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.hidden.lower() == "250x500":      # (the CPU port is timed at the headline architecture)
             cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)
     if dist is not None:
         dist.barrier()
@@ -510,7 +512,7 @@ def main():
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": f"{args.envs} parallel shems_LU1 envs per GPU, Charger98 synthetic train table "
-                                   f"(4320 rows), {EP_LEN}-step episodes, mode={mode}",
+                                   f"(4320 rows), {EP_LEN}-step episodes, mode={mode}" + ("" if args.hidden.lower() == "250x500" else f", networks {args.hidden}"),
                        "envs_per_gpu": args.envs, "episode_len": EP_LEN, "mode": mode, "mixed_profiles": bool(args.mixed)},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -719,7 +719,7 @@ class TrainWorkload:
     dtype = "f32"
     EP_LEN = EP_LENGTH_TRAIN
 
-    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False, scaled_replay=False):
+    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False, scaled_replay=False, hidden=(L1, L2)):
         self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
         # SURVEY.md 8(d), replay-capacity note: the default ring holds MEM_SIZE = 24 000 transitions and every vector step inserts a rotating
         # window of 333 envs; the optional "scaled" mode holds one 72-step episode of EVERY env (capacity 72 N) and inserts all N each step
@@ -734,7 +734,8 @@ class TrainWorkload:
             self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
                                     device=torch.cuda.current_device()).use_torch_stream()
         self.env_seed = int(seed)
-        self.agent = Agent(seed=1231, rng_seed=self.env_seed)   # same initial weights on every rank (config: seed 1231)
+        self.hidden = (int(hidden[0]), int(hidden[1]))       # other than (250, 500): another point of the reference's grids (bench.py --hidden)
+        self.agent = Agent(seed=1231, rng_seed=self.env_seed, hidden=self.hidden)   # same initial weights on every rank (config: seed 1231)
         if dist is not None:
             self.agent.enable_data_parallel(dist)
             import os
@@ -880,8 +881,10 @@ class TrainWorkload:
             self.t, self.episode, self.ring.pushed = t_saved, ep_saved, pushed_saved
         self.update_us = upd_avg / self.updates if self.updates else None
         self.step_us_in_pass = step_avg
-        flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n               # 256 500 FLOP / env-step
-        return dict(kernel="shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)", avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
+        h1, h2 = self.hidden
+        flops = 2 * (9 * h1 + h1 * h2 + h2 * 2) * self.n                     # 256 500 FLOP / env-step at (250, 500)
+        kname = "shems::k_wgemm x3 + k_act_tail (wide network, csrc/shems_wide.hip)" if self.agent.wide else "shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)"
+        return dict(kernel=kname, avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
                     method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
                            + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))
@@ -894,7 +897,8 @@ class TrainWorkload:
                 "overlap": self.overlap,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
-                "update_mflop": 307.8, "data_parallel": getattr(self, "dp", None)}
+                "update_mflop": 307.8 if self.hidden == (L1, L2) else 20 * (10 * self.hidden[0] + self.hidden[0] * self.hidden[1] + 1.5 * self.hidden[1]) * BATCH_SIZE / 1e6,
+                "hidden": list(self.hidden), "data_parallel": getattr(self, "dp", None)}
 
 
 def smoke():
