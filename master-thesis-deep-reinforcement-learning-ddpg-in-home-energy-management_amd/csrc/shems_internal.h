@@ -26,9 +26,11 @@ int check_view(const shems_view *v, const char *fn);    // every entry point tha
 // on any parameter count: the wide-network path (shems_wide.hip) applies its gradients with it.
 int adam_soft_sweep(float *p, const float *g, float *m, float *v, float *target, float *publish, int n, double eta, double bp1, double bp2,
                     double gscale, float tau, hipStream_t st);
-// shems_wide.hip: pre-activation outputs [m][2] (b3 included) of an actor (9 -> l1 -> l2 -> 2) of any hidden sizes for m observations;
-// d_ws holds wide_act_ws_floats(l1, l2, m) floats of scratch (normalised observations and both hidden layers).
+// shems_wide.hip: forward pass of an actor (9 -> l1 -> l2 -> 2) of any hidden sizes for m observations, up to the output layer's partial
+// sums: d_part [*n_partials][m][2] (b3 not included; the caller adds b3 and the partials in index order).  d_ws holds
+// wide_act_ws_floats(l1, l2, m) floats of scratch (normalised observations, layer 1, then -- at wide_act_part_offset -- the partials).
 int wide_actor_pre(const float *actor, const float *s_min, const float *s_max, int l1, int l2, const float *d_obs, int64_t m, float *d_ws,
-                   float *d_pre, hipStream_t st);
+                   float *d_part, int *n_partials, hipStream_t st);
 int64_t wide_act_ws_floats(int l1, int l2, int64_t m);
+int64_t wide_act_part_offset(int l1, int64_t m);
 }

@@ -1720,21 +1720,29 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     return launch_actg<1, 4, 2, 3>(a, st);
 }
 
-// Wide networks (shems_wide.hip): the layers ran as matrix products and left the pre-activation outputs; this is the rest of the
-// fused step -- tanh, noise, clamp, scale_action, step!, remember -- one thread per env, the same act_env_tail as every form above
-// (the same draws for the same (seed, tick, env)).
-__global__ __launch_bounds__(256) void k_act_tail(ActArgs A, const float *__restrict__ pre)
+// Wide networks (shems_wide.hip): the layers ran as matrix products and left partial sums of the output layer; this is the rest of the
+// fused step -- b3 + the partials in index order, tanh, noise, clamp, scale_action, step!, remember -- one thread per env, the same
+// act_env_tail as every form above (the same draws for the same (seed, tick, env)).
+__global__ __launch_bounds__(256) void k_act_tail(ActArgs A, const float *__restrict__ part, int n_part, const float *__restrict__ b3)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < A.m) act_env_tail(A, i, pre[2 * i], pre[2 * i + 1], 0, 0, nullptr);
+    if (i >= A.m) return;
+    float p0 = 0.0f, p1 = 0.0f;
+    for (int p = 0; p < n_part; ++p) {
+        const float2 v = reinterpret_cast<const float2 *>(part)[(int64_t)p * A.m + i];
+        p0 += v.x; p1 += v.y;
+    }
+    act_env_tail(A, i, b3[0] + p0, b3[1] + p1, 0, 0, nullptr);
 }
 
 static int wide_act(const ActArgs &a, int l1, int l2, float *d_ws, hipStream_t st)
 {
     if (!d_ws || ((uintptr_t)d_ws & 15) != 0) return set_error(SHEMS_ERR_ARG, "shems_wide_act: 16-byte aligned workspace required");
-    float *pre = d_ws + wide_act_ws_floats(l1, l2, a.m) - 2 * a.m;
-    if (int rc = wide_actor_pre(a.p.actor, a.p.s_min, a.p.s_max, l1, l2, a.obs, a.m, d_ws, pre, st)) return rc;
-    hipLaunchKernelGGL(k_act_tail, dim3((unsigned)((a.m + 255) / 256)), dim3(256), 0, st, a, pre);
+    float *part = d_ws + wide_act_part_offset(l1, a.m);
+    int n_part = 0;
+    if (int rc = wide_actor_pre(a.p.actor, a.p.s_min, a.p.s_max, l1, l2, a.obs, a.m, d_ws, part, &n_part, st)) return rc;
+    const float *b3 = a.p.actor + ((int64_t)kIn * l1 + l1 + (int64_t)l1 * l2 + l2 + (int64_t)l2 * kOut);
+    hipLaunchKernelGGL(k_act_tail, dim3((unsigned)((a.m + 255) / 256)), dim3(256), 0, st, a, part, n_part, b3);
     return hip_ok(hipGetLastError(), "k_act_tail launch");
 }
 

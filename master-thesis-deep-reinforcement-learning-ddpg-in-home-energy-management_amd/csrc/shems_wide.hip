@@ -5,20 +5,25 @@
 // here, layer by layer, exactly as the reference's Flux / CUBLAS path does (Dense = W*x .+ b, Zygote's pullbacks: DDPG.jl:21-46,
 // 99-145): every layer, forward or backward, is ONE general matrix product with a fused bias / relu / relu' epilogue.
 //
-//   k_wgemm   C[M][N] = epilogue(sum_k A(i, k) B(k, j)) on v_mfma_f32_32x32x2_f32, 64 x 64 tile per workgroup of 4 waves, K in
-//             stages of 16 through LDS with the next stage's global loads in flight; both operands by (row, column) element
-//             strides, so W (Flux layout [in][out]), its transpose, and the sample-major activations [m][features] all go in
-//             without a copy.  fp32 accumulation in a fixed order: results are reproducible bit for bit, and tolerance-class
-//             against the oracle like the tuned kernels (tests/test_wide_gpu.py).
-//   the rest  elementwise / column-sum kernels: normalize, minibatch sample + gather (the same Philox sampler as the tuned path:
-//             the same (seed, tick) draws the same slots), tanh + concatenation, the two loss heads.
+// All on v_mfma_f32_32x32x2_f32 with fp32 accumulation in fixed orders (reproducible bit for bit; tolerance-class against the oracle like
+// the tuned kernels, tests/test_wide_gpu.py); both operands by (row, column) element strides, so W (Flux layout [in][out]), its
+// transpose, and the sample-major activations [m][features] go in without a copy.
+//   k_wgemm       64 x 64 tile per workgroup of 4 waves, K in stages of 16 through double-buffered LDS: the vector step's layer 1.
+//   k_wgemm128    128 x 128 tile, each wave a 64 x 64 quarter as 2 x 2 MFMA blocks: the vector step's layer 2 -- with the output layer
+//                 folded into its epilogue, so relu(layer 2) never leaves the registers.
+//   k_wgemm_sk    32 x 32 tile, K stage split over the four waves, up to four independent products per launch: everything in replay(),
+//                 where one of M, N, K is the 128-row minibatch.
+//   the rest      elementwise kernels: normalize, minibatch sample + gather (the same Philox sampler as the tuned path: the same
+//                 (seed, tick) draws the same slots), tanh + concatenation, the two loss heads.
 // ADAM + soft target update are shems_ddpg.hip's sweep (adam_soft_sweep: the same arithmetic on any parameter count).
 //
-// This path is about running the grid point, not about the roofline: ~45 launches per replay() (~0.3 ms), a vector step of 65 536
-// envs is three GEMMs through HBM-resident activations.  The headline configuration never comes here.
+// This path is about running the grid point, not about the roofline: sampler + 24 launches per replay() (0.22 ms at (300, 600)), a
+// vector step of 65 536 envs 0.36 ms (68 TFLOP/s).  The headline configuration never comes here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
+#include <initializer_list>
 
 #include "philox.h"
 #include "shems_internal.h"
@@ -41,6 +46,11 @@ struct GemmArgs {
     const float *gate;                   // [M][ldg] or null: C = gate > 0 ? C : 0  (relu' read off the stored post-relu activations)
     int64_t ldg;
     int relu;
+    // k_wgemm128<true> only: the output layer folded into this product's epilogue.  With C = relu(A B + bias) never stored,
+    // head_out[(2 t + h) * M + i][o] = sum over the 64 columns j of half h of column tile t of C[i][j] * head_w[j * head_n + o]
+    const float *head_w;
+    float *head_out;
+    int head_n;
 };
 
 __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
@@ -107,13 +117,128 @@ __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
     }
 }
 
+// The vector step's layer 2 (M = tens of thousands of envs, N = l2, K = l1: 98 % of its FLOPs): 128 x 128 tile, each wave a 64 x 64
+// quarter as 2 x 2 MFMA blocks, so a k-step's four operand reads feed four MFMAs (the 64 x 64 kernel above: two reads per MFMA).
+// HEAD: the output layer (l2 -> 2) is folded into the epilogue -- every wave reduces its 64 columns of relu(C) against W3 and leaves one
+// partial per (row, output); relu(layer 2), 157 MB at 65 536 envs x 600, is never written or read back, and the N = 2 product, which
+// a 64-wide tile pads 32-fold, disappears.  k_act_tail adds the partials in index order.
+constexpr int BT = 128, BLD = BT + 4, BR = BT * GK / 256;
+template <bool HEAD>
+__global__ __launch_bounds__(256) void k_wgemm128(GemmArgs G)
+{
+    __shared__ float As[2][GK][BLD], Bs[2][GK][BLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BT, n0 = (int64_t)blockIdx.y * BT;
+    const bool a_kfast = G.sak == 1, b_jfast = G.sbj == 1;
+    int ai[BR], ak[BR], bj[BR], bk[BR];
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+        const int e = tid + 256 * r;
+        ai[r] = a_kfast ? e >> GKB : e & (BT - 1);  ak[r] = a_kfast ? e & (GK - 1) : e >> 7;
+        bj[r] = b_jfast ? e & (BT - 1) : e >> GKB;  bk[r] = b_jfast ? e >> 7 : e & (GK - 1);
+    }
+    float ra[BR], rb[BR];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            const int64_t i = m0 + ai[r], j = n0 + bj[r];
+            const int ka = k0 + ak[r], kb = k0 + bk[r];
+            ra[r] = (i < G.M && ka < G.K) ? G.A[i * G.sai + ka * G.sak] : 0.0f;
+            rb[r] = (j < G.N && kb < G.K) ? G.B[kb * G.sbk + j * G.sbj] : 0.0f;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < BR; ++r) { As[buf][ak[r]][ai[r]] = ra[r]; Bs[buf][bk[r]][bj[r]] = rb[r]; }
+    };
+    wf32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int nst = (G.K + GK - 1) / GK;
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) fetch((s + 1) * GK);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a0 = As[buf][kk + lh][wi * 64 + li], a1 = As[buf][kk + lh][wi * 64 + 32 + li];
+            const float b0 = Bs[buf][kk + lh][wj * 64 + li], b1 = Bs[buf][kk + lh][wj * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nst) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if constexpr (!HEAD) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int64_t j = n0 + wj * 64 + y * 32 + li;
+            if (j >= G.N) continue;
+            const float bj_ = G.bias ? G.bias[j] : 0.0f;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t i = m0 + wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (i < G.M) {
+                        float v = acc[x][y][r] + bj_;
+                        if (G.relu) v = fmaxf(v, 0.0f);
+                        if (G.gate) v = G.gate[i * G.ldg + j] > 0.0f ? v : 0.0f;
+                        G.C[i * G.ldc + j] = v;
+                    }
+                }
+        }
+    } else {
+        // this lane's two columns: bias and the head's weights (zero beyond N, so padded columns add nothing)
+        float bb[2], w3[2][2];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int64_t j = n0 + wj * 64 + y * 32 + li;
+            const bool in = j < G.N;
+            const int64_t jc = in ? j : 0;
+            bb[y] = in && G.bias ? G.bias[jc] : 0.0f;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) w3[y][o] = in && o < G.head_n ? G.head_w[jc * G.head_n + o] : 0.0f;
+        }
+        float *out = G.head_out + ((int64_t)blockIdx.y * 2 + wj) * G.M * G.head_n;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v0 = fmaxf(acc[x][0][r] + bb[0], 0.0f), v1 = fmaxf(acc[x][1][r] + bb[1], 0.0f);
+                float s0 = v0 * w3[0][0] + v1 * w3[1][0], s1 = v0 * w3[0][1] + v1 * w3[1][1];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }     // over the half's 32 lanes
+                const int64_t i = m0 + wi * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (li == 0 && i < G.M) {
+                    out[i * G.head_n] = s0;
+                    if (G.head_n > 1) out[i * G.head_n + 1] = s1;
+                }
+            }
+    }
+}
+
 // The minibatch-sized products (M <= a few hundred rows): few tiles and a long K.  One wave's chain of 32x32x2 MFMAs costs 32 cycles
 // per k whatever the memory system does (K = 600: 9 us), and a 64 x 64 tile per workgroup leaves most CUs idle (N = 600: 20
 // workgroups).  So here a workgroup owns a 32 x 32 tile and its four waves split every 64-deep K stage four ways (16 k each); the
 // four partial tiles meet in LDS at the end and are added in wave order (a fixed order).  Same operands, strides and epilogue.
-constexpr int SK = 64, SKB = 6, SLD = 32 + 4, SR = 32 * SK / 256;
-__global__ __launch_bounds__(256) void k_wgemm_sk(GemmArgs G)
+// Up to four INDEPENDENT products ride in one launch (grid z): the update is a chain of small dependent launches, and e.g. the layer-1
+// products of three forward passes, or a layer's weight gradient, bias gradient and back-propagated error, need nothing from each other.
+constexpr int SK = 64, SKB = 6, SLD = 32 + 4, SR = 32 * SK / 256, GMAX = 4;
+struct GemmBatch { GemmArgs g[GMAX]; };
+__global__ __launch_bounds__(256) void k_wgemm_sk(GemmBatch B)
 {
+    const GemmArgs &G = B.g[blockIdx.z];
+    if ((int64_t)blockIdx.x * 32 >= G.M || (int64_t)blockIdx.y * 32 >= G.N) return;      // (the grid is the largest problem's)
     __shared__ float As[2][SK][SLD], Bs[2][SK][SLD];
     __shared__ float red[4][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -190,14 +315,31 @@ __global__ __launch_bounds__(256) void k_wgemm_sk(GemmArgs G)
     }
 }
 
+static GemmArgs prod(const float *A, int64_t sai, int64_t sak, const float *B, int64_t sbk, int64_t sbj, float *C, int64_t ldc,
+                     int64_t M, int N, int K, const float *bias = nullptr, int relu = 0, const float *gate = nullptr, int64_t ldg = 0)
+{
+    return GemmArgs{A, B, C, (int)M, N, K, sai, sak, sbk, sbj, ldc, bias, gate, ldg, relu};
+}
+// independent minibatch-sized products (one of M, N, K is the minibatch) in one launch
+static int gemm_multi(hipStream_t st, std::initializer_list<GemmArgs> list)
+{
+    GemmBatch b;
+    std::memset(&b, 0, sizeof b);
+    unsigned gx = 1, gy = 1, n = 0;
+    for (const GemmArgs &g : list) {
+        if (n >= GMAX) return set_error(SHEMS_ERR_ARG, "gemm_multi: at most %d products per launch", GMAX);
+        b.g[n++] = g;
+        gx = std::max(gx, (unsigned)((g.M + 31) / 32));
+        gy = std::max(gy, (unsigned)((g.N + 31) / 32));
+    }
+    hipLaunchKernelGGL(k_wgemm_sk, dim3(gx, gy, n), dim3(256), 0, st, b);
+    return hip_ok(hipGetLastError(), "k_wgemm_sk launch");
+}
 static int gemm(hipStream_t st, const float *A, int64_t sai, int64_t sak, const float *B, int64_t sbk, int64_t sbj, float *C, int64_t ldc,
                 int64_t M, int N, int K, const float *bias = nullptr, int relu = 0, const float *gate = nullptr, int64_t ldg = 0)
 {
     GemmArgs g{A, B, C, (int)M, N, K, sai, sak, sbk, sbj, ldc, bias, gate, ldg, relu};
-    if (M <= 512) {
-        hipLaunchKernelGGL(k_wgemm_sk, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, st, g);
-        return hip_ok(hipGetLastError(), "k_wgemm_sk launch");
-    }
+    if (M <= 512) return gemm_multi(st, {g});
     hipLaunchKernelGGL(k_wgemm, dim3((unsigned)((M + GT - 1) / GT), (unsigned)((N + GT - 1) / GT)), dim3(256), 0, st, g);
     return hip_ok(hipGetLastError(), "k_wgemm launch");
 }
@@ -213,6 +355,14 @@ static WNet wnet(const float *P, int in, int l1, int l2, int out)
     return WNet{W1, b1, W2, b2, W3, b3, in, l1, l2, out};
 }
 static int64_t wnet_size(int in, int l1, int l2, int out) { return (int64_t)in * l1 + l1 + (int64_t)l1 * l2 + l2 + (int64_t)l2 * out + out; }
+
+// The three layer products of a forward pass over WBP rows, as values: independent passes are launched layer by layer together.
+struct Fwd { GemmArgs l1, l2, l3; };
+static Fwd fwd_of(const WNet &n, const float *X, float *H1, float *H2, float *P)
+{
+    return Fwd{prod(X, n.in, 1, n.W1, n.l1, 1, H1, n.l1, WBP, n.l1, n.in, n.b1, 1), prod(H1, n.l1, 1, n.W2, n.l2, 1, H2, n.l2, WBP, n.l2, n.l1, n.b2, 1),
+               prod(H2, n.l2, 1, n.W3, n.out, 1, P, n.out, WBP, n.out, n.l2, n.b3, 0)};
+}
 
 // X [m][in] -> H1 [m][l1], H2 [m][l2] (post-relu), P [m][out] (pre-activation of the last layer, b3 included)
 static int net_forward(hipStream_t st, const WNet &n, const float *X, int64_t m, float *H1, float *H2, float *P)
@@ -240,6 +390,7 @@ struct WWs {
     int32_t *IDX;                             // [WBP] sampled ring slots
     float *PA, *PT, *API, *DA, *D3;           // [WBP][2] actor pre-activation, target actor's, a_pi; [WBP][11] d loss / d [s; a_pi]; [WBP][2]
     float *T1, *T2, *H1c, *H2c, *H1a, *H2a, *H1q, *H2q, *G1, *G2;
+    float *ONES;                              // [WBP] ones: a bias gradient sum_m dY[m][n] is the product ones' dY, one more tile in a launch that runs anyway
     int64_t total;
 };
 static WWs wws(float *base, int l1, int l2)
@@ -256,6 +407,7 @@ static WWs wws(float *base, int l1, int l2)
     w.H1a = take((int64_t)WBP * l1); w.H2a = take((int64_t)WBP * l2);
     w.H1q = take((int64_t)WBP * l1); w.H2q = take((int64_t)WBP * l2);
     w.G1 = take((int64_t)WBP * l1); w.G2 = take((int64_t)WBP * l2);
+    w.ONES = take(WBP);
     w.total = o;
     return w;
 }
@@ -293,26 +445,21 @@ __global__ __launch_bounds__(WBP) void k_wprep(WPrep A)
     w.DONE[m] = live && A.ring.done[j] ? 1.0f : 0.0f;
     w.DQA[m] = live ? -1.0f / (float)A.batch : 0.0f;                 // d(-mean q) / dq
     w.IDX[m] = live ? (int32_t)j : -1;
+    w.ONES[m] = 1.0f;
 }
 
-// a = tanh(P) for the live rows -> A_out [WBP][2] (may be null) and the action columns of a [WBP][11] critic input
-__global__ __launch_bounds__(WBP) void k_wtanh_cat(const float *__restrict__ P, float *__restrict__ a_out, float *__restrict__ cat, int batch)
+// a = tanh(P) for the live rows -> a_out [WBP][2] (may be null) and the action columns of a [WBP][11] critic input; workgroup 0: the
+// target actor's head into [s'; a'], workgroup 1: the actor's into a_pi and [s; a_pi]
+__global__ __launch_bounds__(WBP) void k_wtanh_cat(const float *__restrict__ P0, float *__restrict__ a0_out, float *__restrict__ cat0,
+                                                   const float *__restrict__ P1, float *__restrict__ a1_out, float *__restrict__ cat1, int batch)
 {
     const int m = threadIdx.x;
+    const float *P = blockIdx.x == 0 ? P0 : P1;
+    float *a_out = blockIdx.x == 0 ? a0_out : a1_out, *cat = blockIdx.x == 0 ? cat0 : cat1;
     const float a0 = m < batch ? tanhf(P[2 * m]) : 0.0f, a1 = m < batch ? tanhf(P[2 * m + 1]) : 0.0f;
     if (a_out) { a_out[2 * m] = a0; a_out[2 * m + 1] = a1; }
     cat[m * WCIN + 9] = a0;
     cat[m * WCIN + 10] = a1;
-}
-
-// out[j] = sum_m D[m][j], m ascending (one thread per column: a fixed order)
-__global__ __launch_bounds__(256) void k_wcolsum(const float *__restrict__ D, int n, float *__restrict__ out)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    float s = 0.0f;
-    for (int m = 0; m < WBP; ++m) s += D[(int64_t)m * n + j];
-    out[j] = s;
 }
 
 // critic loss head (DDPG.jl:131-135): y = r + gamma (1 - done) q', dq = 2 (q - y) / B, loss = mean((q - y)^2)
@@ -354,31 +501,27 @@ __global__ __launch_bounds__(WBP) void k_wactor_head(WWs w, int batch, float *lo
 }
 
 // Zygote's pullback of Chain(Dense, Dense, Dense) for the error d3 [WBP][out] at the last layer's pre-activation: parameter
-// gradients into `grad` (flat Flux layout); dX [WBP][in] = d loss / d input if asked for.  X, H1, H2: what the forward pass kept.
+// gradients into `grad` (flat Flux layout; null = input gradient only); dX [WBP][in] = d loss / d input if asked for.  X, H1, H2: what
+// the forward pass kept.  Three launches: {gW3, gb3, G2}, {gW2, gb2, G1}, {gW1, gb1, dX} -- within one, nothing depends on anything.
 static int net_backward(hipStream_t st, const WNet &n, const float *X, const float *H1, const float *H2, const float *d3, float *grad,
-                        float *G1, float *G2, float *dX)
+                        float *G1, float *G2, float *dX, const float *ones)
 {
-    const int64_t oW1 = 0, ob1 = oW1 + (int64_t)n.in * n.l1, oW2 = ob1 + n.l1, ob2 = oW2 + (int64_t)n.l1 * n.l2, oW3 = ob2 + n.l2,
-                  ob3 = oW3 + (int64_t)n.l2 * n.out;
-    float *gW1 = grad ? grad + oW1 : nullptr, *gb1 = grad ? grad + ob1 : nullptr, *gW2 = grad ? grad + oW2 : nullptr,
-          *gb2 = grad ? grad + ob2 : nullptr, *gW3 = grad ? grad + oW3 : nullptr, *gb3 = grad ? grad + ob3 : nullptr;
-    if (grad) {
-        if (int rc = gemm(st, H2, 1, n.l2, d3, n.out, 1, gW3, n.out, n.l2, n.out, WBP)) return rc;                       // gW3 = H2' d3
-        hipLaunchKernelGGL(k_wcolsum, dim3(1), dim3(256), 0, st, d3, n.out, gb3);
+    const GemmArgs g2 = prod(d3, n.out, 1, n.W3, 1, n.out, G2, n.l2, WBP, n.l2, n.out, nullptr, 0, H2, n.l2);       // (d3 W3') .* relu'
+    const GemmArgs g1 = prod(G2, n.l2, 1, n.W2, 1, n.l2, G1, n.l1, WBP, n.l1, n.l2, nullptr, 0, H1, n.l1);          // (G2 W2') .* relu'
+    if (!grad) {
+        if (int rc = gemm_multi(st, {g2})) return rc;
+        if (int rc = gemm_multi(st, {g1})) return rc;
+        return dX ? gemm_multi(st, {prod(G1, n.l1, 1, n.W1, 1, n.l1, dX, n.in, WBP, n.in, n.l1)}) : SHEMS_OK;      // G1 W1'
     }
-    if (int rc = gemm(st, d3, n.out, 1, n.W3, 1, n.out, G2, n.l2, WBP, n.l2, n.out, nullptr, 0, H2, n.l2)) return rc;     // (d3 W3') .* relu'
-    if (grad) {
-        hipLaunchKernelGGL(k_wcolsum, dim3((n.l2 + 255) / 256), dim3(256), 0, st, G2, n.l2, gb2);
-        if (int rc = gemm(st, H1, 1, n.l1, G2, n.l2, 1, gW2, n.l2, n.l1, n.l2, WBP)) return rc;                          // gW2 = H1' G2
-    }
-    if (int rc = gemm(st, G2, n.l2, 1, n.W2, 1, n.l2, G1, n.l1, WBP, n.l1, n.l2, nullptr, 0, H1, n.l1)) return rc;        // (G2 W2') .* relu'
-    if (grad) {
-        hipLaunchKernelGGL(k_wcolsum, dim3((n.l1 + 255) / 256), dim3(256), 0, st, G1, n.l1, gb1);
-        if (int rc = gemm(st, X, 1, n.in, G1, n.l1, 1, gW1, n.l1, n.in, n.l1, WBP)) return rc;                            // gW1 = X' G1
-    }
+    float *gW1 = grad, *gb1 = gW1 + (int64_t)n.in * n.l1, *gW2 = gb1 + n.l1, *gb2 = gW2 + (int64_t)n.l1 * n.l2, *gW3 = gb2 + n.l2,
+          *gb3 = gW3 + (int64_t)n.l2 * n.out;
+    auto colsum = [&](const float *D, int cols, float *out) { return prod(ones, WBP, 1, D, cols, 1, out, cols, 1, cols, WBP); };   // ones' D
+    if (int rc = gemm_multi(st, {prod(H2, 1, n.l2, d3, n.out, 1, gW3, n.out, n.l2, n.out, WBP), colsum(d3, n.out, gb3), g2})) return rc;       // gW3 = H2' d3
+    if (int rc = gemm_multi(st, {prod(H1, 1, n.l1, G2, n.l2, 1, gW2, n.l2, n.l1, n.l2, WBP), colsum(G2, n.l2, gb2), g1})) return rc;           // gW2 = H1' G2
     if (dX)
-        if (int rc = gemm(st, G1, n.l1, 1, n.W1, 1, n.l1, dX, n.in, WBP, n.in, n.l1)) return rc;                          // G1 W1'
-    return hip_ok(hipGetLastError(), "wide backward launches");
+        return gemm_multi(st, {prod(X, 1, n.in, G1, n.l1, 1, gW1, n.l1, n.in, n.l1, WBP), colsum(G1, n.l1, gb1),                             // gW1 = X' G1
+                               prod(G1, n.l1, 1, n.W1, 1, n.l1, dX, n.in, WBP, n.in, n.l1)});
+    return gemm_multi(st, {prod(X, 1, n.in, G1, n.l1, 1, gW1, n.l1, n.in, n.l1, WBP), colsum(G1, n.l1, gb1)});
 }
 
 static int check_shape(int l1, int l2, const char *fn)
@@ -396,17 +539,28 @@ static int check_wide(const shems_ddpg *d, int l1, int l2, const char *fn)
     return SHEMS_OK;
 }
 
-// used by shems_policy.hip's wide act entry points
+// used by shems_policy.hip's wide act entry points: the vector step's forward pass.  Outputs `n_partials` partial pre-activation sums
+// [p][m][2] into d_part (b3 NOT included: k_act_tail adds b3 and the partials in index order).
 int wide_actor_pre(const float *actor, const float *s_min, const float *s_max, int l1, int l2, const float *d_obs, int64_t m, float *d_ws,
-                   float *d_pre, hipStream_t st)
+                   float *d_part, int *n_partials, hipStream_t st)
 {
     if (int rc = check_shape(l1, l2, "shems_wide_act")) return rc;
-    float *xn = d_ws, *H1 = xn + (m * WSIN + 3) / 4 * 4, *H2 = H1 + m * l1;
+    float *xn = d_ws, *H1 = xn + (m * WSIN + 3) / 4 * 4;
     const int64_t cnt = m * WSIN;
+    const WNet n = wnet(actor, WSIN, l1, l2, WAIN);
     hipLaunchKernelGGL(k_wnorm, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_obs, s_min, s_max, xn, cnt);
-    return net_forward(st, wnet(actor, WSIN, l1, l2, WAIN), xn, m, H1, H2, d_pre);
+    if (int rc = gemm(st, xn, n.in, 1, n.W1, n.l1, 1, H1, n.l1, m, n.l1, n.in, n.b1, 1)) return rc;
+    // layer 2 with the output layer in its epilogue: relu(layer 2) stays in registers
+    GemmArgs g = prod(H1, n.l1, 1, n.W2, n.l2, 1, nullptr, 0, m, n.l2, n.l1, n.b2, 1);
+    g.head_w = n.W3; g.head_out = d_part; g.head_n = WAIN;
+    const unsigned ty = (unsigned)((l2 + BT - 1) / BT);
+    *n_partials = 2 * (int)ty;
+    hipLaunchKernelGGL(k_wgemm128<true>, dim3((unsigned)((m + BT - 1) / BT), ty), dim3(256), 0, st, g);
+    return hip_ok(hipGetLastError(), "k_wgemm128 launch");
 }
-int64_t wide_act_ws_floats(int l1, int l2, int64_t m) { return (m * WSIN + 3) / 4 * 4 + m * ((int64_t)l1 + l2) + 2 * m; }
+// floats of d_ws: normalised observations, layer 1, and the partial sums of the output layer
+int64_t wide_act_part_offset(int l1, int64_t m) { return (m * WSIN + 3) / 4 * 4 + (m * (int64_t)l1 + 3) / 4 * 4; }      // 16-byte aligned
+int64_t wide_act_ws_floats(int l1, int l2, int64_t m) { return wide_act_part_offset(l1, m) + 2 * ((l2 + BT - 1) / BT) * m * WAIN; }
 
 }  // namespace shems
 
@@ -450,15 +604,20 @@ int shems_wide_critic_grad_ex(const shems_ddpg *d, int32_t l1, int32_t l2, const
     const WWs w = wws(d->ws, l1, l2);
     WPrep p{*ring, ring_len, excl_pos, excl_count, seed, tick, d->batch, d->s_min, d->s_max, w};
     hipLaunchKernelGGL(k_wprep, dim3(1), dim3(WBP), 0, st, p);
-    // a' = actor_target(s'), q' = critic_target([s'; a'])  (DDPG.jl:131-132)
-    if (int rc = net_forward(st, wnet(d->actor_t, WSIN, l1, l2, WAIN), w.XS2, WBP, w.T1, w.T2, w.PT)) return rc;
-    hipLaunchKernelGGL(k_wtanh_cat, dim3(1), dim3(WBP), 0, st, w.PT, (float *)nullptr, w.XC2, d->batch);
-    if (int rc = net_forward(st, wnet(d->critic_t, WCIN, l1, l2, 1), w.XC2, WBP, w.T1, w.T2, w.Q2)) return rc;
-    // q = critic([s; a]); loss_crit = mse(q, y) and its pullback (DDPG.jl:133-135)
+    // Three forward passes need only the minibatch: a' = actor_target(s') (DDPG.jl:131), q = critic([s; a]) (:134) and a_pi = actor(s)
+    // (:138; the actor does not change before shems_wide_actor_apply_pub) -- launched together, layer by layer.
     const WNet c = wnet(d->critic, WCIN, l1, l2, 1);
-    if (int rc = net_forward(st, c, w.XC, WBP, w.H1c, w.H2c, w.Q)) return rc;
+    const Fwd ft = fwd_of(wnet(d->actor_t, WSIN, l1, l2, WAIN), w.XS2, w.T1, w.T2, w.PT), fc = fwd_of(c, w.XC, w.H1c, w.H2c, w.Q),
+              fa = fwd_of(wnet(d->actor, WSIN, l1, l2, WAIN), w.XS, w.H1a, w.H2a, w.PA);
+    if (int rc = gemm_multi(st, {ft.l1, fc.l1, fa.l1})) return rc;
+    if (int rc = gemm_multi(st, {ft.l2, fc.l2, fa.l2})) return rc;
+    if (int rc = gemm_multi(st, {ft.l3, fc.l3, fa.l3})) return rc;
+    hipLaunchKernelGGL(k_wtanh_cat, dim3(2), dim3(WBP), 0, st, w.PT, (float *)nullptr, w.XC2, w.PA, w.API, w.XQ, d->batch);
+    // q' = critic_target([s'; a'])  (DDPG.jl:132); T1 / T2 are free again
+    if (int rc = net_forward(st, wnet(d->critic_t, WCIN, l1, l2, 1), w.XC2, WBP, w.T1, w.T2, w.Q2)) return rc;
+    // loss_crit = mse(q, y) and its pullback (DDPG.jl:133-135)
     hipLaunchKernelGGL(k_wloss, dim3(1), dim3(WBP), 0, st, w, d->gamma, d->batch, d->losses);
-    return net_backward(st, c, w.XC, w.H1c, w.H2c, w.DQ, d->grad_critic, w.G1, w.G2, nullptr);
+    return net_backward(st, c, w.XC, w.H1c, w.H2c, w.DQ, d->grad_critic, w.G1, w.G2, nullptr, w.ONES);
 }
 
 int shems_wide_actor_grad(const shems_ddpg *d, int32_t l1, int32_t l2, void *stream)
@@ -466,14 +625,13 @@ int shems_wide_actor_grad(const shems_ddpg *d, int32_t l1, int32_t l2, void *str
     if (int rc = check_wide(d, l1, l2, "shems_wide_actor_grad")) return rc;
     hipStream_t st = (hipStream_t)stream;
     const WWs w = wws(d->ws, l1, l2);
-    // loss_act = -mean(critic([s; actor(s)])) through the critic as it stands now (already updated, DDPG.jl:137-140)
+    // loss_act = -mean(critic([s; actor(s)])) through the critic as it stands now (already updated, DDPG.jl:137-140); a_pi = actor(s) and
+    // the actor's hidden layers were laid down by shems_wide_critic_grad_ex
     const WNet a = wnet(d->actor, WSIN, l1, l2, WAIN), c = wnet(d->critic, WCIN, l1, l2, 1);
-    if (int rc = net_forward(st, a, w.XS, WBP, w.H1a, w.H2a, w.PA)) return rc;
-    hipLaunchKernelGGL(k_wtanh_cat, dim3(1), dim3(WBP), 0, st, w.PA, w.API, w.XQ, d->batch);
     if (int rc = net_forward(st, c, w.XQ, WBP, w.H1q, w.H2q, w.Q)) return rc;
-    if (int rc = net_backward(st, c, w.XQ, w.H1q, w.H2q, w.DQA, nullptr, w.G1, w.G2, w.DA)) return rc;
+    if (int rc = net_backward(st, c, w.XQ, w.H1q, w.H2q, w.DQA, nullptr, w.G1, w.G2, w.DA, w.ONES)) return rc;
     hipLaunchKernelGGL(k_wactor_head, dim3(1), dim3(WBP), 0, st, w, d->batch, d->losses);
-    return net_backward(st, a, w.XS, w.H1a, w.H2a, w.D3, d->grad_actor, w.G1, w.G2, nullptr);
+    return net_backward(st, a, w.XS, w.H1a, w.H2a, w.D3, d->grad_actor, w.G1, w.G2, nullptr, w.ONES);
 }
 
 int shems_wide_critic_apply(const shems_ddpg *d, int32_t l1, int32_t l2, double eta, double bp1, double bp2, double grad_scale, void *stream)
