@@ -24,7 +24,7 @@ const LIB = get(ENV, "SHEMS_HIP_LIB", joinpath(@__DIR__, "..", "master-thesis-de
 const HIP = "libamdhip64"
 
 const STATE_SIZE, ACTION_SIZE = 9, 2                            # length(env.state), length(env.a) (input.jl:180-181)
-const L1, L2 = 250, 500                                         # the tuned architecture (input09_08_on_01-09_eval.jl:66); see `wide` below
+const L1, L2 = 250, 500                                         # the tuned architecture (input09_08_on_01-09_eval.jl:66); (300, 600): the shems_wide_* entry points (INTEGRATION.md)
 const N_ACTOR, N_CRITIC = 129002, 129001                        # SHEMS_ACTOR_PARAMS / SHEMS_CRITIC_PARAMS
 const BATCH_SIZE, MEM_SIZE, EP_LENGTH = 120, 24000, 72          # input09_08_on_01-09_eval.jl:64-91
 
