@@ -18,7 +18,7 @@
 // ADAM + soft target update are shems_ddpg.hip's sweep (adam_soft_sweep: the same arithmetic on any parameter count).
 //
 // This path is about running the grid point, not about the roofline: sampler + 24 launches per replay() (0.22 ms at (300, 600)), a
-// vector step of 65 536 envs 0.36 ms (68 TFLOP/s).  The headline configuration never comes here.
+// vector step of 65 536 envs 0.28 ms (87 TFLOP/s).  The headline configuration never comes here.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -123,10 +123,14 @@ __global__ __launch_bounds__(256) void k_wgemm(GemmArgs G)
 // partial per (row, output); relu(layer 2), 157 MB at 65 536 envs x 600, is never written or read back, and the N = 2 product, which
 // a 64-wide tile pads 32-fold, disappears.  k_act_tail adds the partials in index order.
 constexpr int BT = 128, BLD = BT + 4, BR = BT * GK / 256;
-template <bool HEAD>
+// V4: both operands are contiguous along the index that runs across a stage (A along k, B along j), 16-byte aligned, with row strides, K
+// and N multiples of 4 (the host checks): a stage is staged with two 16-byte loads per operand and thread instead of eight predicated
+// 4-byte ones -- a quarter of the load / address / bounds instructions next to the MFMAs.
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+template <bool HEAD, bool V4>
 __global__ __launch_bounds__(256) void k_wgemm128(GemmArgs G)
 {
-    __shared__ float As[2][GK][BLD], Bs[2][GK][BLD];
+    __shared__ __attribute__((aligned(16))) float As[2][GK][BLD], Bs[2][GK][BLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.x * BT, n0 = (int64_t)blockIdx.y * BT;
@@ -139,18 +143,42 @@ __global__ __launch_bounds__(256) void k_wgemm128(GemmArgs G)
         bj[r] = b_jfast ? e & (BT - 1) : e >> GKB;  bk[r] = b_jfast ? e >> 7 : e & (GK - 1);
     }
     float ra[BR], rb[BR];
+    wf32x4 va[2], vb[2];
     auto fetch = [&](int k0) {
+        if constexpr (V4) {
+            // quad f = tid + 256 r: A row f >> 2, k = 4 (f & 3) ..; B row k = f >> 5, j = 4 (f & 31) ..
 #pragma unroll
-        for (int r = 0; r < BR; ++r) {
-            const int64_t i = m0 + ai[r], j = n0 + bj[r];
-            const int ka = k0 + ak[r], kb = k0 + bk[r];
-            ra[r] = (i < G.M && ka < G.K) ? G.A[i * G.sai + ka * G.sak] : 0.0f;
-            rb[r] = (j < G.N && kb < G.K) ? G.B[kb * G.sbk + j * G.sbj] : 0.0f;
+            for (int r = 0; r < 2; ++r) {
+                const int f = tid + 256 * r;
+                const int64_t i = m0 + (f >> 2), j = n0 + 4 * (f & 31);
+                const int ka = k0 + 4 * (f & 3), kb = k0 + (f >> 5);
+                const wf32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                va[r] = (i < G.M && ka < G.K) ? *reinterpret_cast<const wf32x4 *>(G.A + i * G.sai + ka) : z;
+                vb[r] = (j < G.N && kb < G.K) ? *reinterpret_cast<const wf32x4 *>(G.B + kb * G.sbk + j) : z;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                const int64_t i = m0 + ai[r], j = n0 + bj[r];
+                const int ka = k0 + ak[r], kb = k0 + bk[r];
+                ra[r] = (i < G.M && ka < G.K) ? G.A[i * G.sai + ka * G.sak] : 0.0f;
+                rb[r] = (j < G.N && kb < G.K) ? G.B[kb * G.sbk + j * G.sbj] : 0.0f;
+            }
         }
     };
     auto stash = [&](int buf) {
+        if constexpr (V4) {
 #pragma unroll
-        for (int r = 0; r < BR; ++r) { As[buf][ak[r]][ai[r]] = ra[r]; Bs[buf][bk[r]][bj[r]] = rb[r]; }
+            for (int r = 0; r < 2; ++r) {
+                const int f = tid + 256 * r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) As[buf][4 * (f & 3) + c][f >> 2] = va[r][c];
+                *reinterpret_cast<wf32x4 *>(&Bs[buf][f >> 5][4 * (f & 31)]) = vb[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < BR; ++r) { As[buf][ak[r]][ai[r]] = ra[r]; Bs[buf][bk[r]][bj[r]] = rb[r]; }
+        }
     };
     wf32x16 acc[2][2];
 #pragma unroll
@@ -555,7 +583,9 @@ int wide_actor_pre(const float *actor, const float *s_min, const float *s_max, i
     g.head_w = n.W3; g.head_out = d_part; g.head_n = WAIN;
     const unsigned ty = (unsigned)((l2 + BT - 1) / BT);
     *n_partials = 2 * (int)ty;
-    hipLaunchKernelGGL(k_wgemm128<true>, dim3((unsigned)((m + BT - 1) / BT), ty), dim3(256), 0, st, g);
+    const bool v4 = (l1 % 4) == 0 && (l2 % 4) == 0 && ((uintptr_t)H1 & 15) == 0 && ((uintptr_t)n.W2 & 15) == 0;     // (300, 600): yes
+    if (v4) hipLaunchKernelGGL((k_wgemm128<true, true>), dim3((unsigned)((m + BT - 1) / BT), ty), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_wgemm128<true, false>), dim3((unsigned)((m + BT - 1) / BT), ty), dim3(256), 0, st, g);
     return hip_ok(hipGetLastError(), "k_wgemm128 launch");
 }
 // floats of d_ws: normalised observations, layer 1, and the partial sums of the output layer
