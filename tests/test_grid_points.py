@@ -99,6 +99,8 @@ def test_job_ids_of_smaller_networks_are_accepted():
     assert D.is_wide((300, 600)) and not D.is_wide((250, 500)) and not D.is_wide((200, 400)) and D.is_wide((250, 501))
     for code in range(81):                                                               # every code of the tuned template's grid is accepted
         M._check_supported(M.config_from_env({"JOB_ID": "117098%02d" % code, "TASK_ID": "1", "GPU_ID": "0"}))
+    for code in range(27):                                                               # and every code of input.jl's
+        M._check_supported(M.config_from_env({"JOB_ID": "117098%02d" % code, "TASK_ID": "1", "GPU_ID": "0", "SHEMS_INPUT_TEMPLATE": "input"}))
 
 
 @pytest.mark.gpu

@@ -373,3 +373,21 @@ def test_entry_script_on_the_300_600_grid_point(tmp_path):
     assert a.size == 9 * 300 + 300 + 300 * 600 + 600 + 600 * 2 + 2 and np.isfinite(a).all() and np.count_nonzero(a) > 180000
     rows = list(csv.reader(open(tmp_path / written[0])))
     assert len(rows) == 1 + 1439 and np.isfinite(np.array(rows[1:], float)).all()
+
+
+def test_entry_script_input_template_300_600_ou_noise_batch_200(tmp_path):
+    """The untuned template (input.jl:58-100) at its heaviest code: (300, 600), BATCH_SIZE 200 (two sub-batches of 100, one ADAM step),
+    MEM_SIZE 30 000, OU noise -- the wide path with every host-side branch that differs from the tuned run."""
+    pytest.importorskip("torch")
+    M = importlib.import_module(U.PKG_NAME + ".main")
+    env = {"JOB_ID": "1179802", "TASK_ID": "1", "GPU_ID": "0", "SHEMS_INPUT_TEMPLATE": "input", "SHEMS_NUM_EP": "2", "SHEMS_NUM_SEEDS": "1",
+           "SHEMS_NUM_ENVS": "64", "SHEMS_SYNTHETIC_DATA": "1"}
+    cwd0 = os.getcwd()
+    try:
+        cfg, written = M.main(env, cwd=str(tmp_path), log=lambda *_: None)
+    finally:
+        os.chdir(cwd0)
+    assert (cfg.L1, cfg.L2, cfg.BATCH_SIZE, cfg.MEM_SIZE, cfg.noise_type) == (300, 600, 200, 30000, "ou")
+    assert len(written) == 2 and all("_300_600_" in w for w in written)
+    rows = list(csv.reader(open(tmp_path / written[0])))
+    assert len(rows) > 100 and np.isfinite(np.array(rows[1:], float)).all()
