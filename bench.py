@@ -375,9 +375,17 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    json_fd = None
+    if world > 1:
+        # RCCL prints its version banner to STDOUT at communicator creation (seen on this image: "RCCL version : ...", "Librccl path : ...").
+        # The contract is ONE JSON line on stdout, so everything any library writes to descriptor 1 goes to stderr for the life of the
+        # process, and rank 0 writes its line to the saved descriptor.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+    import torch
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -527,7 +535,10 @@ def main():
             out["updates_per_sec"] = args.updates * args.steps / dt      # complete replay() equivalents (B = 120)
         if mode == "group":
             out["updates_per_sec"] = args.learners * world * args.steps / dt   # one replay() per learner per vector step
-        print(json.dumps(out), flush=True)
+        if json_fd is None:
+            print(json.dumps(out), flush=True)
+        else:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

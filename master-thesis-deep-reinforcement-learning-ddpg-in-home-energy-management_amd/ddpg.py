@@ -284,8 +284,11 @@ class Agent:
         self.bp_critic = [0.9, 0.999]
         self.updates = 0
         self.sync = GradSync(None)                 # replicas exchange gradients through this (RCCL)
-        self.dp_overlap = True                     # data parallel: the critic's gradient all-reduce runs asynchronously under the actor's E
-                                                   # products (shems_ddpg_actor_prepare); False = everything in program order (same bits)
+        self.dp_overlap = False                    # data parallel: True = the critic's gradient all-reduce runs asynchronously under the actor's E
+                                                   # products (shems_ddpg_actor_prepare); False = everything in program order (same bits).
+                                                   # Off by default since it was measured on real RCCL streams (one-rank group,
+                                                   # tools/dp_one_rank_steps.py): the asynchronous form costs 20 us per step MORE than
+                                                   # program order (207 against 187 us at 65 536 envs) to hide 4 us of E products
         self.fused = True                          # single replica: replay() = ONE call, shems_ddpg_update (5 launches, ADAM inside the
                                                    # gradient launches); False = the split calls the data-parallel path uses (same bits)
 
@@ -739,8 +742,8 @@ class TrainWorkload:
         if dist is not None:
             self.agent.enable_data_parallel(dist)
             import os
-            if os.environ.get("SHEMS_DP_OVERLAP") == "0":        # A/B knob of the rehearsal test: collectives in program order
-                self.agent.dp_overlap = False
+            if os.environ.get("SHEMS_DP_OVERLAP") in ("0", "1"):   # A/B knob: "1" = the critic's all-reduce asynchronous, under the actor's E products
+                self.agent.dp_overlap = os.environ["SHEMS_DP_OVERLAP"] == "1"
         self.ring = ReplayRing(self.mem_size)
         self.agent.populate_memory(self.env, self.ring, seed=self.env_seed)          # MAIN:28
         self.agent.min_max_buffer(self.ring, self.mem_size, seed=self.env_seed)      # MAIN:30

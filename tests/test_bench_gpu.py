@@ -97,6 +97,7 @@ def test_bench_starts_its_own_ranks_without_torchrun():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    assert [l for l in out.stdout.splitlines() if l.strip()] == lines, "nothing but the JSON line on stdout (library banners go to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["envs_per_gpu"] == 8192 and d["cpu_baseline"] is None and d["value"] > 0
     assert d["updates_per_sec"] > 0 and d["roofline"]["frac"] == d["roofline"]["frac"]      # (present; its sign is noise under gloo, see below)
@@ -106,7 +107,11 @@ def test_bench_starts_its_own_ranks_without_torchrun():
 def test_async_gradient_exchange_gives_the_same_bytes():
     """Data parallel: the critic's gradient all-reduce issued asynchronously with the actor's E products running under it
     (shems_ddpg_actor_prepare) against everything in program order: the learner must end up bit-identical (2-rank rehearsal on one
-    device; the collective's timing itself cannot be measured on a one-GPU box)."""
+    device; gloo's collectives are host-synchronous -- the stream ordering on real RCCL is test_rccl_stream_ordering_on_a_one_rank_group).  Program
+    order is the default since the asynchronous form measured slower (tools/dp_one_rank_steps.py)."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--envs", "4096", "--prewarm-s", "0"],
+             env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
+    assert d["dp_overlap"] is False
     out = []
     for knob in ("1", "0"):
         # --prewarm-s 0: the pre-warm runs for a wall-clock time, i.e. a different number of updates from run to run
@@ -115,3 +120,14 @@ def test_async_gradient_exchange_gives_the_same_bytes():
         assert d["n_gpus"] == 2 and d["dp_overlap"] is (knob == "1")
         out.append(d["learner_crc32"])
     assert out[0] == out[1]
+
+
+def test_rccl_stream_ordering_on_a_one_rank_group():
+    """The data-parallel replay() on real RCCL streams (a one-rank NCCL group: RCCL refuses two ranks on one device): asynchronous critic
+    all-reduce with the actor's E products under it + wait(), everything in program order, and no collective at all must leave
+    bit-identical learners (tests/dp_rccl_one_rank.py)."""
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "tests", "dp_rccl_one_rank.py")], cwd=U.ROOT, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl"
+    assert d["async_overlap"] == d["in_order"] == d["no_collective"], d
