@@ -64,7 +64,7 @@ def inference_many(env, actors, s_min, s_max, num_steps=None, hidden=None):
 
 def _track(env, actor, s_min, s_max, stride, track, num_steps, which, keep=None, hidden=None):
     import torch
-    from .ddpg import ActParams, _declare, is_wide
+    from .ddpg import ActParams, _declare
     _declare()
     n = env.n
     num_steps = env.maxsteps if num_steps is None else int(num_steps)
