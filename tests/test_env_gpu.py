@@ -276,6 +276,41 @@ def test_full_size_65536_envs_properties_and_sampled_parity():
     env.close()
 
 
+def test_four_million_envs_sampled_parity():
+    """64 x BASELINE config 3: 4 194 304 households in one launch (the size at which the env-only kernel reaches its HBM-bound regime,
+    profiles/r01_env_scaling.txt).  Index bookkeeping for every env, oracle parity bit for bit on a sample spread over the whole range
+    (first, last and random envs), the per-workgroup reward sums."""
+    torch = pytest.importorskip("torch")
+    S = _S()
+    n = 1 << 22
+    tab = S.tables.synthetic_table("train", 98)
+    cfg, prof = _profile_cfg(S, 98, 0, tab.shape[0])
+    env = S.ShemsBatch(n, 72, [tab], [cfg]).use_torch_stream()
+    env.reset_(321, episode=2)
+    idx_start = env.idx.copy()
+    st0 = env.state.copy()
+    assert ((idx_start >= 1) & (idx_start <= tab.shape[0] - 72)).all()
+    assert len(np.unique(idx_start)) > 2000 and st0[:, 0].std() > 1.0                # the draws differ from env to env (the start resolver, LU1:227-246, admits ~2 600 of the 4 248 rows)
+    sample = np.unique(np.concatenate([[0, 1, n - 2, n - 1], np.random.default_rng(1).choice(n, 1020, replace=False)]))
+    ref = oracle_c.Batch(len(sample), 72, tab, prof)
+    ref.set_state(st0[sample], idx_start[sample])
+    act = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    rew = torch.empty(n, dtype=torch.float64, device="cuda")
+    blk = torch.empty((n + 255) // 256, dtype=torch.float64, device="cuda")
+    for t in range(5):
+        a = ((philox_np.random_actions(9, t, n).astype(np.float64) + 1.0) * 0.5).astype(np.float32)
+        act.copy_(torch.from_numpy(a))
+        env.step_dev(act, 0, rewards=rew, block_reward=blk)
+        r = rew.cpu().numpy()
+        np.testing.assert_allclose(blk.cpu().numpy(), r.reshape(-1, 256).sum(1), rtol=1e-12, atol=1e-12)
+        _, r_ref, o_ref, _ = ref.step(a[sample], 0)
+        assert (U.bits64(r[sample]) == U.bits64(r_ref)).all()
+    env.check_error()
+    assert (env.idx == idx_start + 5).all() and (env.step == 5).all()
+    assert (U.bits32(env.state[sample]) == U.bits32(ref.state())).all()
+    env.close()
+
+
 def test_real_series_mixed_profiles_reset_and_steps_bit_exact():
     """BASELINE config 5 on the REAL exogenous series (tables.real_series: Chargers 01/03/04/05/08/09 train from the reference's MPC
     result files, synthetic for 02/06/07/98): seeded reset (Philox draws + the LU1:227-246 extension loop on real transaction
