@@ -125,6 +125,47 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps):
     env.close()
 
 
+def test_fused_step_at_four_times_config_3_ragged():
+    """262 144 + 37 households (4 x BASELINE config 3, ragged against every tile size): the fused kernel's grid arithmetic beyond the
+    benchmarked size.  Actions against the float64 evaluation and transitions against the env oracle on a sample spread over the whole
+    range (first, last, the ragged tail, random envs); index bookkeeping for every env."""
+    torch, S, D = _mods()
+    n = 262144 + 37
+    tab = S.tables.synthetic_table("train", 98)
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    ag = D.Agent(seed=5)
+    p = D.init_params(5, 9, 2, 0)
+    p[128000:129000] *= 60.0
+    ag.set_params(actor=p)
+    env.reset_(9, episode=3)
+    st0, idx0 = env.state, env.idx.copy()
+    lo, hi = st0.min(0), st0.max(0)
+    ag.set_norm(lo, hi)
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, n - 38, n - 37, n - 2, n - 1], np.random.default_rng(2).choice(n, 1500, replace=False)]))
+    ref = oracle_c.Batch(len(sample), 72, tab, oracle_c.profile(98))
+    ref.set_state(st0[sample], idx0[sample])
+    a_out = torch.empty((n, 2), dtype=torch.float32, device="cuda")
+    rew = torch.empty(n, dtype=torch.float64, device="cuda")
+    for t in range(2):
+        pre = env.state[sample]
+        ag.act_step(env, train=True, tick=t, a_out=a_out, rewards=rew)
+        env.check_error()
+        a = a_out.cpu().numpy()
+        assert np.isfinite(a).all() and a.min() >= -1 and a.max() <= 1
+        # act() of the sampled envs: the float64 forward + the noise rows of THOSE env ids (the stream is indexed by env)
+        det = DO.actor_forward(p, DO.normalize(pre, lo, hi), dtype=np.float64)
+        want = np.clip(det + (0.0 + 0.1 * DO.gauss_noise(5, t, n)[sample].astype(np.float64)), -1.0, 1.0)
+        rc, r_ref, o_ref, _ = ref.step(oracle_c.scale_action(a[sample]), 0)
+        assert rc == 0 and (U.bits64(rew.cpu().numpy()[sample]) == U.bits64(r_ref)).all()
+        assert (U.bits32(env.state[sample]) == U.bits32(o_ref)).all()
+        assert np.abs(a[sample] - want).max() < 5e-6 + ATOL
+    # deterministic actions on the sample against the float64 evaluation (no noise stream to index)
+    got = ag.act(torch.from_numpy(st0[sample]).cuda(), train=False).cpu().numpy()
+    assert np.abs(got - DO.act(p, st0[sample], lo, hi, False, dtype=np.float64)).max() < ATOL
+    assert (env.idx == idx0 + 2).all() and (env.step == 2).all()
+    env.close()
+
+
 def test_ou_and_epsilon_noise_branches():
     """noise_type "ou" (persistent per-env OUNoise.X) and "en" (epsilon-greedy uniform actions), DDPG.jl:49-72, 157-170."""
     torch, S, D = _mods()
