@@ -50,7 +50,12 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env", "group"])
     ap.add_argument("--learners", type=int, default=32, help="group mode: independent learners per GPU (the thesis protocol of many seeds x chargers, SURVEY 8(f) rank 4); --envs must be learners x a multiple of 128")
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
-    ap.add_argument("--overlap", action="store_true", help="train mode: run replay() on a second stream, concurrently with the act/step kernel (see DESIGN.md 5b; not the headline configuration)")
+    ap.add_argument("--overlap", nargs="?", const="pipelined", default=None, choices=["pipelined", "exact"],
+                    help="train mode: run replay() on a second stream under the act/step launch (DESIGN.md 5b; not the headline configuration).  "
+                         "pipelined: replay(t) samples the ring as it stood before step t's inserts; exact: the inserting envs are stepped first and "
+                         "replay(t) runs under the rest of the batch -- the ordered loop's bytes")
+    ap.add_argument("--loop", default=None, choices=["native", "host"], help="train mode: native = k vector steps enqueued by one shems_train_steps call "
+                    "(default for a single replica on the tuned kernels), host = one foreign call per launch from Python")
     ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
     ap.add_argument("--scaled-replay", action="store_true", help="train mode: SURVEY 8(d)'s optional replay mode: ring capacity 72 x envs, every env's transition inserted each step (177 B per env-step) instead of MEM_SIZE = 24 000 with a rotating window of 333 envs")
     ap.add_argument("--hidden", default="250x500", help="train mode: Dense widths L1xL2 of actor and critic; the headline is the tuned 250x500, 300x600 is the reference grids' wider point (layer-by-layer path, csrc/shems_wide.hip), smaller ones run zero-padded")
@@ -421,10 +426,19 @@ def main():
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
-        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap, mixed=args.mixed, scaled_replay=args.scaled_replay,
+        wl = train_mod.TrainWorkload(S, torch, args.envs, seed=1231 + rank, updates=args.updates, dist=dist, overlap=args.overlap or False, loop=args.loop, mixed=args.mixed, scaled_replay=args.scaled_replay,
                                      hidden=tuple(int(x) for x in args.hidden.lower().split("x")))
     else:
         wl = EnvWorkload(S, torch, args.envs, seed=123 + rank)
+
+    def run_steps(k):
+        # the train workload enqueues k vector steps with ONE foreign call (shems_train_steps: the hour loop of episode! in native code);
+        # the other workloads are one call per launch
+        many = getattr(wl, "steps", None)
+        if many is not None:
+            return many(k)
+        for _ in range(k):
+            wl.step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -439,8 +453,7 @@ def main():
     if args.prewarm_s > 0:
         tp = time.perf_counter()
         while True:
-            for _ in range(50):
-                wl.step()
+            run_steps(50)
             prewarm_steps += 50
             torch.cuda.synchronize()
             more = time.perf_counter() - tp < args.prewarm_s
@@ -450,12 +463,10 @@ def main():
                 more = bool(flag.item() > 0.5)
             if not more:
                 break
-    for _ in range(args.warmup):
-        wl.step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     wl.finish()

@@ -235,6 +235,12 @@ int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64
 int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
                        float *d_rewards_f32, double *d_block_reward, double *d_returns_acc,
                        const shems_replay *ring, const shems_ring_window *window, void *stream);
+/* The same fused step for the envs [env_lo, env_lo + env_count) of the view only (the other envs are not touched).  Every env
+ * draws its noise from (seed, tick, ITS index in the view) and the ring window is still defined on the whole batch, so stepping a
+ * batch range by range -- in any order, on any streams -- leaves the same bytes as one shems_act_step_dev over the view.  The training
+ * loop's order-exact pipelined mode steps the window's envs first with it (shems_train_steps). */
+int shems_act_step_range_dev(const shems_view *v, const shems_act_params *p, int64_t env_lo, int64_t env_count, float *d_rewards_f32,
+                             const shems_replay *ring, const shems_ring_window *window, void *stream);
 /* scale_action (DDPG.jl:178-184) on device: d_a [n][2] in [-1,1] -> d_out [n][2] SoC targets in [0,1]. */
 int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stream);
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
@@ -322,6 +328,53 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
                                float *d_publish, void *stream);
 /* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
 int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
+/* ------------------------------------------------- the training loop -- */
+/* The hour loop of episode! (DDPG.jl:195-234) for every env of a view, `k` vector steps enqueued by ONE call:
+ *   per step t:  [t > 0 and t % ep_len == 0: episode += 1, reset!(env) with (env_seed, episode)  -- DDPG.jl:189-193]
+ *                a = act(normalize(s)); step!(env, s, scale_action(a)); remember(...)               -- shems_act_step_dev
+ *                updates_per_step x replay()                                                        -- shems_ddpg_update
+ * exactly the calls a host loop over shems_act_step_dev / shems_ddpg_update would make, with the same arguments (the noise tick is
+ * t, the ring window rotates by `window` envs per step, the sampler tick is the running update count, ADAM's beta powers advance in
+ * Float64 after every update), so a run of the loop leaves the same bytes as that host loop.  What it removes is the host time per
+ * launch: a Python / Julia caller pays several microseconds per foreign call, which at <= 8 192 envs is comparable to the kernels.
+ *
+ * mode SHEMS_LOOP_ORDERED   : program order on `stream` -- the reference's order.
+ * mode SHEMS_LOOP_PIPELINED : replay(t) runs on `stream2` while the fused act/step launch of step t runs on `stream`; act(t) reads the
+ *                             actor published by replay(t - 1) (actor_pub[t & 1], written by the ADAM sweep), exactly the actor the
+ *                             ordered loop would use; the one deviation is that replay(t) samples the ring as it stood BEFORE step
+ *                             t's inserts (the window being written is excluded, shems_ddpg_critic_grad_ex).
+ * mode SHEMS_LOOP_PIPELINED_EXACT : the envs of step t's ring window are stepped FIRST (their own launch on `stream`), replay(t) then
+ *                             runs on `stream2` and samples the ring WITH those inserts while the rest of the batch is stepped on
+ *                             `stream`: the same bytes as SHEMS_LOOP_ORDERED.
+ * The struct is caller-owned state: fields marked in/out are advanced by the call.  `sync` holds the loop's events and is created on
+ * first use of a pipelined mode; release it with shems_train_loop_release (it does not touch the device buffers). */
+enum { SHEMS_LOOP_ORDERED = 0, SHEMS_LOOP_PIPELINED = 1, SHEMS_LOOP_PIPELINED_EXACT = 2 };
+typedef struct shems_train_loop {
+    shems_view       view;
+    shems_act_params act;            /* .tick is overwritten with t; .actor = the learner's actor (ddpg.actor)                  */
+    shems_ddpg       ddpg;
+    shems_replay     ring;
+    float   *rewards_f32;            /* dev [n] or NULL: Float32(reward) of the last step                                        */
+    float   *actor_pub[2];           /* pipelined modes: two dev [129002] copies of the actor, both equal to ddpg.actor on entry of the first call */
+    int64_t  window;                 /* envs whose transitions enter the ring per vector step (<= n, <= ring.capacity)            */
+    int64_t  ring_pushed;            /* in/out: transitions pushed so far (push position = ring_pushed mod capacity)              */
+    int64_t  t;                      /* in/out: vector steps done so far                                                          */
+    int64_t  updates;                /* in/out: replay() calls done so far (the sampler's tick)                                   */
+    uint64_t env_seed;               /* reset!(env) key (shems_reset_seeded_dev)                                                  */
+    uint64_t sample_seed;            /* getData key (shems_ddpg_update's seed)                                                    */
+    uint32_t episode;                /* in/out                                                                                    */
+    int32_t  ep_len;                 /* steps per episode (EP_LENGTH["train"] = 72)                                              */
+    int32_t  updates_per_step;       /* 0 = no learning                                                                           */
+    int32_t  mode;                   /* SHEMS_LOOP_*                                                                              */
+    double   eta_crit, bp_crit[2];   /* in/out: ADAM(eta_crit) and its beta^t powers for the NEXT critic step                     */
+    double   eta_act, bp_act[2];     /* in/out: same for the actor                                                                */
+    void    *sync;                   /* opaque, NULL on first use                                                                 */
+} shems_train_loop;
+int shems_train_steps(shems_train_loop *loop, int64_t k, void *stream, void *stream2);
+/* Pipelined modes: make `stream` wait for everything the loop has in flight on stream2 (the caller then synchronises `stream`). */
+int shems_train_loop_join(shems_train_loop *loop, void *stream, void *stream2);
+int shems_train_loop_release(shems_train_loop *loop);
+
 /* ------------------------------------------------- learner groups -- */
 /* The thesis protocol trains many INDEPENDENT learners (40 seeds x 10 charger profiles, one OS process and one
  * batch-1 GPU stream each: run scripts + DDPG_reinforce_charger_v1.jl:10-47).  A learner

@@ -24,6 +24,7 @@ UNITS = [
     ("shems_ddpg.hip", []),
     ("shems_track.hip", ["-ffp-contract=off"]),
     ("shems_wide.hip", []),
+    ("shems_train.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(ROOT, "include")]

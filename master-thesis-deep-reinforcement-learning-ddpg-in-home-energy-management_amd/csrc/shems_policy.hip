@@ -95,6 +95,7 @@ struct ActArgs {
     shems_act_params p;
     const float *obs;          // [m][9]
     int64_t m;
+    int64_t m0;                // first env of this launch (0 = the whole batch): the launch covers envs [m0, m), tile t = envs m0 + t * BM ..
     float *a_out;              // [m][2] or null
     double *rewards;
     float *rewards_f32;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // tiles (= a few whole learners) instead of a slice of every learner.
     int64_t bid = blockIdx.x;
     if (A.gcount > 1 && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int64_t env0 = bid * BM;
+    const int64_t env0 = A.m0 + bid * BM;
     const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
     const int64_t goff = learner * A.gstride;
     const float *__restrict__ P = gsh(A.p.actor, goff);
@@ -1034,7 +1035,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (b < full) { tile = (int64_t)(b >> 4) * 8 + (b & 7); half = (b >> 3) & 1; }
         else { tile = (int64_t)(T >> 3) * 8 + ((b - full) >> 1); half = (b - full) & 1; }
     }
-    const int64_t env0 = tile * BM;
+    const int64_t env0 = A.m0 + tile * BM;
     const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
     const int64_t goff = learner * A.gstride;
     const float *__restrict__ P = gsh(A.p.actor, goff);
@@ -1344,7 +1345,7 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
     const int li = lane & 31, lh = lane >> 5;
     int64_t bid = blockIdx.x;
     if (A.gcount > 1 && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // a learner's tiles share an XCD
-    const int64_t env0 = bid * BM;
+    const int64_t env0 = A.m0 + bid * BM;
     const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
     const int64_t goff = learner * A.gstride;
     const float *__restrict__ P = gsh(A.p.actor, goff);
@@ -1609,7 +1610,7 @@ static int launch_act2(const ActArgs &a, hipStream_t st)
     static_assert(lds <= 80 * 1024, "k_act2: two workgroups must fit a CU's 160 KB");
     static std::atomic<uint64_t> optin{0};
     if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_act2), (int)lds, "hipFuncSetAttribute(k_act2)")) return rc;
-    hipLaunchKernelGGL(k_act2, dim3((unsigned)((a.m + 63) / 64)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_act2, dim3((unsigned)((a.m - a.m0 + 63) / 64)), dim3(256), lds, st, a);
     return hip_ok(hipGetLastError(), "k_act2 launch");
 }
 
@@ -1629,7 +1630,7 @@ static int launch_act(const ActArgs &a, hipStream_t st)
     static_assert(act_lds_bytes<TM, NW, RD>() <= 160 * 1024, "k_act: LDS image exceeds 160 KB");
     static std::atomic<uint64_t> optin{0};                   // per device: see lds_optin
     if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_act<TM, NW, RD>), (int)lds, "hipFuncSetAttribute(k_act)")) return rc;
-    const unsigned grid = (unsigned)((a.m + BM - 1) / BM);
+    const unsigned grid = (unsigned)((a.m - a.m0 + BM - 1) / BM);
     hipLaunchKernelGGL((k_act<TM, NW, RD>), dim3(grid), dim3(64 * NW), lds, st, a);
     return hip_ok(hipGetLastError(), "k_act launch");
 }
@@ -1673,7 +1674,7 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
     static_assert(lds <= 160 * 1024, "k_actg: LDS image exceeds 160 KB");
     static std::atomic<uint64_t> optin{0};                   // per device: see lds_optin
     if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_actg<TM, NW, NS, RD>), (int)lds, "hipFuncSetAttribute(k_actg)")) return rc;
-    const int64_t tiles = (a.m + BM - 1) / BM;
+    const int64_t tiles = (a.m - a.m0 + BM - 1) / BM;
     ActSplit x = {nullptr};
     if (NS == 2) {
         if (tiles > kSplitMaxTiles) return set_error(SHEMS_ERR_ARG, "k_actg: %lld env tiles exceed the split form's scratch", (long long)tiles);
@@ -1708,15 +1709,16 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
 #else
     const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
-    if (form4 == 2 && form < 0 && a.m > 8192 && a.gcount <= 1) return launch_act2(a, st);
+    const int64_t cnt = a.m - a.m0;                           // envs of this launch (a range launch: every form writes the same bytes)
+    if (form4 == 2 && form < 0 && cnt > 8192 && a.gcount <= 1) return launch_act2(a, st);
     if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
-    const int tm = pick_tm(a.m);
+    const int tm = pick_tm(cnt);
     if (tm == 4) return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
     if (tm == 2) return form == 0 || form4 == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
     if (form == 0) return launch_act<1, 4>(a, st);
     if (form == 2) return launch_act<1, 4, 2>(a, st);
     if (form == 3) return launch_act<1, 4, 3>(a, st);
-    if (form == 8 || (form != 9 && (a.m > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
+    if (form == 8 || (form != 9 && (cnt > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
     return launch_actg<1, 4, 2, 3>(a, st);
 }
 
@@ -1799,6 +1801,29 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
         if (window->offset < 0 || window->offset >= v->n_envs)
             return set_error(SHEMS_ERR_ARG, "shems_act_step_dev: ring window offset %lld outside the batch of %lld envs",
                              (long long)window->offset, (long long)v->n_envs);
+        a.ring = *ring; a.win = *window; a.use_ring = 1;
+    }
+    return dispatch_act(a, (hipStream_t)stream);
+}
+
+int shems_act_step_range_dev(const shems_view *v, const shems_act_params *p, int64_t env_lo, int64_t env_count, float *d_rewards_f32,
+                             const shems_replay *ring, const shems_ring_window *window, void *stream)
+{
+    if (int rc = check_act(p, "shems_act_step_range_dev")) return rc;
+    if (int rc = check_view(v, "shems_act_step_range_dev")) return rc;
+    if (env_lo < 0 || env_count <= 0 || env_lo + env_count > v->n_envs)
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_range_dev: envs [%lld, %lld + %lld) outside the batch of %lld", (long long)env_lo,
+                         (long long)env_lo, (long long)env_count, (long long)v->n_envs);
+    ActArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.v = *v; a.p = *p; a.obs = v->obs; a.m0 = env_lo; a.m = env_lo + env_count;
+    a.rewards_f32 = d_rewards_f32;
+    a.do_step = 1;
+    if (ring && window && window->count > 0) {
+        if (ring->capacity <= 0 || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_range_dev: incomplete replay ring");
+        if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0 || window->offset < 0 || window->offset >= v->n_envs)
+            return set_error(SHEMS_ERR_ARG, "shems_act_step_range_dev: ring window outside the ring or the batch");
         a.ring = *ring; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);

@@ -59,11 +59,30 @@ class RingWindow(C.Structure):         # shems_ring_window
     _fields_ = [("pos", C.c_int64), ("count", C.c_int64), ("offset", C.c_int64)]
 
 
+class TrainLoop(C.Structure):          # shems_train_loop: the hour loop of episode! enqueued natively (shems_train_steps)
+    _fields_ = [("view", _capi.View), ("act", ActParams), ("ddpg", DdpgArgs), ("ring", _capi.Replay),
+                ("rewards_f32", C.c_void_p), ("actor_pub", C.c_void_p * 2), ("window", C.c_int64), ("ring_pushed", C.c_int64),
+                ("t", C.c_int64), ("updates", C.c_int64), ("env_seed", C.c_uint64), ("sample_seed", C.c_uint64),
+                ("episode", C.c_uint32), ("ep_len", C.c_int32), ("updates_per_step", C.c_int32), ("mode", C.c_int32),
+                ("eta_crit", C.c_double), ("bp_crit", C.c_double * 2), ("eta_act", C.c_double), ("bp_act", C.c_double * 2),
+                ("sync", C.c_void_p)]
+
+
+LOOP_ORDERED, LOOP_PIPELINED, LOOP_PIPELINED_EXACT = 0, 1, 2
+
+
 def _declare():
     L = _capi.lib()
     if getattr(L, "_ddpg_declared", False):
         return L
     vp, i64 = C.c_void_p, C.c_int64
+    L.shems_train_steps.argtypes = [C.POINTER(TrainLoop), i64, vp, vp]
+    L.shems_train_loop_join.argtypes = [C.POINTER(TrainLoop), vp, vp]
+    L.shems_train_loop_release.argtypes = [C.POINTER(TrainLoop)]
+    L.shems_act_step_range_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), i64, i64, vp, C.POINTER(_capi.Replay),
+                                           C.POINTER(RingWindow), vp]
+    for fn in ("shems_train_steps", "shems_train_loop_join", "shems_train_loop_release", "shems_act_step_range_dev"):
+        getattr(L, fn).restype = C.c_int
     L.shems_actor_forward_dev.argtypes = [C.POINTER(ActParams), vp, i64, vp, vp]
     L.shems_actor_forward_dev.restype = C.c_int
     L.shems_act_step_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), vp, vp, vp, vp, vp,
@@ -722,8 +741,16 @@ class TrainWorkload:
     dtype = "f32"
     EP_LEN = EP_LENGTH_TRAIN
 
-    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False, scaled_replay=False, hidden=(L1, L2)):
+    def __init__(self, S, torch, n, seed, updates=1, dist=None, overlap=False, mixed=False, scaled_replay=False, hidden=(L1, L2), loop=None):
+        """overlap: False = the reference's order; True / "pipelined" = replay(t) under the fused launch of step t, sampling the ring as
+        it stood before step t's inserts; "exact" = the window's envs stepped first, replay(t) under the rest of the batch: the ordered
+        loop's bytes.  loop: "native" = the steps are enqueued by shems_train_steps (one foreign call for k steps),
+        "host" = one foreign call per launch from this class; None = native wherever the learner is a single replica on the tuned
+        kernels (data parallel replicas exchange gradients through torch.distributed between launches, wide networks take their own path)."""
         self.S, self.torch, self.n, self.updates = S, torch, int(n), int(updates)
+        self.overlap_mode = {False: LOOP_ORDERED, None: LOOP_ORDERED, True: LOOP_PIPELINED, "pipelined": LOOP_PIPELINED,
+                             "exact": LOOP_PIPELINED_EXACT}[overlap]
+        overlap = self.overlap_mode != LOOP_ORDERED
         # SURVEY.md 8(d), replay-capacity note: the default ring holds MEM_SIZE = 24 000 transitions and every vector step inserts a rotating
         # window of 333 envs; the optional "scaled" mode holds one 72-step episode of EVERY env (capacity 72 N) and inserts all N each step
         self.scaled_replay = bool(scaled_replay)
@@ -752,6 +779,17 @@ class TrainWorkload:
         self.t = 0
         self.episode = 1
         self.env.reset_(self.env_seed, episode=self.episode)
+        native_ok = dist is None and not self.agent.wide and self.agent.noise_type != "pn" and self.agent.batch <= self.agent.MAX_PASS_BATCH
+        if loop is None:
+            loop = "native" if native_ok else "host"
+        if loop == "native" and not native_ok:
+            raise NotImplementedError("the native loop drives one replica on the tuned kernels (no gradient exchange, no wide network, no parameter noise)")
+        if self.overlap_mode == LOOP_PIPELINED_EXACT and loop != "native":
+            raise NotImplementedError("the order-exact pipelined mode exists in the native loop only (shems_train_steps)")
+        if self.overlap and self.agent.wide:
+            raise NotImplementedError("pipelined modes run the tuned (250, 500) kernels: a wide network's actor copies are not in their layout")
+        self.loop = loop
+        self._native = None
         if self.overlap:
             # Pipelined mode: replay(t) runs on a second stream while the fused act/step kernel of step t runs on the main
             # one.  act(t) still uses the actor produced by replay(t-1), exactly as in the sequential loop; the one deviation
@@ -775,7 +813,46 @@ class TrainWorkload:
                                                         None, C.byref(rs), C.byref(w), self.agent._stream()))
         self.ring.pushed += self.win
 
+    def _native_loop(self):
+        """The shems_train_loop record of this workload, its in/out fields loaded from the Python-side state."""
+        ag = self.agent
+        if self._native is None:
+            L = TrainLoop()
+            L.view = self.env.view()
+            L.act = ag._act_params(True, 0)
+            L.ddpg = ag._ddpg_args()
+            L.ring = self.ring.struct()
+            L.rewards_f32 = self.rew32.data_ptr()
+            if self.overlap:
+                L.actor_pub[0], L.actor_pub[1] = self.actor_pub[0].data_ptr(), self.actor_pub[1].data_ptr()
+            L.window, L.env_seed, L.sample_seed = self.win, self.env_seed, ag.rng_seed
+            L.ep_len, L.updates_per_step, L.mode = self.EP_LEN, self.updates, self.overlap_mode
+            L.eta_crit, L.eta_act = ag.eta_crit, ag.eta_act
+            self._native = L
+        L = self._native
+        L.ring_pushed, L.t, L.updates, L.episode = self.ring.pushed, self.t, ag.updates, self.episode
+        L.bp_crit[0], L.bp_crit[1], L.bp_act[0], L.bp_act[1] = ag.bp_critic[0], ag.bp_critic[1], ag.bp_actor[0], ag.bp_actor[1]
+        return L
+
+    def steps(self, k):
+        """k vector steps.  Native loop: ONE foreign call enqueues all of them."""
+        if self.loop != "native":
+            for _ in range(int(k)):
+                self.step()
+            return
+        ag = self.agent
+        L = self._native_loop()
+        st2 = C.c_void_p(self.upd_stream.cuda_stream) if self.overlap else None
+        try:
+            _capi.check(ag.L.shems_train_steps(C.byref(L), int(k), ag._stream(), st2))
+        finally:
+            self.ring.pushed, self.t, self.episode = L.ring_pushed, L.t, L.episode
+            ag.updates = L.updates
+            ag.bp_critic, ag.bp_actor = [L.bp_crit[0], L.bp_crit[1]], [L.bp_act[0], L.bp_act[1]]
+
     def step(self):
+        if self.loop == "native":
+            return self.steps(1)
         torch = self.torch
         if self.t and self.t % self.EP_LEN == 0:
             self.episode += 1
@@ -805,6 +882,8 @@ class TrainWorkload:
         if self.overlap:
             self.torch.cuda.current_stream().wait_stream(self.upd_stream)
             self.torch.cuda.synchronize()
+        if self._native is not None:
+            _capi.check(self.agent.L.shems_train_loop_release(C.byref(self._native)))
         self.env.check_error()
         if self.agent.sync_timeouts():
             raise RuntimeError("the merged K4 + K5 launch gave up a wait: its workgroups were not all resident")

@@ -38,6 +38,22 @@ def test_struct_layouts_match_header():
     assert C.sizeof(U.HCConfig) == 48
 
 
+def test_train_loop_record_matches_the_c_struct(tmp_path):
+    """shems_train_loop is passed by pointer and advanced in place: the ctypes mirror must have the C struct's offsets (gcc lays the
+    header's declaration out; compared field by field)."""
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    names = [f[0] for f in D.TrainLoop._fields_]
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "shems_hip.h"\nint main(void){printf("%zu", sizeof(shems_train_loop));' +
+                   "".join(f'printf(" %zu", offsetof(shems_train_loop, {n}));' for n in names) + 'return 0;}\n')
+    exe = tmp_path / "o"
+    subprocess.check_call(["gcc", "-I", os.path.join(U.ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    assert vals[0] == C.sizeof(D.TrainLoop)
+    assert vals[1:] == [getattr(D.TrainLoop, n).offset for n in names]
+    assert (D.LOOP_ORDERED, D.LOOP_PIPELINED, D.LOOP_PIPELINED_EXACT) == (0, 1, 2)
+
+
 def test_gpu_code_object_is_gfx950(built_lib):
     blob = open(built_lib, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob[:0]

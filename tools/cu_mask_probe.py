@@ -2,7 +2,7 @@
 fused kernel of step t runs; without a reservation the update's workgroups find no free CU slot between the fused kernel's rounds.)
 Streams created with hipExtStreamCreateWithCUMask: the fused kernel on 256 - R CUs, the five update launches on the other R (mask bit i
 = CU i / 8 of XCD i % 8, so both sets are spread evenly over the 8 XCDs).  Timing only: the pipelined mode's ordering (5b) is kept as it is.
-    python3 tools/cu_mask_probe.py [envs]"""
+    [CU_MASK_R=64,96,128] python3 tools/cu_mask_probe.py [envs]"""
 import ctypes as C, importlib, json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -45,6 +45,6 @@ def run(label, overlap, R):
 run("sequential, default stream", False, None)
 run("sequential, fused kernel + update on a stream masked to 224 CUs", False, 32)
 run("pipelined (5b), two unmasked streams", True, None)
-for R in (16, 24, 32, 40, 48, 64):
+for R in [int(x) for x in os.environ.get("CU_MASK_R", "16,24,32,40,48,64").split(",")]:
     run(f"pipelined, update on {R} CUs / fused kernel on {256 - R}", True, R)
 print(json.dumps(out, indent=1))
