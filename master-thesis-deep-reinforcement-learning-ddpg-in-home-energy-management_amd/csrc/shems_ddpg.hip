@@ -416,7 +416,7 @@ struct FwdJob {
     const float *d3q;      // QG: [BP] upstream gradient of q (-1/B, 0 in the pad columns)
     float *DAP;            // QG: [NT][2][BP] partial d loss / d a_pi
 };
-struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; };    // prep: 1 = this launch opens the update (K1), 2 = K4
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; DevSync sy; };   // sy: K1 of a pipelined loop waits for the step kernel that filled the ring    // prep: 1 = this launch opens the update (K1), 2 = K4
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
     J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
@@ -881,6 +881,8 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx, 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);                 // pipelined loop: the update's few MFMAs go ahead of a co-resident step kernel's long loop (older waves win otherwise)
+    dev_wait(A.sy);                                // pipelined loop, K1 only: every ring row this update may sample has landed
     constexpr int kPerJob = NT * (BP / 32) + 6;    // K1: a one-dimensional grid of 3 x (64 tile + 6 publishing) workgroups
     const int job = A.prep == 1 ? (int)blockIdx.x / kPerJob : 0, bx = (int)blockIdx.x - job * kPerJob;
     FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];      // (no dynamic indexing of the kernarg block: that goes through scratch)
@@ -980,6 +982,7 @@ __device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_mid(MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);
     const int64_t off = blockIdx.z * A.gstride;
     if ((int)blockIdx.x < A.nfwd) {
         FwdJob J = A.fwd;
@@ -1044,7 +1047,7 @@ __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
     float m = c.mt[i], v = c.vt[i], p = c.p[i], t = c.target[i];
     adam_math(c, graw, m, v, p, t);
     c.mt[i] = m; c.vt[i] = v; c.p[i] = p; c.target[i] = t;
-    if (c.publish) c.publish[i] = p;
+    if (c.publish) pub_store(c.publish + i, p, true);
 }
 // N independent elements of one lane: all loads first (one exposed latency), then the arithmetic, then the stores.  idx < 0: skip.
 template <int N>
@@ -1063,7 +1066,7 @@ __device__ __forceinline__ void adam_batch(const AdamCtx &c, const int (&idx)[N]
         if (idx[i] >= 0) {
             const int e = idx[i];
             c.mt[e] = m[i]; c.vt[e] = v[i]; c.p[e] = p[i]; c.target[e] = t[i];
-            if (c.publish) c.publish[e] = p[i];
+            if (c.publish) pub_store(c.publish + e, p[i], true);
         }
     }
 }
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ void adam_apply(const AdamCtx &c, const int (&idx)[N]
         if (idx[i] >= 0) {
             const int e = idx[i];
             c.mt[e] = R.m[i]; c.vt[e] = R.v[i]; c.p[e] = R.p[i]; c.target[e] = R.t[i];
-            if (c.publish) c.publish[e] = R.p[i];
+            if (c.publish) pub_store(c.publish + e, R.p[i], true);
         }
     }
 }
@@ -1256,6 +1259,7 @@ struct GradArgs {
     shems_ddpg dd;         // for the heads
     AdamCtx c;
     int64_t gstride;       // learner groups: byte stride between learners (0 = single learner)
+    DevSync sy;            // K5 of a pipelined loop: tells the step kernel waiting for the published actor that one more workgroup is done
 };
 __device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
 {
@@ -1572,8 +1576,10 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_grad(GradArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __builtin_amdgcn_s_setprio(3);
     gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
     if (A.in == SIN) grad_body<SIN, 2>(A, smem, (int)blockIdx.x); else grad_body<CIN, 1>(A, smem, (int)blockIdx.x);
+    dev_arrive(A.sy, false);                       // the published actor copy is stored write-through (AdamCtx::publish): draining is enough
 }
 
 // ---- K4 + K5 in ONE launch (single learner, fused ADAM): workgroups [0, 128) are K4's tiles, the rest K5's gradient workgroups.
@@ -1671,13 +1677,19 @@ __global__ __launch_bounds__(256) void k_action_distance(const float *__restrict
 constexpr int FWD_LDS = FwdShape<false>::LDS, QG_LDS = FWD_LDS > QG16_LDS ? FWD_LDS : QG16_LDS;
 constexpr int MID_LDS = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
 static_assert(QG_LDS <= 160 * 1024, "one workgroup's LDS");
+// Pipelined loop with device-side dependencies: the five launches of an update ask for ONE LDS size.  A CU's LDS is handed out in
+// contiguous blocks; a step workgroup (92 KB) that starts while a 57-KB gradient workgroup sits at the bottom of the CU's LDS is placed
+// above it, and the hole that workgroup leaves then never fits K1 / K2 (63.5 KB) for as long as the step workgroup lives -- traced in
+// round 4: K1 took 26 us instead of 6, waiting for CUs.  With one size every hole an update workgroup leaves fits the next one.
+constexpr int UPD_LDS_ = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
+constexpr int UPD_LDS = (UPD_LDS_ > GR_LDS ? UPD_LDS_ : GR_LDS) > QG16_LDS ? (UPD_LDS_ > GR_LDS ? UPD_LDS_ : GR_LDS) : QG16_LDS;
 
 static int set_lds_attrs()
 {
     static std::atomic<uint64_t> m_fwd{0}, m_mid{0}, m_grad{0};          // per device: see lds_optin
     if (int rc = lds_optin(m_fwd, reinterpret_cast<const void *>(&k_fwd), QG_LDS, "attr k_fwd")) return rc;
     if (int rc = lds_optin(m_mid, reinterpret_cast<const void *>(&k_mid), MID_LDS, "attr k_mid")) return rc;
-    if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), GR_LDS, "attr k_grad")) return rc;
+    if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), UPD_LDS, "attr k_grad")) return rc;
     return SHEMS_OK;
 }
 
@@ -1769,7 +1781,8 @@ static int actor_e_launch(const shems_ddpg *d, unsigned L, int64_t gs, hipStream
 }
 
 static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                       int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
+                       int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream,
+                       const DevSync *first = nullptr)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
     if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
@@ -1793,7 +1806,8 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     f.job[2] = FwdJob{nullptr, d->actor, SIN, 2, 2, none, SA + SL_H2, SA + SL_P3, nullptr, nullptr};
     f.prep = 1;
     f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    hipLaunchKernelGGL(k_fwd, dim3(3 * (fgx + 6), 1, L), dim3(256), flds, st, f);      // + 6 publishing workgroups per job (see fwd_body)
+    if (first) f.sy = *first;
+    hipLaunchKernelGGL(k_fwd, dim3(3 * (fgx + 6), 1, L), dim3(256), first ? UPD_LDS : flds, st, f);      // + 6 publishing workgroups per job (see fwd_body)
     // K2: critic_target on [s'; actor_target(s')] | E of the critic | E of the actor's two outputs
     MidArgs m;
     std::memset(&m, 0, sizeof m);
@@ -1803,19 +1817,19 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     m.e[1] = EJob{d->actor, SIN, 2, 0, SA + SL_H2, SA + SL_EP};
     m.e[2] = EJob{d->actor, SIN, 2, 1, SA + SL_H2, ws + WS_EA1};
     const bool defer_ea = !fuse && (d->flags & SHEMS_DDPG_DEFER_ACTOR_E) != 0;       // the caller runs shems_ddpg_actor_prepare later
-    hipLaunchKernelGGL(k_mid, dim3(fgx + (defer_ea ? 1 : 3) * KT * NQ, 1, L), dim3(256), MID_LDS, st, m);
+    hipLaunchKernelGGL(k_mid, dim3(fgx + (defer_ea ? 1 : 3) * KT * NQ, 1, L), dim3(256), first ? UPD_LDS : MID_LDS, st, m);
     // K3: critic gradient (+ ADAM + soft update)
     GradArgs g;
     std::memset(&g, 0, sizeof g);
     g.w1t = w1t_of(ws, SLOT_CRITIC); g.P = d->critic; g.in = CIN; g.out = 1; g.x = x_sa; g.H2 = SC + SL_H2; g.w3f = ws + WS_FW3C;
     g.grad = d->grad_critic; g.E0 = SC + SL_EP; g.E1 = nullptr; g.head = 1; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, true, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
-    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), first ? UPD_LDS : GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg critic-side launches");
 }
 
 // K4 + K5: the actor side (DDPG.jl:137-140), through the critic as it stands now (already updated)
-static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
+static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream, const DevSync *last = nullptr)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1835,13 +1849,14 @@ static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamSca
     g.w1t = w1t_of(ws, SLOT_ACTOR); g.P = d->actor; g.in = SIN; g.out = 2; g.x = x_s; g.H2 = SA + SL_H2; g.w3f = ws + WS_FW3A;
     g.grad = d->grad_actor; g.E0 = SA + SL_EP; g.E1 = ws + WS_EA1; g.head = 2; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, false, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
-    if (fuse && L == 1 && gs == 0 && merge_ok()) {
+    if (last) g.sy = *last;
+    if (fuse && L == 1 && gs == 0 && !last && merge_ok()) {
         // one replica, ADAM inside the gradient launch: K4 and K5 as ONE launch (k_qg_grad); the arrival counter was zeroed by K3
         hipLaunchKernelGGL(k_qg_grad, dim3(QGG_GRID), dim3(256), QGG_LDS, st, f, g, reinterpret_cast<unsigned *>(ws + WS_SYNC));
         return hip_ok(hipGetLastError(), "ddpg actor-side launch (merged)");
     }
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG16_LDS, st, f);
-    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), last ? UPD_LDS : QG16_LDS, st, f);
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), last ? UPD_LDS : GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg actor-side launches");
 }
 
@@ -1919,6 +1934,25 @@ int shems_ddpg_update(const shems_ddpg *d, const shems_replay *ring, int64_t rin
     if (int rc = critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, &sc, stream)) return rc;
     return actor_side(d, 1, 0, &sa, stream);
 }
+
+}  // extern "C"
+
+namespace shems {
+int ddpg_update_sync(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick, int64_t excl_pos,
+                     int64_t excl_count, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act, double bp2_act,
+                     float *d_publish, const DevSync &first, const DevSync &last, hipStream_t st)
+{
+    if (int rc = check_adam(bp1_crit, bp2_crit, "ddpg_update_sync")) return rc;
+    if (int rc = check_adam(bp1_act, bp2_act, "ddpg_update_sync")) return rc;
+    const AdamScalars sc{eta_crit, bp1_crit, bp2_crit, 1.0, nullptr}, sa{eta_act, bp1_act, bp2_act, 1.0, d_publish};
+    if (int rc = critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, &sc, st, &first)) return rc;
+    return actor_side(d, 1, 0, &sa, st, &last);
+}
+int ddpg_last_launch_grid() { return GR_NW + GR_NG + GR_NR; }
+unsigned *ddpg_timeout_word(const shems_ddpg *d) { return reinterpret_cast<unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT; }
+}  // namespace shems
+
+extern "C" {
 
 int shems_ddpg_group_update(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len, uint64_t seed,
                             uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,

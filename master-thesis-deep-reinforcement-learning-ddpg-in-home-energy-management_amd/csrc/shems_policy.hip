@@ -110,6 +110,8 @@ struct ActArgs {
     int gcount;
     int64_t gstride;
     int64_t genvs;
+    DevSync sy;                // pipelined training loop: wait for the update that publishes p.actor / tell the next update the ring is complete
+    int force_split;           // 1: the two-workgroups-per-tile form whatever the size (leaves LDS for a co-resident update workgroup)
 };
 
 template <class T>
@@ -552,12 +554,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 
     // Layer 1 on the matrix pipe (K = 10 = 5 k-steps): rows [32g, 32g+32) x this workgroup's BM columns into Hc[g & 1];
     // wave w owns column tile w (TM <= 4 tiles).  D layout: row (r&3)+8(r>>2)+4*lh, column lane&31.
+/* A operand of k-step s_ (input row j_ = 2 s_ + lh) of row group g: from the LDS image w1 here; k_actg redefines it (registers). */
+#define L1_A(s_, j_, g, which) w1[(j_) * kW1C + 32 * (g) + li]
 #define L1_TILE(g, b, dst)                                                                        \
     do {                                                                                          \
             float a_[kW1K / 2], b_[kW1K / 2];                                                     \
             _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
                 const int j_ = 2 * s_ + lh;                                                       \
-                a_[s_] = w1[j_ * kW1C + 32 * (g) + li];                                           \
+                a_[s_] = L1_A(s_, j_, g, 0);                                                      \
                 b_[s_] = xT[j_ * BM + TM * li + (b)];             /* env column m = TM*j + tile */  \
             }                                                                                     \
             /* The accumulator of this tile must stay in VGPRs: given the builtin, the compiler parks it in a[0:15] and moves */ \
@@ -585,9 +589,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             float a0_[kW1K / 2], c0_[kW1K / 2], a1_[kW1K / 2], c1_[kW1K / 2];                     \
             _Pragma("unroll") for (int s_ = 0; s_ < kW1K / 2; ++s_) {                             \
                 const int j_ = 2 * s_ + lh;                                                       \
-                a0_[s_] = w1[j_ * kW1C + 32 * (g0) + li];                                         \
+                a0_[s_] = L1_A(s_, j_, g0, 0);                                                    \
                 c0_[s_] = xT[j_ * BM + TM * li + (b0)];                                           \
-                a1_[s_] = w1[j_ * kW1C + 32 * (g1) + li];                                         \
+                a1_[s_] = L1_A(s_, j_, g1, 1);                                                    \
                 c1_[s_] = xT[j_ * BM + TM * li + (b1)];                                           \
             }                                                                                     \
             f32x16 t0_, t1_;                                                                      \
@@ -986,7 +990,7 @@ constexpr unsigned long long kSplitEmpty = ~0ull;         // no pair of layer-3 
 template <int TM, int NW, int RD>
 constexpr size_t actg_lds_bytes()
 {
-    return sizeof(float) * (NW * RD * kGChunkFloats + 16 + 256 * 32 * TM + kW1K * 32 * TM + kW1K * kW1C + (kTailFloats + 2) +
+    return sizeof(float) * (NW * RD * kGChunkFloats + 16 + 256 * 32 * TM + kW1K * 32 * TM + (kTailFloats + 2) +
                             8 * 32 * TM * kOut + 32 * TM * kIn + 32 * TM * kPreDw + 4);
 }
 
@@ -1011,14 +1015,14 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
 #define GSTAMP(i, cond)
 #endif
     GSTAMP(0, blockIdx.x == 0);
+    dev_wait(A.sy);                                           // pipelined loop: the update that publishes A.p.actor has finished
     static_assert(RD >= 2 && RD <= 4 && TM >= 1 && TM <= 2, "ring of 2..4 chunks; relu(layer 1) fully resident (TM <= 2)");
     constexpr int NT_ = 64 * NW, BM = 32 * TM, HR = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Wc = reinterpret_cast<float *>(smem);             // [NW][RD][16][64] private W2 rings
     float *Hc = Wc + NW * RD * kGChunkFloats + 16;           // [256][BM] relu(layer 1)
     float *xT = Hc + HR * BM;                                // [10][BM]  normalised obs (rows 0..8), row 9 = 1 (bias)
-    float *w1 = xT + kW1K * BM;                              // [10][256] layer-1 operand image
-    float *tl = w1 + kW1K * kW1C;                            // b2 [512], W3 [512][2], b3 [2]
+    float *tl = xT + kW1K * BM;                              // b2 [512], W3 [512][2], b3 [2]   (no layer-1 operand image: see wa_ below)
     float *red = tl + (kTailFloats + 2);                     // [8 groups][BM][2] layer-3 group sums
     float *xR = red + 8 * BM * kOut;                         // [BM][9] raw observations
     float *xP = xR + BM * kIn;                               // [BM][kPreDw] TailPre blocks
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         tp.step = pstep[view ? pe : 0];
     }
     constexpr int kIt = (BM * kIn + NT_ - 1) / NT_;
-    float sv[kIt], lo[kIt], hi[kIt], wv[kW1K], tv[6];
+    float sv[kIt], lo[kIt], hi[kIt], tv[6];
     const int64_t last = A.m * kIn - 1;
 #pragma unroll
     for (int it = 0; it < kIt; ++it) {
@@ -1078,10 +1082,23 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         lo[it] = s_min[k];
         hi[it] = s_max[k];
     }
-    {
-        const int kc = min(tid & 255, kH1 - 1);
+    // Layer-1 A operands straight from the parameter block (round 4; k_act2 does the same): a wave lays down row groups wave (and
+    // wave + 4 when it has two), and lane (li, lh) of a tile of group g multiplies W1[2 s + lh][32 g + li], s = 0..4 (input row 9 = b1)
+    // -- ten words per lane, requested here with everything else.  No [10][256] image in LDS: 10 KB less per workgroup, which is what
+    // lets a 64-KB workgroup of the update share the CU with the two-workgroups-per-tile form (92 + 64 KB <= 160 KB).
+    constexpr int kL1PerWave = (8 * TM) / NW;                // 2 (NW = 4) or 1 (NW = 8)
+    static_assert(TM == 1 && (kL1PerWave == 1 || kL1PerWave == 2), "k_actg lays layer 1 down for 32-env tiles");
+    float wa_[kL1PerWave][kW1K / 2];
+    bool wok_[kL1PerWave];
 #pragma unroll
-        for (int j = 0; j < kW1K; ++j) wv[j] = P[(j == kW1K - 1 ? kIn : min(j, kIn - 1)) * kH1 + kc];
+    for (int u = 0; u < kL1PerWave; ++u) {
+        const int k = 32 * (wave + NW * u) + li;
+        wok_[u] = k < kH1;
+#pragma unroll
+        for (int s2 = 0; s2 < kW1K / 2; ++s2) {
+            const int j = 2 * s2 + lh;                        // 0..9; row 9 of the operand = b1 = parameter row kIn
+            wa_[u][s2] = P[j * kH1 + min(k, kH1 - 1)];
+        }
     }
 #pragma unroll
     for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
@@ -1105,10 +1122,6 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (e < BM * kIn) { xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f; xR[e] = sv[it]; }
     }
     for (int e = tid; e < BM; e += NT_) xT[kIn * BM + e] = 1.0f;                               // row 9 = 1: the bias input
-    if (tid < kW1C) {
-#pragma unroll
-        for (int j = 0; j < kW1K; ++j) w1[j * kW1C + tid] = ((j < kIn || j == kW1K - 1) && tid < kH1) ? wv[j] : 0.0f;
-    }
     {
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
@@ -1120,8 +1133,10 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
         if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT, w1 visible (LDS stores only; the row loads keep flying)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT visible (LDS stores only; the row loads keep flying)
     GSTAMP(1, blockIdx.x == 0);
+#undef L1_A
+#define L1_A(s_, j_, g, which) (wok_[which] ? wa_[which][s_] : 0.0f)           /* rows of W1 / b1 held in registers since stage 0 */
     {
         // the ring's first chunks go out only now: 256 workgroups x 64 KB of pieces would otherwise queue in front of the few KB
         // every workgroup is waiting for
@@ -1302,6 +1317,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (tid == 0) A.block_reward[tile] = s;
     }
 #endif
+    dev_arrive(A.sy, true);                                   // ring rows and env state of this workgroup are visible: one more workgroup done
 }
 
 // =====================================================================================================================
@@ -1335,6 +1351,7 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
 {
     constexpr int TM = 2, BM = 64, NA = 4, NT_ = 256, HR = 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    dev_wait(A.sy);                                           // pipelined loop: the update that publishes A.p.actor has finished
     float *Wc = reinterpret_cast<float *>(smem);             // [4 waves][RD][4 rows][128] private W2 rings
     float *Hc = Wc + 4 * k2RD * k2CF + 16;                   // [128][BM] relu(layer 1), one half at a time
     float *xT = Hc + HR * BM;                                // [10][BM]
@@ -1602,6 +1619,7 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
         if (tid == 0) A.block_reward[bid] = s;
     }
 #endif
+    dev_arrive(A.sy, true);
 }
 
 static int launch_act2(const ActArgs &a, hipStream_t st)
@@ -1710,6 +1728,13 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
     const int64_t cnt = a.m - a.m0;                           // envs of this launch (a range launch: every form writes the same bytes)
+    if (a.sy.wait_flags || a.sy.arrive_count || a.force_split) {
+        // device-side dependencies live in the two forms the pipelined loop runs: the split form (one 92-KB workgroup per CU at a time)
+        // up to 16 384 envs when asked for, else two-per-CU 64-env tiles
+        if (a.gcount > 1 || a.block_reward) return set_error(SHEMS_ERR_ARG, "act: device-side dependencies are not available to learner groups / per-tile sums");
+        if (a.force_split && (cnt + 31) / 32 <= kSplitMaxTiles) return launch_actg<1, 4, 2, 3>(a, st);
+        return launch_act2(a, st);
+    }
     if (form4 == 2 && form < 0 && cnt > 8192 && a.gcount <= 1) return launch_act2(a, st);
     if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
     const int tm = pick_tm(cnt);
@@ -1805,6 +1830,35 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
     }
     return dispatch_act(a, (hipStream_t)stream);
 }
+
+}  // extern "C"
+
+namespace shems {
+int act_step_sync(const shems_view *v, const shems_act_params *p, float *d_rewards_f32, const shems_replay *ring, const shems_ring_window *window,
+                  const DevSync &sy, int split, int64_t *grid_out, hipStream_t st)
+{
+    if (int rc = check_act(p, "act_step_sync")) return rc;
+    if (int rc = check_view(v, "act_step_sync")) return rc;
+    ActArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.v = *v; a.p = *p; a.obs = v->obs; a.m = v->n_envs;
+    a.rewards_f32 = d_rewards_f32;
+    a.do_step = 1;
+    a.sy = sy; a.force_split = split;
+    if (ring && window && window->count > 0) {
+        if (ring->capacity <= 0 || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done)
+            return set_error(SHEMS_ERR_ARG, "act_step_sync: incomplete replay ring");
+        if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0 || window->offset < 0 || window->offset >= v->n_envs)
+            return set_error(SHEMS_ERR_ARG, "act_step_sync: ring window outside the ring or the batch");
+        a.ring = *ring; a.win = *window; a.use_ring = 1;
+    }
+    const bool splitf = split && (a.m + 31) / 32 <= kSplitMaxTiles;
+    if (grid_out) *grid_out = splitf ? 2 * ((a.m + 31) / 32) : (a.m + 63) / 64;
+    return dispatch_act(a, st);
+}
+}  // namespace shems
+
+extern "C" {
 
 int shems_act_step_range_dev(const shems_view *v, const shems_act_params *p, int64_t env_lo, int64_t env_count, float *d_rewards_f32,
                              const shems_replay *ring, const shems_ring_window *window, void *stream)

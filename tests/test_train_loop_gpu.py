@@ -80,12 +80,17 @@ def test_order_exact_pipelined_loop_leaves_the_bytes_of_the_ordered_loop(n):
     _same(torch, ordered, exact2, "exact pipelined in three calls vs ordered")
 
 
-@pytest.mark.parametrize("n", [2048, 8192])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384, 20000])
 def test_native_pipelined_loop_leaves_the_bytes_of_the_host_pipelined_loop(n):
-    torch, host = _run(n, 150, [150], loop="host", overlap="pipelined")
-    _, nat = _run(n, 150, [150], loop="native", overlap="pipelined")
+    """Up to 16 384 envs the native pipelined loop has NO queue-level dependency: the launches wait in the kernel for counts of finished
+    producer workgroups (DevSync).  A lost or late dependency shows as different bytes against the host loop, whose two streams are
+    ordered by events."""
+    torch, host = _run(n, 300, [300], loop="host", overlap="pipelined")
+    _, nat = _run(n, 300, [300], loop="native", overlap="pipelined")
     _same(torch, host, nat, "pipelined native vs host")
-    _, ordered = _run(n, 150, [150], loop="native")
+    _, nat3 = _run(n, 300, [7, 200, 93], loop="native", overlap="pipelined")
+    _same(torch, host, nat3, "pipelined native in three calls vs host")
+    _, ordered = _run(n, 300, [300], loop="native")
     assert not torch.equal(ordered[0]["actor"], nat[0]["actor"])         # the documented deviation: replay(t) does not see step t's inserts
 
 

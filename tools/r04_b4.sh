@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04_b4; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-for m in pipelined exact; do
+for m in pipelined; do
 rocprofv3 --kernel-trace --output-format csv -d $O/kt_$m -- python3 $R/bench.py --envs 4096 --overlap $m --steps 300 --warmup 50 --prewarm-s 0.1 --no-cpu-baseline > $O/kt_$m.log 2>&1
 cp $(find $O/kt_$m -name "*kernel_trace.csv" | head -1) $O/${m}_trace.csv; rm -rf $O/kt_$m
 python3 - <<PY
