@@ -145,8 +145,9 @@ class PolicyWorkload(EnvWorkload):
         reset = lambda g, i: self._reset_dev(1000 + i) if g % 8 == 0 else None
         avg, med, reps = T.time_launches(self.torch, self._launch, min(reps, 200), before_group=reset)
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n       # 256 500 FLOP per env-step
-        return dict(kernel="shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)", avg_us=avg, median_us=med, launches=reps,
-                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS)
+        return dict(kernel=self.D.act_kernel_name(self.n), avg_us=avg, median_us=med, launches=reps,
+                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=MFMA_F32_PEAK_TFLOPS,
+                    algorithmic_bytes=self.D.act_algorithmic_bytes(self.n, self.win_count))
 
 
 def cpu_baseline(n_envs, mode, updates, scale=1.0):
@@ -446,6 +447,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_gpu_section_start = time.perf_counter()
     # Device pre-warm (untimed, reported as prewarm_steps): a GPU that has been idle runs its first milliseconds well below the
     # sustained state (clock ramp, cold instruction / TLB / L2 state): 20 steps right after start-up measured 353 M env-steps/s where
     # the same build sustains 388 M.  The contract's W warm-up steps and K timed steps follow unchanged.  Ranks agree on the count.
@@ -470,6 +472,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     wl.finish()
+    t_gpu_section_end = time.perf_counter()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -492,8 +495,11 @@ def main():
     roof = None
     cpu = None
     all_ranks_pass = dist is not None and mode == "train"      # the data-parallel pass issues collectives: every rank runs it
+    t_pass0 = time.perf_counter()
     if rank == 0 or all_ranks_pass:
         k = wl.kernel_pass(max(200, min(args.steps, 500)))
+    t_pass = time.perf_counter() - t_pass0
+    t_cpu = 0.0
     if rank == 0:
         achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
         traffic, traffic_src = None, None
@@ -510,8 +516,17 @@ def main():
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],
                 "algorithmic_per_launch": k["algorithmic"],
                 "timing": k.get("method", "HIP events over back-to-back groups of 8 launches")}
+        # north_star asks for "rocprof HBM GB/s": the counter bytes per launch over the launch's time; next to it the bytes the launch
+        # HAS to move and their ratio (well above 1 = wasted re-reads; an MFMA-bound kernel sits far below the HBM roof either way)
+        roof["algorithmic_bytes"] = k.get("algorithmic_bytes")
+        roof["hbm_gbs"] = traffic / (k["avg_us"] * 1e-6) / 1e9 if traffic else None
+        roof["traffic_ratio"] = traffic / k["algorithmic_bytes"] if traffic and k.get("algorithmic_bytes") else None
+        if k.get("avg_us_is"):
+            roof["kernel_avg_us_is"] = k["avg_us_is"]
         if world == 1 and not args.no_cpu_baseline and args.hidden.lower() == "250x500":      # (the CPU port is timed at the headline architecture)
+            t_cpu0 = time.perf_counter()
             cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)
+            t_cpu = time.perf_counter() - t_cpu0
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -535,6 +550,11 @@ def main():
                        "envs_per_gpu": args.envs, "episode_len": EP_LEN, "mode": mode, "mixed_profiles": bool(args.mixed)},
             "roofline": roof,
             "cpu_baseline": cpu,
+            # where the run's wall time went, so that a sampled GPU-utilisation figure can be reconciled with the line: the GPU is busy
+            # during gpu_section_s (pre-warm + warm-up + timed steps) and roofline_pass_s only; cpu_baseline_s is host cores alone
+            "gpu_section_s": t_gpu_section_end - t_gpu_section_start,
+            "roofline_pass_s": t_pass,
+            "cpu_baseline_s": t_cpu,
         }
         out.update(wl.extra())
         if census is not None:

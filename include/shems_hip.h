@@ -243,6 +243,9 @@ int shems_act_step_range_dev(const shems_view *v, const shems_act_params *p, int
                              const shems_replay *ring, const shems_ring_window *window, void *stream);
 /* scale_action (DDPG.jl:178-184) on device: d_a [n][2] in [-1,1] -> d_out [n][2] SoC targets in [0,1]. */
 int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stream);
+/* The kernel shems_act_step_dev (grouped = 0) / shems_act_step_group_dev (grouped != 0) dispatches for n_envs envs, by the name a
+ * profiler shows (e.g. "shems::k_act2", "shems::k_actg<1, 8, 1, 3>"), NUL-terminated into out[cap]: bench.py's roofline.kernel. */
+int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap);
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 
@@ -298,9 +301,9 @@ typedef struct shems_ddpg {
 enum { SHEMS_DDPG_DEFER_ACTOR_E = 1 };
 
 int shems_ddpg_workspace_floats(int64_t *out);
-/* shems_ddpg_update runs the last two of its five dependent steps (critic on [s; actor(s)] with its input gradient, then the actor's
- * gradient + ADAM + soft update; DDPG.jl:137-144) as ONE launch whose second half waits, bounded, for the first.  *out = how many
- * workgroups ever gave up that wait on this workspace (0 in every supported use; non-zero = that update's actor step is invalid). */
+/* The pipelined training loop's opt-in device-side form (shems_train_steps, SHEMS_LOOP_SYNC=device) makes launches wait, bounded, inside
+ * the kernel.  *out = how many workgroups gave up such a wait on this workspace since the last call (read and cleared; 0 in every
+ * supported use; non-zero = the steps enqueued since then are invalid).  Synchronises `stream`. */
 int shems_ddpg_sync_timeouts(const struct shems_ddpg *d, int64_t *out, void *stream);
 /* The whole replay() for one replica.  grad_actor / grad_critic still receive the complete gradients.  excl_pos / excl_count:
  * as shems_ddpg_critic_grad_ex (0, 0 = none).  d_publish: optional second copy [129002] of the updated actor (see
@@ -328,6 +331,27 @@ int shems_ddpg_actor_apply_pub(const shems_ddpg *d, double eta, double bp1, doub
                                float *d_publish, void *stream);
 /* The minibatch indices of (seed, tick): host helper for tests (same Philox as the device). */
 int shems_ddpg_sample_indices(uint64_t seed, uint32_t tick, int32_t batch, int64_t ring_len, int64_t *out);
+/* ------------------------------------------ data-parallel replicas -- */
+/* One process per GPU, each with its own env shard and ring, one learner replicated: replay() sums the gradients over the replicas at
+ * its two exchange points (the reference has no collective: 40 independent processes,
+ * RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87).  shems_dp is one RCCL communicator; its all-reduces are issued IN THE CALLER'S
+ * STREAM (no stream of their own, hence no dependency between queues -- 5-10 us each on this stack), RCCL itself is loaded with dlopen
+ * at first use.  Rank 0 makes the 128-byte id and hands it to the others by any means (the Python host: torch.distributed broadcast);
+ * shems_dp_create is collective (every rank calls it, on its own device). */
+enum { SHEMS_DP_ID_BYTES = 128 };
+typedef struct shems_dp shems_dp;
+int shems_dp_unique_id(char *out128);
+int shems_dp_create(const char *id128, int rank, int world, shems_dp **out);
+int shems_dp_destroy(shems_dp *dp);
+int shems_dp_info(const shems_dp *dp, int *rank, int *world, char *lib, int32_t cap);   /* lib: which librccl was loaded */
+int shems_dp_allreduce_sum(shems_dp *dp, float *d_buf, int64_t n, void *stream);        /* in place, float32, in `stream` */
+/* replay() of one replica: shems_ddpg_critic_grad_ex, all-reduce(grad_critic), shems_ddpg_critic_apply(grad_scale = 1 / world),
+ * shems_ddpg_actor_grad, all-reduce(grad_actor), shems_ddpg_actor_apply_pub -- everything in `stream`.  dp == NULL: a single replica in
+ * the split form (the bytes of shems_ddpg_update). */
+int shems_ddpg_update_dp(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick, int64_t excl_pos,
+                         int64_t excl_count, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act, double bp2_act,
+                         float *d_publish, shems_dp *dp, void *stream);
+
 /* ------------------------------------------------- the training loop -- */
 /* The hour loop of episode! (DDPG.jl:195-234) for every env of a view, `k` vector steps enqueued by ONE call:
  *   per step t:  [t > 0 and t % ep_len == 0: episode += 1, reset!(env) with (env_seed, episode)  -- DDPG.jl:189-193]
@@ -369,6 +393,7 @@ typedef struct shems_train_loop {
     double   eta_crit, bp_crit[2];   /* in/out: ADAM(eta_crit) and its beta^t powers for the NEXT critic step                     */
     double   eta_act, bp_act[2];     /* in/out: same for the actor                                                                */
     void    *sync;                   /* opaque, NULL on first use                                                                 */
+    shems_dp *dp;                    /* data-parallel replicas (SHEMS_LOOP_ORDERED only): replay() = shems_ddpg_update_dp; NULL = one replica */
 } shems_train_loop;
 int shems_train_steps(shems_train_loop *loop, int64_t k, void *stream, void *stream2);
 /* Pipelined modes: make `stream` wait for everything the loop has in flight on stream2 (the caller then synchronises `stream`). */

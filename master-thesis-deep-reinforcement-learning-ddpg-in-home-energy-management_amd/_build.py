@@ -25,6 +25,7 @@ UNITS = [
     ("shems_track.hip", ["-ffp-contract=off"]),
     ("shems_wide.hip", []),
     ("shems_train.hip", []),
+    ("shems_dp.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(ROOT, "include")]
@@ -69,7 +70,7 @@ def build(force=False, verbose=False, defines=(), tag=""):
             rebuilt = True
         objs.append(obj)
     if rebuilt or not os.path.exists(lib):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

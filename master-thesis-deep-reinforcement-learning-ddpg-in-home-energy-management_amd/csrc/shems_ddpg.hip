@@ -96,9 +96,9 @@ constexpr int64_t SL_SIZE = SL_EP + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
 static_assert(WS_W1T % 4 == 0 && WS_SLOT0 % 4 == 0 && SL_SIZE % 4 == 0, "16-byte aligned blocks");
 __host__ __device__ inline float *w1t_of(float *ws, int net) { return ws + WS_W1T + (int64_t)net * 12 * 256; }   // net = SLOT_* < 4
-constexpr int64_t WS_SYNC = WS_SLOT0 + N_SLOTS * SL_SIZE;      // sync words of the merged K4 + K5 launch (SY_*), each on a 128-byte line of its own
-constexpr int64_t WS_FLOATS = WS_SYNC + 96;                    // three 128-byte lines: the counter K4 adds to, the flag K5 polls, the timeout count
-constexpr int SY_ARRIVE = 0, SY_FLAG = 32, SY_TIMEOUT = 64;
+constexpr int64_t WS_SYNC = WS_SLOT0 + N_SLOTS * SL_SIZE;      // three 128-byte lines; the third holds SY_TIMEOUT: device-side waits of the pipelined
+constexpr int64_t WS_FLOATS = WS_SYNC + 96;                    // training loop that gave up (DevSync, shems_internal.h; shems_ddpg_sync_timeouts).  Round 3's
+constexpr int SY_TIMEOUT = 64;                                 // merged K4 + K5 launch used the first two (measured slower, profiles/r03_update_merge.txt; removed)
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
 
@@ -122,11 +122,9 @@ __device__ __forceinline__ float wave_sum(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
-// In-launch hand-off (the merged K4 + K5 launch): a value another workgroup of the SAME launch reads is stored write-through and read
-// past the caches -- relaxed agent-scope atomic store / load = global_store / global_load ... sc1 -- so that neither a release nor an
-// acquire fence is needed (a device-scope release writes the whole L2 back: measured in round 1, it costs more than a launch boundary).
-// Every storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup's barrier, then ONE lane adds to the arrival counter;
-// the consumer polls the counter with the same kind of load, bounded, and loads the payload only behind its own barrier.
+// A value a workgroup of ANOTHER launch still running reads (the published actor copy of the pipelined training loop) is stored
+// write-through -- relaxed agent-scope atomic store = global_store ... sc1 -- so that no release fence is needed (a device-scope release
+// writes the whole L2 back: measured in round 1, it costs more than a launch boundary); see DevSync in shems_internal.h.
 __device__ __forceinline__ void pub_store(float *p, float v, bool wt)
 {
     if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
@@ -135,23 +133,6 @@ __device__ __forceinline__ float pub_load(const float *p, bool wt)
 {
     return wt ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
-constexpr unsigned kWaitSpins = 1u << 16;        // x (one sc1 load + s_sleep) ~ tens of ms: a launch that cannot make progress gives up, it never hangs
-// All threads call it.  Returns after `target` producers have arrived (or the bound ran out: counted in sync[1], results are then wrong
-// and shems_ddpg_sync_timeouts reports it).  The polled word sits on a cache line of its own: 207 pollers on the line the producers
-// add to would queue those adds behind their loads.
-__device__ __forceinline__ void wait_arrivals(unsigned *sync, unsigned target, unsigned *timeouts)
-{
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > kWaitSpins) { __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the payload loads below the barrier
-}
-
 // Where a network input [in][BP] comes from: rows 0..8 = a normalised-state block, rows 9..10 (critics) either the
 // stored actions or tanh(b3 + sum of the layer-3 partials of an actor pass).
 struct XSrc {
@@ -688,11 +669,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int QG16_WST = 20;                                   // W2 panel row stride: 16-B aligned rows, both operand reads conflict-free
 constexpr int QG16_LDS = (256 * QG16_WST + W1K * 32 + W1K * W1C + 256 + 4 * 2 * 4 * 64 + 4 * 64 + 16 * 32 + 4 * 2 * 2 * 64) * 4;
 
-struct GradArgs;
-__device__ __forceinline__ void qg_last_arriver(const GradArgs &G, float *smem, unsigned *sync);
-__device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx, unsigned *sig = nullptr, const GradArgs *G = nullptr)
+__device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
 {
-    const bool wt = sig != nullptr;            // merged K4 + K5 launch: outputs are read by workgroups of this same launch
+    constexpr bool wt = false;                 // (round 3's merged K4 + K5 launch stored these write-through; removed in round 4, see WS_SYNC)
     constexpr int WST = QG16_WST;
     float *Wc = smem;                          // [256][WST]  W2[k][n0 .. n0 + 15] (rows >= 250: copies of row 249, never effective)
     float *xs = Wc + 256 * WST;                // [12][32]
@@ -866,22 +845,11 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx, 
         pub_store(J.DAP + (ntile * 2 + j) * BP + mbase + mm, sres, wt);
     }
     STAMP(3, 9);
-    if (wt) {                                                  // arrival: stores drained by every wave, barrier, one lane counts
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned *lds_u = reinterpret_cast<unsigned *>(smem);
-        if (tid == 0) lds_u[0] = __hip_atomic_fetch_add(sig + SY_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const bool last = lds_u[0] == (unsigned)(NT16 * (BP / 32) - 1);
-        __syncthreads();
-        if (last) qg_last_arriver(*G, smem, sig);             // everybody else's partials are complete: evaluate the actor head ONCE
-    }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __builtin_amdgcn_s_setprio(3);                 // pipelined loop: the update's few MFMAs go ahead of a co-resident step kernel's long loop (older waves win otherwise)
     dev_wait(A.sy);                                // pipelined loop, K1 only: every ring row this update may sample has landed
     constexpr int kPerJob = NT * (BP / 32) + 6;    // K1: a one-dimensional grid of 3 x (64 tile + 6 publishing) workgroups
     const int job = A.prep == 1 ? (int)blockIdx.x / kPerJob : 0, bx = (int)blockIdx.x - job * kPerJob;
@@ -982,7 +950,6 @@ __device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_mid(MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __builtin_amdgcn_s_setprio(3);
     const int64_t off = blockIdx.z * A.gstride;
     if ((int)blockIdx.x < A.nfwd) {
         FwdJob J = A.fwd;
@@ -1174,8 +1141,6 @@ __device__ __forceinline__ void head_loss(const shems_ddpg &d, const HeadRegs &R
         __syncthreads();
         if (t == 0) {
             d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
-            reinterpret_cast<unsigned *>(ws + WS_SYNC)[SY_ARRIVE] = 0u;                                // merged K4 + K5 launch that follows: arrivals of K4's workgroups,
-            reinterpret_cast<unsigned *>(ws + WS_SYNC)[SY_FLAG] = 0u;                          // "actor head published" flag
             const float g = red[4] + red[5];
             d.grad_critic[off_b3(CIN, 1)] = g;
             if (fuse) adam_elem(*fuse, off_b3(CIN, 1), g);
@@ -1218,25 +1183,6 @@ __device__ __forceinline__ void head_actor(const shems_ddpg &d, const HeadRegs &
     }
 }
 
-// Merged K4 + K5 launch: the workgroup of K4 that arrives last (all 128 sets of partials are complete and were stored write-through)
-// evaluates the actor head once -- the same head_actor, so the same bits as the separate launches, where every K5 workgroup evaluates
-// it for itself from 33 KB of partials -- and publishes d3 (1 KB, write-through), the loss, gb3 and b3's ADAM step; then it raises
-// the flag K5's workgroups poll.  (K5's 207 workgroups each reading the 33 KB past the caches was measured first: 41 us per update
-// against 35.7 -- the reads of one small region from everywhere queue at the memory side.)
-struct GradArgs;
-__device__ __forceinline__ void qg_last_arriver_impl(const shems_ddpg &dd, const AdamCtx *fz, float *smem, unsigned *sync)
-{
-    float *d3 = smem, *red = smem + AIN * BP;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    HeadRegs hr;
-    head_actor_load(dd, hr, true);
-    head_actor(dd, hr, d3, red, true, fz, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(sync + SY_FLAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    STAMP(3, 11);
-}
-
 // ---- K3 / K5: every gradient block of one network, by batch contractions only -------------------------------------------
 // D2[n][m] = (sum_o W3[n][o] d3[o][m]) * (h2[n][m] > 0) is generated while staging, never stored.
 //   W workgroups (kt, nt): gW2[32 k][32 n] = sum_m h1[k][m] D2[n][m], one 16 x 16 block per wave over the whole batch
@@ -1265,10 +1211,6 @@ __device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
 {
     B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.w3f = gsh(B.w3f, off);
     B.grad = gsh(B.grad, off); B.E0 = gsh(B.E0, off); B.E1 = gsh(B.E1, off); gshift(B.dd, off); gshift(B.c, off);
-}
-__device__ __forceinline__ void qg_last_arriver(const GradArgs &G, float *smem, unsigned *sync)
-{
-    qg_last_arriver_impl(G.dd, G.fuse ? &G.c : nullptr, smem, sync);
 }
 // W tiles are 32 k x 32 n (128 workgroups), G workgroups take 32 rows (16 workgroups).  -DGR_WN=16 builds the finer tiling tried in
 // round 3: W tiles 32 k x 16 n (256 workgroups: two 16 x 16 blocks, waves (w >> 1) pick the block, (w & 1) the batch half, the halves
@@ -1340,13 +1282,9 @@ __device__ __forceinline__ void l1row_wave(const L1Row<IN, OUT> &R, const float 
 }
 
 template <int IN, int OUT>
-__device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const int bx, unsigned *wait_sync = nullptr, unsigned wait_n = 0)
+__device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const int bx)
 {
-    // bx: this workgroup's index within the gradient grid.  wait_sync (merged K4 + K5 launch, actor head only): everything that does
-    // not depend on K4 -- the H2 panel, the ADAM state, the input block, the layer-1 image, the E slabs of the R rows -- is requested
-    // and staged first; then the workgroup waits for the wait_n workgroups of K4 and only then reads what they published.
-    const bool wt = wait_sync != nullptr;
-    (void)wait_n;
+    // bx: this workgroup's index within the gradient grid
     float *Bt = smem;                          // W: [32 n][GR_PS] D2 panel
     float *At = Bt + GR_BT;                    // W: [32 k][GR_PS] h1 panel
     float *xs = At + GR_AT;                    // [12][BP]
@@ -1372,15 +1310,9 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         HeadRegs hr;
         L1Row<IN, OUT> R;
         l1row_load<IN, OUT>(A, min(k, H1N - 1), lane, R);
-        if (wt) {                                              // merged launch: the head was evaluated once, by K4's last workgroup
-            STAMP(kRegion, 10);
-            wait_arrivals(wait_sync + SY_FLAG, 1u, wait_sync + SY_TIMEOUT);
-            d3[tid] = pub_load(A.dd.ws + WS_D3A + tid, true);
-        } else {
-            if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
-        }
+        if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
         STAMP(kRegion, 1);
-        if (!wt) { if (A.head == 1) head_loss(A.dd, hr, d3, red, false, nullptr); else head_actor(A.dd, hr, d3, red, false, nullptr); }
+        if (A.head == 1) head_loss(A.dd, hr, d3, red, false, nullptr); else head_actor(A.dd, hr, d3, red, false, nullptr);
         __syncthreads();
         STAMP(kRegion, 2);
         if (k >= H1N) return;
@@ -1435,16 +1367,12 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         w3v = A.w3f[(nrow0 + (t >> 1)) * OUT + min(o, OUT - 1)];                              // frozen copy: 512 rows, zero padded
     }
     HeadRegs hr;
-    if (!wt) { if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr); }
+    if (A.head == 1) head_loss_load(A.dd, hr); else head_actor_load(A.dd, hr);
     if (is_w) {
         build_x_store<IN>(A.x, xr, xs, false);
         if (tid < 96) *reinterpret_cast<f32x4 *>(w1 + (tid >> 3) * 32 + 4 * (tid & 7)) = wq;
     }
-    if (wt) {                                                  // merged launch: the head (and the publisher's work) was done by K4's last workgroup
-        STAMP(kRegion, 10);
-        wait_arrivals(wait_sync + SY_FLAG, 1u, wait_sync + SY_TIMEOUT);
-        d3[tid] = pub_load(A.dd.ws + WS_D3A + tid, true);
-    } else if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
+    if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
     if (tid < 2 * (GR_WN == 16 ? 16 : 32)) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
     STAMP(kRegion, 1);
     __syncthreads();
@@ -1576,24 +1504,9 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_grad(GradArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __builtin_amdgcn_s_setprio(3);
     gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
     if (A.in == SIN) grad_body<SIN, 2>(A, smem, (int)blockIdx.x); else grad_body<CIN, 1>(A, smem, (int)blockIdx.x);
     dev_arrive(A.sy, false);                       // the published actor copy is stored write-through (AdamCtx::publish): draining is enough
-}
-
-// ---- K4 + K5 in ONE launch (single learner, fused ADAM): workgroups [0, 128) are K4's tiles, the rest K5's gradient workgroups.
-// K5's workgroups are resident from the start (335 workgroups, two fit a CU: checked on the host before this kernel is ever used),
-// so their first burst -- 45 of the 57 KB a W tile stages -- and its exposed latency run UNDER K4, and the K4 -> K5 launch boundary
-// (1.8 us) disappears; what K4 hands over is small (d loss / d a partials 32 KB, a_pi 1 KB, q partials 16 KB) and travels write-through
-// (pub_store / pub_load), so no fence is involved.  Nothing K5 writes (the actor, its target, its moments) is read by K4 except the
-// actor's b3 -- and every K5 workgroup waits for ALL of K4 before it computes, let alone writes, anything.
-constexpr int QG_NWG = NT16 * (BP / 32);
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_qg_grad(FwdArgs F, GradArgs G, unsigned *sync)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < QG_NWG) { qg16_body(F.job[0], smem, (int)blockIdx.x, sync, &G); return; }
-    grad_body<SIN, 2>(G, smem, (int)blockIdx.x - QG_NWG, sync, (unsigned)QG_NWG);
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -1691,38 +1604,6 @@ static int set_lds_attrs()
     if (int rc = lds_optin(m_mid, reinterpret_cast<const void *>(&k_mid), MID_LDS, "attr k_mid")) return rc;
     if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), UPD_LDS, "attr k_grad")) return rc;
     return SHEMS_OK;
-}
-
-// The merged K4 + K5 launch (SHEMS_DDPG_MERGE=1; NOT the default) needs every one of its workgroups resident at once (K5's wait for
-// K4's).  Per device, once: the occupancy the runtime reports for k_qg_grad, capped at the two workgroups per CU its waves_per_eu
-// attribute allows, times the CU count must cover the grid with a margin -- otherwise the two launches stay separate.  Even then the
-// wait is bounded.  Round-3 measurement (profiles/r03_update_merge.txt): correct (every update test green, bit-identical to the
-// separate launches) but 37.0 us per update against 35.6: K5's first burst does run under K4 (3.8 k cycles staged before the wait), but
-// between K4's last tile and K5's resumption lie a write-through drain, the arrival add, the last arriver's 33 KB of past-the-cache
-// loads, its head, another drain, the flag and the poll -- 5 us where the launch boundary it replaces costs 1.8 us + 2 us of staging.
-constexpr int QGG_LDS = QG16_LDS > GR_LDS ? QG16_LDS : GR_LDS;
-constexpr int QGG_GRID = QG_NWG + GR_NW + GR_NG + GR_NR;
-static bool merge_ok()
-{
-    static std::atomic<uint64_t> known{0}, good{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(known.load(std::memory_order_acquire) & bit)) {
-        bool ok = false;
-        const char *e = getenv("SHEMS_DDPG_MERGE");
-        if (e && atoi(e) == 1) {                  // opt-in: measured SLOWER than the two launches (37.0 against 35.6 us per update), see below
-            static std::atomic<uint64_t> optin{0};
-            int nb = 0, cus = 0;
-            if (lds_optin(optin, reinterpret_cast<const void *>(&k_qg_grad), QGG_LDS, "attr k_qg_grad") == SHEMS_OK &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&k_qg_grad), 256, QGG_LDS) == hipSuccess &&
-                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-                ok = (int64_t)(nb < 2 ? nb : 2) * cus >= QGG_GRID + QGG_GRID / 4;          // 335 workgroups + 25 % margin
-        }
-        if (ok) good.fetch_or(bit, std::memory_order_release);
-        known.fetch_or(bit, std::memory_order_release);
-    }
-    return (good.load(std::memory_order_acquire) & bit) != 0;
 }
 
 }  // namespace shems
@@ -1850,11 +1731,6 @@ static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamSca
     g.grad = d->grad_actor; g.E0 = SA + SL_EP; g.E1 = ws + WS_EA1; g.head = 2; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, false, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
     if (last) g.sy = *last;
-    if (fuse && L == 1 && gs == 0 && !last && merge_ok()) {
-        // one replica, ADAM inside the gradient launch: K4 and K5 as ONE launch (k_qg_grad); the arrival counter was zeroed by K3
-        hipLaunchKernelGGL(k_qg_grad, dim3(QGG_GRID), dim3(256), QGG_LDS, st, f, g, reinterpret_cast<unsigned *>(ws + WS_SYNC));
-        return hip_ok(hipGetLastError(), "ddpg actor-side launch (merged)");
-    }
     hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), last ? UPD_LDS : QG16_LDS, st, f);
     hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), last ? UPD_LDS : GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg actor-side launches");
@@ -1893,14 +1769,16 @@ int shems_debug_set_stamps(void *d_buf)
 }
 #endif
 
-/* Merged K4 + K5 launch: how many of its workgroups ever gave up waiting (0 unless the device could not keep the launch resident,
- * e.g. two such launches on two streams at once): copies one word from the workspace, synchronising with `stream`. */
+/* Device-side waits (the pipelined training loop with SHEMS_LOOP_SYNC=device) that gave up since the last call: reads AND clears one
+ * word of the workspace, synchronising with `stream`.  Non-zero = the steps enqueued since then are invalid. */
 int shems_ddpg_sync_timeouts(const shems_ddpg *d, int64_t *out, void *stream)
 {
     if (!d || !d->ws || !out) return set_error(SHEMS_ERR_ARG, "shems_ddpg_sync_timeouts: NULL");
     unsigned v = 0;
-    if (int rc = hip_ok(hipMemcpyAsync(&v, reinterpret_cast<const unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream), "memcpy sync")) return rc;
+    unsigned *w = reinterpret_cast<unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT;
+    if (int rc = hip_ok(hipMemcpyAsync(&v, w, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream), "memcpy sync")) return rc;
     if (int rc = hip_ok(hipStreamSynchronize((hipStream_t)stream), "sync")) return rc;
+    if (v) if (int rc = hip_ok(hipMemsetAsync(w, 0, sizeof v, (hipStream_t)stream), "memset sync")) return rc;
     *out = (int64_t)v;
     return SHEMS_OK;
 }

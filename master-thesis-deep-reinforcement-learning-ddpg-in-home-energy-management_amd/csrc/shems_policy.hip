@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 
@@ -1694,9 +1695,14 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
     if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_actg<TM, NW, NS, RD>), (int)lds, "hipFuncSetAttribute(k_actg)")) return rc;
     const int64_t tiles = (a.m - a.m0 + BM - 1) / BM;
     ActSplit x = {nullptr};
-    if (NS == 2) {
+    if constexpr (NS == 2) {
         if (tiles > kSplitMaxTiles) return set_error(SHEMS_ERR_ARG, "k_actg: %lld env tiles exceed the split form's scratch", (long long)tiles);
-        if (int rc = split_scratch(st, &x)) return rc;
+        if (split_scratch(st, &x) != SHEMS_OK) {
+            // no exchange slab for this (device, stream) -- the 33rd distinct stream of a long-lived process, or hipMalloc failed: the
+            // one-workgroup-per-tile form needs none and writes the same bytes (unless the caller asked for THIS form's LDS footprint)
+            if (a.force_split || a.sy.wait_flags || a.sy.arrive_count) return SHEMS_ERR_ARG;      // (message set by split_scratch)
+            return launch_actg<1, 8, 1, RD>(a, st);
+        }
     }
     hipLaunchKernelGGL((k_actg<TM, NW, NS, RD>), dim3((unsigned)(tiles * NS)), dim3(64 * NW), lds, st, a, x);
     return hip_ok(hipGetLastError(), "k_actg launch");
@@ -1784,6 +1790,29 @@ int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks)
     if (n_envs <= 0 || !out_blocks) return set_error(SHEMS_ERR_ARG, "shems_act_step_grid: bad arguments");
     const int bm = act_tile_envs(n_envs);
     *out_blocks = (n_envs + bm - 1) / bm;
+    return SHEMS_OK;
+}
+
+/* Which kernel shems_act_step_dev / shems_act_step_group_dev dispatches for n_envs envs (grouped != 0: a learner group), as the
+ * profiler prints it: the same decisions as dispatch_act, environment overrides included. */
+int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
+{
+    if (n_envs <= 0 || !out || cap < 2) return set_error(SHEMS_ERR_ARG, "shems_act_step_kernel: bad arguments");
+    static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    const int form = act_form(), form4 = act_form4();
+    const char *name;
+    if (form4 == 2 && ((form < 0 && n_envs > 8192 && !grouped) || form == 12)) name = "shems::k_act2";
+    else {
+        const int tm = pick_tm(n_envs);
+        if (tm == 4) name = nw == 8 ? "shems::k_act<4, 8, 0>" : form4 == 0 ? "shems::k_act<4, 4, 0>" : "shems::k_act<4, 4, 2>";
+        else if (tm == 2) name = form == 0 || form4 == 0 ? "shems::k_act<2, 4, 0>" : "shems::k_act<2, 4, 2>";
+        else if (form == 0) name = "shems::k_act<1, 4, 0>";
+        else if (form == 2) name = "shems::k_act<1, 4, 2>";
+        else if (form == 3) name = "shems::k_act<1, 4, 3>";
+        else if (form == 8 || (form != 9 && n_envs > 128 * 32)) name = "shems::k_actg<1, 8, 1, 3>";
+        else name = "shems::k_actg<1, 4, 2, 3>";
+    }
+    snprintf(out, (size_t)cap, "%s", name);
     return SHEMS_OK;
 }
 

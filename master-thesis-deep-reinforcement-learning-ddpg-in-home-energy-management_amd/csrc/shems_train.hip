@@ -175,6 +175,7 @@ int check_loop(const shems_train_loop *L, void *stream, void *stream2)
                 return set_error(SHEMS_ERR_ARG, "shems_train_steps: ADAM beta powers must lie in (0, 1)");
         if (L->act.actor != L->ddpg.actor) return set_error(SHEMS_ERR_ARG, "shems_train_steps: act.actor must be the learner's actor (ddpg.actor)");
     }
+    if (L->dp && L->mode != SHEMS_LOOP_ORDERED) return set_error(SHEMS_ERR_ARG, "shems_train_steps: data-parallel replicas run in program order");
     if (L->mode != SHEMS_LOOP_ORDERED) {
         if (L->updates_per_step < 1) return set_error(SHEMS_ERR_ARG, "shems_train_steps: a pipelined mode needs updates_per_step >= 1");
         if (!L->actor_pub[0] || !L->actor_pub[1] || L->actor_pub[0] == L->actor_pub[1])
@@ -301,7 +302,11 @@ int shems_train_steps(shems_train_loop *L, int64_t k, void *stream, void *stream
             const bool last = u == L->updates_per_step - 1;
             const bool excl = L->mode == SHEMS_LOOP_PIPELINED && use_ring;
             float *pub = (L->mode != SHEMS_LOOP_ORDERED && last) ? L->actor_pub[(t + 1) & 1] : nullptr;
-            if (int rc = shems_ddpg_update(&L->ddpg, &L->ring, ring_len, L->sample_seed, (uint32_t)(L->updates & 0xFFFFFFFFll),
+            if (L->dp) {                                          // replicas: the split form with both all-reduces in this stream
+                if (int rc = shems_ddpg_update_dp(&L->ddpg, &L->ring, ring_len, L->sample_seed, (uint32_t)(L->updates & 0xFFFFFFFFll), 0, 0,
+                                                  L->eta_crit, L->bp_crit[0], L->bp_crit[1], L->eta_act, L->bp_act[0], L->bp_act[1], nullptr, L->dp, U))
+                    return rc;
+            } else if (int rc = shems_ddpg_update(&L->ddpg, &L->ring, ring_len, L->sample_seed, (uint32_t)(L->updates & 0xFFFFFFFFll),
                                            excl ? w.pos : 0, excl ? w.count : 0, L->eta_crit, L->bp_crit[0], L->bp_crit[1], L->eta_act,
                                            L->bp_act[0], L->bp_act[1], pub, U))
                 return rc;

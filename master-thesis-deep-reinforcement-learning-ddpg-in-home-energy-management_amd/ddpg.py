@@ -65,7 +65,7 @@ class TrainLoop(C.Structure):          # shems_train_loop: the hour loop of epis
                 ("t", C.c_int64), ("updates", C.c_int64), ("env_seed", C.c_uint64), ("sample_seed", C.c_uint64),
                 ("episode", C.c_uint32), ("ep_len", C.c_int32), ("updates_per_step", C.c_int32), ("mode", C.c_int32),
                 ("eta_crit", C.c_double), ("bp_crit", C.c_double * 2), ("eta_act", C.c_double), ("bp_act", C.c_double * 2),
-                ("sync", C.c_void_p)]
+                ("sync", C.c_void_p), ("dp", C.c_void_p)]
 
 
 LOOP_ORDERED, LOOP_PIPELINED, LOOP_PIPELINED_EXACT = 0, 1, 2
@@ -81,6 +81,9 @@ def _declare():
     L.shems_train_loop_release.argtypes = [C.POINTER(TrainLoop)]
     L.shems_act_step_range_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), i64, i64, vp, C.POINTER(_capi.Replay),
                                            C.POINTER(RingWindow), vp]
+    L.shems_ddpg_update_dp.argtypes = [C.POINTER(DdpgArgs), C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+    L.shems_ddpg_update_dp.restype = C.c_int
     for fn in ("shems_train_steps", "shems_train_loop_join", "shems_train_loop_release", "shems_act_step_range_dev"):
         getattr(L, fn).restype = C.c_int
     L.shems_actor_forward_dev.argtypes = [C.POINTER(ActParams), vp, i64, vp, vp]
@@ -90,6 +93,8 @@ def _declare():
     L.shems_act_step_dev.restype = C.c_int
     L.shems_act_step_grid.argtypes = [i64, C.POINTER(i64)]
     L.shems_act_step_grid.restype = C.c_int
+    L.shems_act_step_kernel.argtypes = [i64, C.c_int, C.c_char_p, C.c_int32]
+    L.shems_act_step_kernel.restype = C.c_int
     PD = C.POINTER(DdpgArgs)
     L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
     L.shems_ddpg_sync_timeouts.argtypes = [PD, C.POINTER(i64), vp]
@@ -137,6 +142,20 @@ def _declare():
         getattr(L, fn).restype = C.c_int
     L._ddpg_declared = True
     return L
+
+
+def act_kernel_name(n_envs, grouped=False):
+    """The kernel the fused-step dispatcher runs for n_envs envs, by its profiler name (shems_act_step_kernel: the dispatcher's own
+    decision, environment overrides included) -- bench.py's roofline.kernel."""
+    buf = C.create_string_buffer(96)
+    _capi.check(_declare().shems_act_step_kernel(int(n_envs), 1 if grouped else 0, buf, 96))
+    return buf.value.decode()
+
+
+def act_algorithmic_bytes(n_envs, inserted):
+    """HBM bytes one fused vector step has to move: 92 B per env-step (obs 36 + action 8 + idx 4 in, obs' 36 +
+    reward 4 + idx 4 out), the actor's parameter block once, 85 B per transition pushed into the ring."""
+    return 92 * int(n_envs) + 4 * N_ACTOR + 85 * int(inserted)
 
 
 # ----------------------------------------------------------- host Philox --
@@ -356,6 +375,11 @@ class Agent:
         """actor / critic: flat Flux-layout vectors, either of this learner's network size (padded here) or already in the (250, 500)
         layout."""
         t = self.torch
+        for name, vec, n_lay, n_own in (("actor", actor, self.n_actor, net_size(STATE, ACTION, self.hidden)),
+                                        ("critic", critic, self.n_critic, net_size(STATE + ACTION, 1, self.hidden))):
+            if vec is not None and np.asarray(vec).size not in (n_lay, n_own):
+                raise ValueError(f"set_params: {name} has {np.asarray(vec).size} parameters; a {self.hidden} network holds {n_own}"
+                                 + ("" if n_lay == n_own else f" ({n_lay} in the kernels' padded layout)"))
         if actor is not None and np.asarray(actor).size != self.n_actor:
             actor = pad_net(actor, STATE, ACTION, self.hidden)
         if critic is not None and np.asarray(critic).size != self.n_critic:
@@ -563,9 +587,10 @@ class Agent:
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
-    def enable_data_parallel(self, dist):
-        """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL."""
-        self.sync = GradSync(dist)
+    def enable_data_parallel(self, dist, native=None):
+        """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL.  native: a shems_dp communicator
+        (parallel.native_comm) -- the all-reduces then run in the update's own stream, from native code."""
+        self.sync = GradSync(dist, native=native)
         self.sync.broadcast(self.actor, self.critic, self.actor_t, self.critic_t)   # identical initial weights
 
     def _allreduce(self, g):
@@ -594,6 +619,17 @@ class Agent:
             self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
             self.updates += 1
             return
+        if self.sync.native is not None and self.sync.world > 1 and self.noise_type != "pn" and not self.wide:
+            # replicas with a native communicator: the split form and both all-reduces in ONE call, everything in this stream
+            d.flags = 0                             # (no deferred E products: nothing runs beside an in-stream exchange)
+            _capi.check(self.L.shems_ddpg_update_dp(C.byref(d), C.byref(rs), len(ring), self.rng_seed, int(tick) & 0xFFFFFFFF, ex_pos, ex_cnt,
+                                                    self.eta_crit, self.bp_critic[0], self.bp_critic[1], self.eta_act, self.bp_actor[0],
+                                                    self.bp_actor[1], C.c_void_p(publish.data_ptr()) if publish is not None else None,
+                                                    self.sync.native, st))
+            self.bp_critic = [self.bp_critic[0] * 0.9, self.bp_critic[1] * 0.999]
+            self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
+            self.updates += 1
+            return
         self._critic_grad_ex(d, rs, len(ring), tick, ex_pos, ex_cnt, st)
         if self.noise_type == "pn":                # DDPG.jl:126-128 (the actor is still the pre-update one here)
             self.adapt_param_noise_(ring, tick)
@@ -617,8 +653,8 @@ class Agent:
         self.updates += 1
 
     def sync_timeouts(self):
-        """Workgroups of the merged K4 + K5 launch that ever gave up their (bounded) wait on this learner's workspace: 0 in every
-        supported use (shems_ddpg_sync_timeouts).  Synchronises the stream."""
+        """Device-side waits of the pipelined training loop (shems_train_steps with SHEMS_LOOP_SYNC=device) that gave up on this learner's
+        workspace since the last call: 0 in every supported use (shems_ddpg_sync_timeouts; read and cleared).  Synchronises the stream."""
         if self.wide:
             return 0                                   # the wide path has no in-launch wait
         d = self._ddpg_args()
@@ -767,7 +803,9 @@ class TrainWorkload:
         self.hidden = (int(hidden[0]), int(hidden[1]))       # other than (250, 500): another point of the reference's grids (bench.py --hidden)
         self.agent = Agent(seed=1231, rng_seed=self.env_seed, hidden=self.hidden)   # same initial weights on every rank (config: seed 1231)
         if dist is not None:
-            self.agent.enable_data_parallel(dist)
+            from .parallel import native_comm
+            import sys
+            self.agent.enable_data_parallel(dist, native=None if self.agent.wide else native_comm(dist, log=lambda m: print(m, file=sys.stderr, flush=True)))
             import os
             if os.environ.get("SHEMS_DP_OVERLAP") in ("0", "1"):   # A/B knob: "1" = the critic's all-reduce asynchronous, under the actor's E products
                 self.agent.dp_overlap = os.environ["SHEMS_DP_OVERLAP"] == "1"
@@ -779,7 +817,7 @@ class TrainWorkload:
         self.t = 0
         self.episode = 1
         self.env.reset_(self.env_seed, episode=self.episode)
-        native_ok = dist is None and not self.agent.wide and self.agent.noise_type != "pn" and self.agent.batch <= self.agent.MAX_PASS_BATCH
+        native_ok = (dist is None or self.agent.sync.world == 1 or self.agent.sync.native is not None) and not self.agent.wide and self.agent.noise_type != "pn" and self.agent.batch <= self.agent.MAX_PASS_BATCH
         if loop is None:
             loop = "native" if native_ok else "host"
         if loop == "native" and not native_ok:
@@ -828,6 +866,7 @@ class TrainWorkload:
             L.window, L.env_seed, L.sample_seed = self.win, self.env_seed, ag.rng_seed
             L.ep_len, L.updates_per_step, L.mode = self.EP_LEN, self.updates, self.overlap_mode
             L.eta_crit, L.eta_act = ag.eta_crit, ag.eta_act
+            L.dp = ag.sync.native if ag.sync.world > 1 else None
             self._native = L
         L = self._native
         L.ring_pushed, L.t, L.updates, L.episode = self.ring.pushed, self.t, ag.updates, self.episode
@@ -886,7 +925,7 @@ class TrainWorkload:
             _capi.check(self.agent.L.shems_train_loop_release(C.byref(self._native)))
         self.env.check_error()
         if self.agent.sync_timeouts():
-            raise RuntimeError("the merged K4 + K5 launch gave up a wait: its workgroups were not all resident")
+            raise RuntimeError("a device-side wait of the pipelined loop gave up: the steps since the last check are invalid")
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
             raise RuntimeError("non-finite network parameters after the timed steps")
 
@@ -945,10 +984,17 @@ class TrainWorkload:
                 loc_avg = time_launches(torch, updates_only, reps)[0] if self.updates else 0.0
                 self.agent.sync = sync
                 gc, ga = torch.zeros_like(self.agent.grad_critic), torch.zeros_like(self.agent.grad_actor)
+                if sync.native is not None:         # the exchange as the update issues it: RCCL in this stream, from native code
+                    Lc = self.agent.L
+                    Lc.shems_dp_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+                    Lc.shems_dp_allreduce_sum.restype = C.c_int
+                    ar = lambda g: _capi.check(Lc.shems_dp_allreduce_sum(sync.native, C.c_void_p(g.data_ptr()), g.numel(), self.agent._stream()))
+                else:
+                    ar = sync.sum_
                 for g in (gc, ga):
-                    sync.sum_(g)
-                ar_c = time_launches(torch, lambda i: sync.sum_(gc), 64)[0]
-                ar_a = time_launches(torch, lambda i: sync.sum_(ga), 64)[0]
+                    ar(g)
+                ar_c = time_launches(torch, lambda i: ar(gc), 64)[0]
+                ar_a = time_launches(torch, lambda i: ar(ga), 64)[0]
                 fig = torch.tensor([step_avg, step_med, upd_avg, upd_med, loc_avg, ar_c, ar_a], dtype=torch.float64, device=self.agent.device)
                 sync.dist.all_reduce(fig, op=sync.dist.ReduceOp.MAX)
                 step_avg, step_med, upd_avg, upd_med, loc_avg, ar_c, ar_a = (float(x) for x in fig.tolist())
@@ -965,9 +1011,11 @@ class TrainWorkload:
         self.step_us_in_pass = step_avg
         h1, h2 = self.hidden
         flops = 2 * (9 * h1 + h1 * h2 + h2 * 2) * self.n                     # 256 500 FLOP / env-step at (250, 500)
-        kname = "shems::k_wgemm x3 + k_act_tail (wide network, csrc/shems_wide.hip)" if self.agent.wide else "shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)"
+        kname = "shems::k_wgemm x3 + k_act_tail (wide network, csrc/shems_wide.hip)" if self.agent.wide else act_kernel_name(self.n)
         return dict(kernel=kname, avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
+                    algorithmic_bytes=None if self.agent.wide else act_algorithmic_bytes(self.n, self.win),
+                    avg_us_is="vector step minus replay(): the fused launch together with the gap in front of it, not a timing of the kernel alone (rocprofv3's per-kernel average in profiles/ is the cross-check)",
                     method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
                            + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))
 
@@ -976,8 +1024,11 @@ class TrainWorkload:
         crc = zlib.crc32(self.agent.actor.detach().cpu().numpy().tobytes()) ^ zlib.crc32(self.agent.critic_t.detach().cpu().numpy().tobytes())
         return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": self.mem_size,
                 "replay_mode": "scaled (capacity 72 N, every env inserts)" if self.scaled_replay else "window (MEM_SIZE = 24 000, 333 envs insert per step)",
-                "overlap": self.overlap,
+                "overlap": {LOOP_ORDERED: False, LOOP_PIPELINED: "pipelined", LOOP_PIPELINED_EXACT: "exact"}[self.overlap_mode],
+                "loop": self.loop,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
+                "dp_exchange": None if self.agent.sync.world == 1 else ("RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)"
+                                                                       if self.agent.sync.native is not None else "torch.distributed all_reduce (its own stream)"),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8 if self.hidden == (L1, L2) else 20 * (10 * self.hidden[0] + self.hidden[0] * self.hidden[1] + 1.5 * self.hidden[1]) * BATCH_SIZE / 1e6,
                 "hidden": list(self.hidden), "data_parallel": getattr(self, "dp", None)}

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from .ddpg import (ACTION, BATCH_SIZE, MEM_SIZE, N_ACTOR, N_CRITIC, NOISE_SIGMA, STATE, Agent, RingWindow, _declare)
+from .ddpg import (ACTION, BATCH_SIZE, MEM_SIZE, N_ACTOR, N_CRITIC, NOISE_SIGMA, STATE, Agent, RingWindow, _declare, act_kernel_name)
 from .replay import ReplayRing
 
 
@@ -244,7 +244,7 @@ class GroupWorkload:
         torch.cuda.synchronize()
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
-        return dict(kernel="shems::k_act2 (> 8192 envs) | k_actg (<= 8192) | k_act (learner groups)", avg_us=avg_us, median_us=med_us, launches=reps,
+        return dict(kernel=act_kernel_name(self.n, grouped=True), avg_us=avg_us, median_us=med_us, launches=reps,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
 
     def extra(self):

@@ -186,6 +186,18 @@ def _check_supported(cfg):
         raise NotImplementedError(f"JOB_ID {cfg.job_id} selects (L1, L2) = ({cfg.L1}, {cfg.L2})")
     if not 1 <= cfg.BATCH_SIZE <= 1024:             # above 128: replay() runs the gradient passes per sub-batch (ddpg.Agent._replay_wide)
         raise NotImplementedError(f"JOB_ID {cfg.job_id} selects BATCH_SIZE = {cfg.BATCH_SIZE}")
+    if cfg.noise_type not in ("gn", "ou", "en", "pn"):
+        raise NotImplementedError(f"JOB_ID {cfg.job_id} selects noise_type = {cfg.noise_type!r} (DDPG.jl:152-161 knows gn, ou, en, pn)")
+    if cfg.noise_type == "pn":
+        # parameter noise adds one scalar to EVERY parameter (DDPG.jl:89-96): it would un-zero the padding a smaller network runs with,
+        # and its adaptation step reads the minibatch of ONE update pass (128 columns) -- refuse here, before populate_memory, not at the
+        # first replay()
+        from .ddpg import L1 as _L1, L2 as _L2, is_wide
+        if (cfg.L1, cfg.L2) != (_L1, _L2) and not is_wide((cfg.L1, cfg.L2)):
+            raise NotImplementedError(f"JOB_ID {cfg.job_id} selects parameter noise with (L1, L2) = ({cfg.L1}, {cfg.L2}): a network smaller than "
+                                      f"({_L1}, {_L2}) runs zero-padded, which parameter noise would break")
+        if cfg.BATCH_SIZE > 128:
+            raise NotImplementedError(f"JOB_ID {cfg.job_id} selects parameter noise with BATCH_SIZE = {cfg.BATCH_SIZE} > 128 (adapt_param_noise! on sub-batches)")
 
 
 def data_path(cfg, split, data_dir="data", charger=None):

@@ -19,13 +19,85 @@ def shard_envs(total_envs, rank, world):
     return offset, count
 
 
-class GradSync:
-    """Keeps learner replicas identical.  `dist` is `torch.distributed` (initialised) or None."""
+def native_comm(dist, timeout_s=120.0, log=None):
+    """A shems_dp communicator (RCCL called in the update's own stream from native code, csrc/shems_dp.hip) for the ranks of `dist`, or
+    None when it cannot be had -- then the caller keeps torch.distributed's all_reduce.  Collective: every rank calls it.
 
-    def __init__(self, dist=None):
+    Rank 0 draws the 128-byte id and torch.distributed broadcasts it; ncclCommInitRank runs in a helper thread so that a rendezvous that
+    never completes cannot hang the job (the thread is abandoned after `timeout_s`); the ranks then agree (MIN over a flag) whether ALL of
+    them have a communicator and a tiny all-reduce through it gave the right sum -- one rank without it and everybody falls back.
+    SHEMS_DP=torch skips the attempt."""
+    import ctypes as C
+    import os
+    import threading
+    import torch
+    from . import _capi
+    if dist is None or not dist.is_initialized() or dist.get_world_size() < 1:
+        return None
+    if os.environ.get("SHEMS_DP", "native") == "torch":
+        return None
+    L = _capi.lib()
+    L.shems_dp_unique_id.argtypes = [C.c_char_p]
+    L.shems_dp_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.shems_dp_destroy.argtypes = [C.c_void_p]
+    L.shems_dp_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    for fn in ("shems_dp_unique_id", "shems_dp_create", "shems_dp_destroy", "shems_dp_allreduce_sum"):
+        getattr(L, fn).restype = C.c_int
+    rank, world = dist.get_rank(), dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    buf = C.create_string_buffer(128)
+    ok = 1.0
+    if rank == 0 and L.shems_dp_unique_id(buf) != 0:
+        ok = 0.0
+    idt = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev)
+    dist.broadcast(idt, src=0)
+    flag = torch.tensor([ok], device=dev)
+    dist.broadcast(flag, src=0)
+    handle = C.c_void_p()
+    state = {"rc": None}
+    if float(flag.item()) > 0.5:
+        idb = bytes(idt.cpu().tolist())
+        cur = torch.cuda.current_device()
+
+        def init():
+            torch.cuda.set_device(cur)
+            state["rc"] = L.shems_dp_create(idb, rank, world, C.byref(handle))
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(timeout_s)
+    mine = 1.0 if state["rc"] == 0 and handle.value else 0.0
+    if mine:
+        # self-test: sum of (rank + 1) over the replicas through the new communicator
+        t = torch.full((1024,), float(rank + 1), dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        if L.shems_dp_allreduce_sum(handle, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st)) != 0:
+            mine = 0.0
+        else:
+            torch.cuda.synchronize()
+            mine = 1.0 if bool((t == world * (world + 1) / 2).all()) else 0.0
+    vote = torch.tensor([mine], device=dev)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if float(vote.item()) < 0.5:
+        if log:
+            log(f"rank {rank}: no native RCCL communicator ({L.shems_last_error().decode('utf-8', 'replace') if not mine else 'another rank failed'}): "
+                "gradients go through torch.distributed")
+        if handle.value and state["rc"] == 0:
+            L.shems_dp_destroy(handle)
+        return None
+    return handle
+
+
+class GradSync:
+    """Keeps learner replicas identical.  `dist` is `torch.distributed` (initialised) or None.  `native`: a shems_dp communicator
+    (native_comm) -- the gradient all-reduces of replay() are then RCCL calls in the update's own stream, issued from native code
+    (shems_ddpg_update_dp / shems_train_steps), and torch.distributed only carries the rendezvous, the broadcasts and the scalars."""
+
+    def __init__(self, dist=None, native=None):
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
+        self.native = native
 
     @property
     def grad_scale(self):

@@ -33,6 +33,20 @@ def test_bench_json_contract_small():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 1e6 and d["updates_per_sec"] > 100
+    # the line says what ran: ONE kernel name (the dispatcher's), the bytes the launch has to move, what kernel_avg_us is, and where the
+    # wall time went (HBM rate / traffic ratio only where committed counters exist for this size: 65 536 envs)
+    assert r["kernel"] == "shems::k_actg<1, 8, 1, 3>" and "|" not in r["kernel"]
+    assert r["algorithmic_bytes"] == 92 * 8192 + 4 * 129002 + 85 * 333 and "hbm_gbs" in r and "traffic_ratio" in r
+    assert "minus replay" in r["kernel_avg_us_is"]
+    assert d["gpu_section_s"] > 0 and d["roofline_pass_s"] > 0 and d["cpu_baseline_s"] == 0.0
+    assert d["overlap"] is False and d["loop"] == "native"
+
+
+def test_bench_kernel_name_follows_the_dispatcher():
+    import importlib
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    assert D.act_kernel_name(65536) == "shems::k_act2" and D.act_kernel_name(4096) == "shems::k_actg<1, 4, 2, 3>"
+    assert D.act_kernel_name(8192) == "shems::k_actg<1, 8, 1, 3>" and D.act_kernel_name(65536, grouped=True) == "shems::k_act<4, 4, 2>"
 
 
 def test_bench_scaled_replay_mode():
@@ -81,6 +95,9 @@ def _check_data_parallel_fields(d, world):
     # (gloo on one device is host-synchronous: a 700 us update next to a 25 us k_act -- the difference of two such group times is
     # noise here and may come out below zero; on RCCL the collectives are stream-ordered and it is the k_act time at the shard size)
     assert abs(d["update_us"] - dp["update_us_dp"]) < 1e-6 and abs(d["roofline"]["kernel_avg_us"]) < 1e4
+    # round 4: how the gradients travel.  Two ranks on ONE device cannot have an RCCL communicator ("Duplicate GPU detected"), so the
+    # rehearsal must have fallen back -- on every rank, by vote -- to torch.distributed, and the line says which path ran
+    assert d["dp_exchange"].startswith("torch.distributed") and d["loop"] == "host"
 
 
 def test_bench_starts_its_own_ranks_without_torchrun():
@@ -131,3 +148,6 @@ def test_rccl_stream_ordering_on_a_one_rank_group():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["backend"] == "nccl"
     assert d["async_overlap"] == d["in_order"] == d["no_collective"], d
+    # round 4: the native exchange (RCCL in the update's own stream, csrc/shems_dp.hip) on a one-rank communicator = a single replica
+    assert d["native_communicator"] is True
+    assert d["native_host_loop"] == d["native_native_loop"] == d["single_replica"], d

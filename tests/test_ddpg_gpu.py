@@ -289,32 +289,3 @@ def test_other_batch_sizes_match_oracle(B):
     rs = ring.struct()
     with pytest.raises(S.ShemsError):
         S._capi.check(ag.L.shems_ddpg_critic_grad_ex(C.byref(d), C.byref(rs), len(ring), 1, 5, 0, 0, ag._stream()))
-
-
-def test_merged_actor_side_launch_is_bit_identical_to_the_two_launches():
-    """SHEMS_DDPG_MERGE=1 (opt-in, measured slower: profiles/r03_update_merge.txt) runs K4 and K5 of replay() as one launch whose second
-    half waits, bounded, for the first.  Same functions, same order of additions -> the learner must end up with the same bytes as the
-    default two launches, and no workgroup may have given up its wait.  Child processes: the knob is read once."""
-    import os, subprocess, sys
-    script = r"""
-import sys, zlib, importlib
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import util as U, torch
-S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg")
-wl = D.TrainWorkload(S, torch, 2048, seed=11, updates=1)
-for _ in range(12):
-    wl.step()
-wl.finish()
-a = wl.agent
-crc = 0
-for t in (a.actor, a.critic, a.actor_t, a.critic_t, a.m_actor, a.v_actor, a.m_critic, a.v_critic, a.losses):
-    crc = zlib.crc32(t.detach().cpu().numpy().tobytes(), crc)
-print("MERGE", crc, a.sync_timeouts())
-""" % (U.ROOT, os.path.join(U.ROOT, "tests"))
-    got = {}
-    for knob in ("0", "1"):
-        e = dict(os.environ); e["SHEMS_DDPG_MERGE"] = knob
-        r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got[knob] = [ln for ln in r.stdout.splitlines() if ln.startswith("MERGE")][-1].split()[1:]
-    assert got["0"] == got["1"] and got["1"][1] == "0", got

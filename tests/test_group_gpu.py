@@ -20,10 +20,18 @@ def _mods():
     return torch, S, D, G
 
 
-def _setup(L=3, E=256, cap=2400):
+def _setup(L=3, E=256, cap=2400, mixed=False):
     torch, S, D, G = _mods()
-    tab = S.tables.synthetic_table("train", 98)
-    env = S.ShemsBatch(L * E, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    if mixed:                                       # the thesis grid: learner l trains on charger profile l mod 10 (ids 1-9, 98; LU1:47-58)
+        ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
+        tabs = [S.tables.synthetic_table("train", c) for c in ids]
+        row0 = np.cumsum([0] + [t.shape[0] for t in tabs])
+        cfgs = [S.make_config(c, row0[k], tabs[k].shape[0]) for k, c in enumerate(ids)]
+        co = ((np.arange(L * E) // E) % len(ids)).astype(np.uint16)
+        env = S.ShemsBatch(L * E, 72, tabs, cfgs, co).use_torch_stream()
+    else:
+        tab = S.tables.synthetic_table("train", 98)
+        env = S.ShemsBatch(L * E, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
     grp = G.LearnerGroup(L, E, seed=21, rng_seed=77, capacity=cap)
     grp.populate_memory(env, seed=5)
     grp.min_max_buffer()
@@ -44,9 +52,12 @@ def test_learners_are_independent_and_populated():
         assert float((ag.s_max - ag.s_min).max()) > 0.5
 
 
-@pytest.mark.parametrize("L,E", [(3, 256), (8, 128)])       # 8 learners: the grouped update switches to its wider forward tile
-def test_group_step_and_update_match_single_learner_calls_bitwise(L, E):
-    torch, S, D, G, env, grp = _setup(L=L, E=E)
+# 8 learners: the grouped update switches to its wider forward tile; (40, 128, mixed): the thesis protocol's shape -- 40 seeds, each on one
+# of the 10 charger profiles (RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87 runs 40 seeds x 10 chargers = 400 learners; bench.py
+# --mode group --learners 400 --envs 51200 --mixed is that width, profiles/r04_group400_bench.json)
+@pytest.mark.parametrize("L,E,mixed", [(3, 256, False), (8, 128, False), (40, 128, True)])
+def test_group_step_and_update_match_single_learner_calls_bitwise(L, E, mixed):
+    torch, S, D, G, env, grp = _setup(L=L, E=E, mixed=mixed)
     L, E, n = grp.count, grp.envs_per_learner, grp.n_envs
     snap = grp.slab.clone()
     st0, idx0, step0 = env.state, env.idx, env.step
@@ -80,8 +91,7 @@ def test_group_step_and_update_match_single_learner_calls_bitwise(L, E):
     for name, (off, cnt) in grp.layout.items():
         # bit patterns, not float values: the workspace keeps int32 ring slots (-1 for the 8 pad columns reads as NaN)
         if name == "ws":
-            cnt -= 96        # the workspace ends with the 96 bookkeeping words of the merged K4 + K5 launch (arrival counter, timeouts):
-                             # the single-learner update runs merged, a group's does not -- they are not results
+            cnt -= 96        # the workspace ends with 96 bookkeeping words (timeout count of the pipelined loop's device-side waits): not results
         assert torch.equal(grp.slab[:, off:off + cnt].contiguous().view(torch.int32), slab_g[:, off:off + cnt].contiguous().view(torch.int32)), name
     env.check_error()
 

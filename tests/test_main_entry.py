@@ -40,6 +40,37 @@ def test_job_id_decoding_and_case_string():
     assert c4.case.startswith("Charger98_disw2_pen0.5_BATCH120_MEM24000_ou-noise_om0.2_th0.2_Y0.99_tau0.001_nact0.0001_ncrit0.001_smart-trainEP")
 
 
+def test_unsupported_parameter_noise_jobs_are_refused_before_anything_runs():
+    """noise_type "pn" (DDPG.jl:74-96) cannot run on a zero-padded smaller network nor with BATCH_SIZE > 128: both used to surface only
+    partway through a job (Agent.__init__ / the first replay()); _check_supported names the JOB_ID up front.  The templates themselves
+    never select "pn" (tuned: "gn", input.jl: "ou"); a caller building the RunConfig can."""
+    import dataclasses
+    c = M.config_from_env({"JOB_ID": "1179808", "TASK_ID": "1", "GPU_ID": "0"})
+    ok = dataclasses.replace(c, noise_type="pn")
+    M._check_supported(ok)                                                   # (250, 500), BATCH 120: runs
+    M._check_supported(dataclasses.replace(c, noise_type="pn", L1=300, L2=600))   # the wide path carries parameter noise
+    for bad, word in ((dataclasses.replace(c, noise_type="pn", L1=200, L2=400), "zero-padded"), (dataclasses.replace(c, noise_type="pn", BATCH_SIZE=150), "BATCH_SIZE = 150"),
+                      (dataclasses.replace(c, noise_type="xx"), "noise_type")):
+        with pytest.raises(NotImplementedError) as ei:
+            M._check_supported(bad)
+        assert "1179808" in str(ei.value) and word in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_set_params_refuses_a_vector_of_the_wrong_size():
+    pytest.importorskip("torch")
+    D = importlib.import_module(U.PKG_NAME + ".ddpg")
+    for hidden in ((250, 500), (200, 400), (300, 600)):
+        ag = D.Agent(seed=1, hidden=hidden)
+        n = D.net_size(9, 2, hidden)
+        ag.set_params(actor=np.zeros(n, np.float32))
+        with pytest.raises(ValueError) as ei:
+            ag.set_params(actor=np.zeros(n - 1, np.float32))
+        assert "set_params" in str(ei.value) and str(n) in str(ei.value)
+        with pytest.raises(ValueError):
+            ag.set_params(critic=np.zeros(7, np.float32))
+
+
 @pytest.mark.gpu
 def test_entry_script_runs_mains_order_and_writes_the_reference_files(tmp_path):
     torch = pytest.importorskip("torch")

@@ -145,3 +145,32 @@ def test_train_loop_refuses_bad_records():
     S._capi.check(wl.agent.L.shems_train_steps(C.byref(L), 0, st, None))   # k = 0: nothing
     wl.steps(3)                                                            # the record is still usable
     wl.finish()
+
+
+def test_pipelined_modes_refuse_a_wide_network():
+    """a pipelined step used to hand the tuned kernel a clone of a (300, 600) actor in the wide layout (silently wrong
+    actions).  Pipelined modes run the tuned kernels only."""
+    torch, S, D = _mods()
+    for ov in ("pipelined", "exact"):
+        with pytest.raises(NotImplementedError):
+            D.TrainWorkload(S, torch, 1024, seed=3, updates=1, overlap=ov, hidden=(300, 600))
+    wl = D.TrainWorkload(S, torch, 1024, seed=3, updates=1, hidden=(300, 600))      # ordered: runs (host loop: the wide path has its own entry points)
+    assert wl.loop == "host"
+    wl.steps(3)
+    wl.finish()
+
+
+def test_fused_step_on_more_than_32_streams():
+    """the two-workgroups-per-tile form keeps one exchange slab per (device, stream) in a 32-entry table; the 33rd stream
+    used to fail every launch of <= 4 096 envs for the rest of the process.  It now runs the one-workgroup-per-tile form (same bytes)."""
+    torch, S, D = _mods()
+    ag = D.Agent(seed=2)
+    obs = torch.rand((300, 9), device="cuda")
+    ref = ag.act(obs, train=False)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            out = ag.act(obs, train=False)
+        st.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))

@@ -38,8 +38,7 @@ for _ in range(nrep):
 S._capi.check(L.shems_debug_set_stamps(None))
 
 names = ["K1 k_fwd x3", "K2 k_mid", "K3 k_grad critic", "K4 k_fwd QG", "K5 k_grad actor"]
-MERGED = os.environ.get("SHEMS_DDPG_MERGE", "1") != "0"      # K4 + K5 in one launch: K5's workgroup ids start at 128
-k5 = (lambda w: w - 128) if MERGED else (lambda w: w)
+k5 = lambda w: w                                  # (round 3's merged K4 + K5 launch, whose K5 ids started at 128, was removed in round 4)
 roles = {0: lambda w: "tile" if (w % 70) < 64 else "duty", 1: lambda w: "fwd" if w < 64 else "E", 2: lambda w: "W" if w < 128 else "G" if w < 144 else "R",
          3: lambda w: "tile", 4: lambda w: "W" if k5(w) < 128 else "G" if k5(w) < 144 else "R"}
 out = {}
