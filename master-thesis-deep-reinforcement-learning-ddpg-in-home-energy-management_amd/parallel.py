@@ -56,26 +56,32 @@ def native_comm(dist, timeout_s=120.0, log=None):
     dist.broadcast(flag, src=0)
     handle = C.c_void_p()
     state = {"rc": None}
-    if float(flag.item()) > 0.5:
-        idb = bytes(idt.cpu().tolist())
-        cur = torch.cuda.current_device()
+    mine = 0.0
+    try:                                            # whatever goes wrong on this rank, it still reaches the vote below
+        if float(flag.item()) > 0.5:
+            idb = bytes(idt.cpu().tolist())
+            cur = torch.cuda.current_device()
 
-        def init():
-            torch.cuda.set_device(cur)
-            state["rc"] = L.shems_dp_create(idb, rank, world, C.byref(handle))
-        th = threading.Thread(target=init, daemon=True)
-        th.start()
-        th.join(timeout_s)
-    mine = 1.0 if state["rc"] == 0 and handle.value else 0.0
-    if mine:
-        # self-test: sum of (rank + 1) over the replicas through the new communicator
-        t = torch.full((1024,), float(rank + 1), dtype=torch.float32, device="cuda")
-        st = torch.cuda.current_stream().cuda_stream
-        if L.shems_dp_allreduce_sum(handle, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st)) != 0:
-            mine = 0.0
-        else:
-            torch.cuda.synchronize()
-            mine = 1.0 if bool((t == world * (world + 1) / 2).all()) else 0.0
+            def init():
+                torch.cuda.set_device(cur)          # HIP's current device is per thread
+                state["rc"] = L.shems_dp_create(idb, rank, world, C.byref(handle))
+            th = threading.Thread(target=init, daemon=True)
+            th.start()
+            th.join(timeout_s)
+        mine = 1.0 if state["rc"] == 0 and handle.value else 0.0
+        if mine:
+            # self-test: sum of (rank + 1) over the replicas through the new communicator, in this thread's current stream
+            t = torch.full((1024,), float(rank + 1), dtype=torch.float32, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            if L.shems_dp_allreduce_sum(handle, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(st)) != 0:
+                mine = 0.0
+            else:
+                torch.cuda.synchronize()
+                mine = 1.0 if bool((t == world * (world + 1) / 2).all()) else 0.0
+    except Exception as e:                          # noqa: BLE001 -- reported below, the job continues on torch.distributed
+        mine = 0.0
+        if log:
+            log(f"rank {rank}: native communicator attempt raised {e!r}")
     vote = torch.tensor([mine], device=dev)
     dist.all_reduce(vote, op=dist.ReduceOp.MIN)
     if float(vote.item()) < 0.5:

@@ -28,8 +28,16 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P = importlib.import_module(U.PKG_NAME + ".parallel")
+    # the native communicator (RCCL in the update's stream, csrc/shems_dp.hip) cannot exist without a GPU: every rank must come out of
+    # the attempt with None -- by vote, with the same number of collectives on every rank (a mismatch would hang right here) -- and
+    # the gradients then travel through torch.distributed
+    msgs = []
+    assert P.native_comm(dist, timeout_s=30.0, log=msgs.append) is None and msgs
+    os.environ["SHEMS_DP"] = "torch"
+    assert P.native_comm(dist) is None                  # switched off: no attempt, no collective
+    del os.environ["SHEMS_DP"]
     sync = P.GradSync(dist)
-    assert sync.world == world and sync.rank == rank and sync.grad_scale == 1.0 / world
+    assert sync.world == world and sync.rank == rank and sync.grad_scale == 1.0 / world and sync.native is None
     rng = np.random.default_rng(0)                      # same data on both ranks, each takes its half
     B = 120
     s = rng.random((2 * B, 9)).astype(np.float32); a = (rng.random((2 * B, 2)) * 2 - 1).astype(np.float32)

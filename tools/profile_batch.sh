@@ -1,7 +1,7 @@
 # The round's evidence batch (run through gpurun from the repo root): bench lines, rocprofv3 kernel-trace summary, PMC passes.
-#   gpurun --timeout 1200 -- 'bash tools/profile_batch.sh r03'
+#   gpurun --timeout 1200 -- 'bash tools/profile_batch.sh r04'
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}_final
 mkdir -p $O
@@ -30,6 +30,11 @@ python3 $R/bench.py --mode group --learners 32 --no-cpu-baseline > $O/${TAG}_gro
 python3 $R/bench.py --mode env --steps 720 > $O/${TAG}_env_mode_bench.json 2>/dev/null
 for n in 4096 8192 16384 32768; do
   python3 $R/bench.py --envs $n --steps 288 --no-cpu-baseline > $O/${TAG}_train_${n}_bench.json 2>/dev/null
+done
+for n in 4096 8192; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$n -- python3 $R/bench.py --envs $n --steps 1440 --warmup 72 --no-cpu-baseline > $O/kt$n.log 2>&1
+  cp $(find $O/kt$n -name "*kernel_stats.csv" | head -1) $O/${TAG}_train_${n}_kernel_stats.csv
+  rm -rf $O/kt$n
 done
 python3 $R/tools/update_forms.py > $O/${TAG}_update_forms.json 2>/dev/null
 python3 $R/tools/track_time.py > $O/${TAG}_track_time.txt 2>/dev/null
