@@ -116,7 +116,7 @@ def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
 _C_SCALARS = {"int": "Cint", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint32_t": "UInt32", "uint16_t": "UInt16",
               "uint8_t": "UInt8", "float": "Float32", "double": "Float64", "shems_config": "ShemsConfig", "void": "Cvoid",
               "shems_env": "Cvoid", "shems_view": "ShemsView", "shems_act_params": "ShemsActParams", "shems_replay": "ShemsReplay",
-              "shems_ring_window": "ShemsRingWindow", "shems_ddpg": "ShemsDdpg"}
+              "shems_ring_window": "ShemsRingWindow", "shems_ddpg": "ShemsDdpg", "shems_train_loop": "ShemsTrainLoop", "shems_dp": "Cvoid"}
 
 
 def _julia_types_for(c_arg):
@@ -191,7 +191,10 @@ def _c_struct_fields(hdr, name):
         m = re.match(r"^(\w+)\s+(.*)$", decl, re.S)
         base = _C_SCALARS[m.group(1)]
         for d in m.group(2).split(","):
-            out.append(f"Ptr{{{base}}}" if d.strip().startswith("*") else base)
+            d = d.strip()
+            t = f"Ptr{{{base}}}" if d.startswith("*") else base
+            arr = re.search(r"\[(\d+)\]$", d)                      # `double bp[2]` / `float *pub[2]`: an inline array = NTuple{2, T}
+            out.append(f"NTuple{{{arr.group(1)}, {t}}}" if arr else t)
     return out
 
 
@@ -199,7 +202,7 @@ def _julia_struct_fields(src, name):
     import re
     body = re.search(r"(?:^|\n)struct " + name + r"\b(.*?)\nend", src, re.S).group(1)
     body = re.sub(r"#.*", "", body)
-    return re.findall(r"\w+::([\w{}]+)", body)
+    return re.findall(r"\w+::((?:NTuple\{\d+, )?[\w{}]+\}?)", body)
 
 
 def test_julia_learner_module_matches_the_header(built_lib):
@@ -213,8 +216,9 @@ def test_julia_learner_module_matches_the_header(built_lib):
     hdr = open(os.path.join(U.ROOT, "include", "shems_hip.h")).read()
     L = S._capi.lib()
     calls = re.findall(r"ccall\(\(:(\w+), LIB\), (\w+),\s*\(([^)]*)\)", src)
-    assert len(calls) >= 14 and {c[0] for c in calls} >= {"shems_act_step_dev", "shems_ddpg_update", "shems_rollout_dev", "shems_minmax_dev",
-                                                           "shems_track_dev", "shems_get_view", "shems_reset_seeded_dev"}
+    assert len(calls) >= 16 and {c[0] for c in calls} >= {"shems_act_step_dev", "shems_ddpg_update", "shems_rollout_dev", "shems_minmax_dev",
+                                                           "shems_track_dev", "shems_get_view", "shems_reset_seeded_dev", "shems_train_steps",
+                                                           "shems_train_loop_release"}
     for name, ret, args in calls:
         assert hasattr(L, name), name
         m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
@@ -227,7 +231,8 @@ def test_julia_learner_module_matches_the_header(built_lib):
         c_ret = re.search(r"(const char \*|int)\s*" + name + r"\s*\(", hdr).group(1).strip()
         assert ret == {"int": "Cint", "const char *": "Cstring"}[c_ret], (name, c_ret, ret)
     for cname, jname in (("shems_config", "ShemsConfig"), ("shems_view", "ShemsView"), ("shems_replay", "ShemsReplay"),
-                         ("shems_act_params", "ShemsActParams"), ("shems_ring_window", "ShemsRingWindow"), ("shems_ddpg", "ShemsDdpg")):
+                         ("shems_act_params", "ShemsActParams"), ("shems_ring_window", "ShemsRingWindow"), ("shems_ddpg", "ShemsDdpg"),
+                         ("shems_train_loop", "ShemsTrainLoop")):
         assert _julia_struct_fields(src, jname) == _c_struct_fields(hdr, cname), (cname, _julia_struct_fields(src, jname), _c_struct_fields(hdr, cname))
     # the ctypes mirrors the tests drive have the same sizes as those field lists imply (8-byte pointers, natural alignment)
     D = importlib.import_module(U.PKG_NAME + ".ddpg")
@@ -243,5 +248,6 @@ def test_julia_learner_module_matches_the_header(built_lib):
     assert c_size(_c_struct_fields(hdr, "shems_view")) == C.sizeof(S._capi.View) and c_size(_c_struct_fields(hdr, "shems_replay")) == C.sizeof(S._capi.Replay)
     for needed in ("module DDPG_hip", "function act(ag::Agent", "function act_step!(ag::Agent", "function replay(ag::Agent", "function populate_memory(ag::Agent",
                    "function min_max_buffer(ag::Agent", "function episode!(ag::Agent", "function run_episodes(ag::Agent", "function inference(env::EnvBatch",
+                   "function train_steps!(ag::Agent",
                    "flat_params(params)"):
         assert needed in src, needed
