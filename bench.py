@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=720)
     ap.add_argument("--warmup", type=int, default=72)
-    ap.add_argument("--prewarm-s", type=float, default=1.0,
+    ap.add_argument("--prewarm-s", type=float, default=5.5,
                     help="run the workload untimed for this many seconds BEFORE the W warm-up steps, so that a short run (--steps 20) is "
                          "measured at the sustained clock and not on a GPU that was idle a moment ago (0 = off)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
