@@ -1710,7 +1710,9 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
 
 // Which form runs a launch of m envs (the knobs exist for the all-forms test and for A/B runs):
 //   m > 8 192            k_act2           64-env tiles, two workgroups resident per CU            (SHEMS_ACT_FORM4 = 1 / 0: k_act, below)
-//   4 096 < m <= 8 192   k_actg<1, 8, 1>  32-env tiles, 8 waves = 8 column groups                 (SHEMS_ACT_FORM = 0 / 2 / 3: k_act<1, 4, .>)
+//   4 096 < m <= 8 192   k_actg<1, 4, 2, 2>  32-env tiles, two workgroups per tile, ring of 2 chunks: both resident on one CU
+//                        (per-tile reward sums asked for, or SHEMS_ACT_FORM = 8: k_actg<1, 8, 1>, 8 waves = 8 column groups; 10: force the ring-2 split form;
+//                         SHEMS_ACT_FORM = 0 / 2 / 3: k_act<1, 4, .>)
 //   m <= 4 096           k_actg<1, 4, 2>  32-env tiles, two workgroups (4 groups each) per tile   (SHEMS_ACT_FORM = 8 / 9: force one of the two)
 // k_act (SHEMS_ACT_FORM4 = 1: free-running waves, 0: shared W2 stream): 128-env tiles from 32 768 envs, 64-env tiles from 16 384, 32 below.
 static int act_form() { static const int f = []() { const char *e = getenv("SHEMS_ACT_FORM"); return e ? atoi(e) : -1; }(); return f; }
@@ -1749,6 +1751,11 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     if (form == 0) return launch_act<1, 4>(a, st);
     if (form == 2) return launch_act<1, 4, 2>(a, st);
     if (form == 3) return launch_act<1, 4, 3>(a, st);
+    // 4 096 < envs <= 8 192 (round 4): the split form with a ring of TWO chunks -- 76.5 KB per workgroup, so the two halves of a tile's work
+    // are two independent workgroups resident on one CU (8 waves, two per SIMD, as the 8-wave form) without that form's coupling (its early
+    // waves wait at the barrier for the late ones): 23.1 against 23.8 us at 8 192 envs.  At <= 4 096 envs (one workgroup per CU) the
+    // shallower ring costs more than it wins (17.7 against 16.2 us): ring of three there.  Per-tile reward sums need ONE workgroup per tile.
+    if ((form == 10 || (form < 0 && cnt > 128 * 32)) && !want_sum && (cnt + 31) / 32 <= kSplitMaxTiles) return launch_actg<1, 4, 2, 2>(a, st);
     if (form == 8 || (form != 9 && (cnt > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
     return launch_actg<1, 4, 2, 3>(a, st);
 }
@@ -1809,6 +1816,7 @@ int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
         else if (form == 0) name = "shems::k_act<1, 4, 0>";
         else if (form == 2) name = "shems::k_act<1, 4, 2>";
         else if (form == 3) name = "shems::k_act<1, 4, 3>";
+        else if ((form == 10 || (form < 0 && n_envs > 128 * 32)) && (n_envs + 31) / 32 <= kSplitMaxTiles) name = "shems::k_actg<1, 4, 2, 2>";
         else if (form == 8 || (form != 9 && n_envs > 128 * 32)) name = "shems::k_actg<1, 8, 1, 3>";
         else name = "shems::k_actg<1, 4, 2, 3>";
     }

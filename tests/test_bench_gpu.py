@@ -35,7 +35,7 @@ def test_bench_json_contract_small():
     assert d["value"] > 1e6 and d["updates_per_sec"] > 100
     # the line says what ran: ONE kernel name (the dispatcher's), the bytes the launch has to move, what kernel_avg_us is, and where the
     # wall time went (HBM rate / traffic ratio only where committed counters exist for this size: 65 536 envs)
-    assert r["kernel"] == "shems::k_actg<1, 8, 1, 3>" and "|" not in r["kernel"]
+    assert r["kernel"] == "shems::k_actg<1, 4, 2, 2>" and "|" not in r["kernel"]
     assert r["algorithmic_bytes"] == 92 * 8192 + 4 * 129002 + 85 * 333 and "hbm_gbs" in r and "traffic_ratio" in r
     assert "minus replay" in r["kernel_avg_us_is"]
     assert d["gpu_section_s"] > 0 and d["roofline_pass_s"] > 0 and d["cpu_baseline_s"] == 0.0
@@ -46,7 +46,7 @@ def test_bench_kernel_name_follows_the_dispatcher():
     import importlib
     D = importlib.import_module(U.PKG_NAME + ".ddpg")
     assert D.act_kernel_name(65536) == "shems::k_act2" and D.act_kernel_name(4096) == "shems::k_actg<1, 4, 2, 3>"
-    assert D.act_kernel_name(8192) == "shems::k_actg<1, 8, 1, 3>" and D.act_kernel_name(65536, grouped=True) == "shems::k_act<4, 4, 2>"
+    assert D.act_kernel_name(8192) == "shems::k_actg<1, 4, 2, 2>" and D.act_kernel_name(65536, grouped=True) == "shems::k_act<4, 4, 2>"
 
 
 def test_bench_scaled_replay_mode():

@@ -263,7 +263,7 @@ def test_every_form_of_the_act_kernel_writes_the_same_bytes():
     # default: k_act2 (two workgroups per CU) above 8 192 envs, the column-group forms below
     forms = {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "free": {"SHEMS_ACT_FORM": "2", "SHEMS_ACT_FORM4": "1"},
              "ring3": {"SHEMS_ACT_FORM": "3", "SHEMS_ACT_FORM4": "1"}, "group8": {"SHEMS_ACT_FORM": "8"}, "split": {"SHEMS_ACT_FORM": "9"},
-             "two_per_cu_everywhere": {"SHEMS_ACT_FORM": "12"}}
+             "two_per_cu_everywhere": {"SHEMS_ACT_FORM": "12"}, "split_ring2": {"SHEMS_ACT_FORM": "10"}}
     for name, env in forms.items():
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
