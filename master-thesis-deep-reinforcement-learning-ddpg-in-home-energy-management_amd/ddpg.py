@@ -824,6 +824,8 @@ class TrainWorkload:
             raise NotImplementedError("the native loop drives one replica on the tuned kernels (no gradient exchange, no wide network, no parameter noise)")
         if self.overlap_mode == LOOP_PIPELINED_EXACT and loop != "native":
             raise NotImplementedError("the order-exact pipelined mode exists in the native loop only (shems_train_steps)")
+        if self.overlap and loop == "native" and self.agent.sync.world > 1:
+            raise NotImplementedError("data-parallel replicas run in program order (the gradient exchange sits in the update's own stream)")
         if self.overlap and self.agent.wide:
             raise NotImplementedError("pipelined modes run the tuned (250, 500) kernels: a wide network's actor copies are not in their layout")
         self.loop = loop
