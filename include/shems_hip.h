@@ -345,6 +345,18 @@ int shems_dp_create(const char *id128, int rank, int world, shems_dp **out);
 int shems_dp_destroy(shems_dp *dp);
 int shems_dp_info(const shems_dp *dp, int *rank, int *world, char *lib, int32_t cap);   /* lib: which librccl was loaded */
 int shems_dp_allreduce_sum(shems_dp *dp, float *d_buf, int64_t n, void *stream);        /* in place, float32, in `stream` */
+/* The same record WITHOUT RCCL (opt-in, SHEMS_DP=direct in the Python host): a direct one-shot exchange over peer-mapped memory.  Every
+ * rank owns an inbox in fine-grained device memory, every peer maps it (hipIpcGetMemHandle / hipIpcOpenMemHandle: xGMI peers on one
+ * node; two processes on one device for rehearsals); the ADAM sweep of each network pushes its slice of the local gradient into every
+ * peer's inbox, stamps a per-slice epoch flag, waits (bounded) for the peers' slices and sums them in rank order -- no collective launch
+ * ("direct one-shot ... over all 7 links").  world <= 8.  shems_dp_create_direct, then exchange the 128-byte handle
+ * blocks by any means and shems_dp_direct_connect every peer on every rank BEFORE the first shems_ddpg_update_dp (a barrier of the
+ * caller's).  shems_dp_direct_timeouts: waits that gave up since the last call (0 in every healthy run; read and cleared).  Validated
+ * on ONE device only (two processes, tests/test_bench_gpu.py); never run across xGMI. */
+int shems_dp_create_direct(int rank, int world, shems_dp **out);
+int shems_dp_direct_handles(shems_dp *dp, char *out128);
+int shems_dp_direct_connect(shems_dp *dp, int peer, const char *handles128);
+int shems_dp_direct_timeouts(shems_dp *dp, int64_t *out, void *stream);
 /* replay() of one replica: shems_ddpg_critic_grad_ex, all-reduce(grad_critic), shems_ddpg_critic_apply(grad_scale = 1 / world),
  * shems_ddpg_actor_grad, all-reduce(grad_actor), shems_ddpg_actor_apply_pub -- everything in `stream`.  dp == NULL: a single replica in
  * the split form (the bytes of shems_ddpg_update). */

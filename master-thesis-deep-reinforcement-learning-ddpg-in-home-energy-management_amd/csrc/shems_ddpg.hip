@@ -1090,6 +1090,59 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
     if (i0 < c.n) adam_vec4(c, i0);
 }
 
+// Data-parallel form with the DIRECT exchange (XchgArgs, shems_internal.h): push my range of the gradient to every peer, wait for
+// theirs, sum in rank order, ADAM.  One workgroup = 1 024 consecutive parameters = 256 threads x 4; the same range on every rank.
+__global__ __launch_bounds__(256) void k_adam_xchg(AdamCtx c, XchgArgs x)
+{
+    const int tid = threadIdx.x, wg = blockIdx.x, i0 = 4 * (wg * 256 + tid);
+    const int par = (int)(x.epoch & 1ull);
+    const bool full = i0 + 3 < c.n;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) { const float4 v = *reinterpret_cast<const float4 *>(c.g + i0); g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w; }
+    else for (int e = 0; e < 4; ++e) if (i0 + e < c.n) g[e] = c.g[i0 + e];
+    // push: slot [par][my rank] of every peer's inbox (16-byte stores; the pad beyond n carries zeros)
+    const int64_t my_slot = ((int64_t)par * x.world + x.rank) * kXchgNmax + i0;
+    for (int q = 0; q < x.world; ++q)
+        if (q != x.rank) *reinterpret_cast<float4 *>(x.inbox[q] + my_slot) = make_float4(g[0], g[1], g[2], g[3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                      // system scope: the pushes are visible to the peers before the flags
+    __syncthreads();
+    if (tid < x.world && tid != x.rank)
+        __hip_atomic_store(x.flags[tid] + ((int64_t)par * x.world + x.rank) * kXchgWgs + wg, x.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // wait: the same workgroup of every peer has pushed this epoch into MY inbox (bounded: a peer that never comes is counted, not waited for)
+    if (tid < x.world && tid != x.rank) {
+        const unsigned long long *f = x.flags[x.rank] + ((int64_t)par * x.world + tid) * kXchgWgs + wg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x.epoch) {
+            if (++spins > (1u << 20)) { __hip_atomic_fetch_add(x.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // sum in rank order
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < x.world; ++r) {
+        float v[4];
+        if (r == x.rank) { for (int e = 0; e < 4; ++e) v[e] = g[e]; }
+        else {
+            const float4 t = *reinterpret_cast<const float4 *>(x.inbox[x.rank] + ((int64_t)par * x.world + r) * kXchgNmax + i0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        for (int e = 0; e < 4; ++e) s4[e] = r == 0 ? v[e] : s4[e] + v[e];
+    }
+    // the summed gradient replaces the local one (what an all-reduce leaves), then ADAM + soft update on the owner's four elements
+    for (int e = 0; e < 4; ++e) {
+        const int i = i0 + e;
+        if (i < c.n) {
+            float m = c.mt[i], v = c.vt[i], p = c.p[i], t = c.target[i];
+            adam_math(c, s4[e], m, v, p, t);
+            c.mt[i] = m; c.vt[i] = v; c.p[i] = p; c.target[i] = t;
+            const_cast<float *>(c.g)[i] = s4[e];
+            if (c.publish) pub_store(c.publish + i, p, true);
+        }
+    }
+}
+
 // ---- critic loss head, evaluated in the prologue of every K3 workgroup (cheaper than a launch boundary) --------
 // d3[0][m] = dq[m] = 2 (q - y) / B into LDS; workgroup 0 also publishes y, q, the loss and gb3 (+ its ADAM step when fused).
 // The global operands of the two heads, fetched with the rest of a workgroup's first batch of loads (all threads load;
@@ -1826,6 +1879,17 @@ int ddpg_update_sync(const shems_ddpg *d, const shems_replay *ring, int64_t ring
     const AdamScalars sc{eta_crit, bp1_crit, bp2_crit, 1.0, nullptr}, sa{eta_act, bp1_act, bp2_act, 1.0, d_publish};
     if (int rc = critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, &sc, st, &first)) return rc;
     return actor_side(d, 1, 0, &sa, st, &last);
+}
+int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, double bp2, float *d_publish, const XchgArgs &x, hipStream_t st)
+{
+    if (int rc = check_ddpg(d, "ddpg_apply_xchg")) return rc;
+    if (int rc = check_adam(bp1, bp2, "ddpg_apply_xchg")) return rc;
+    if (x.world < 1 || x.world > kXchgMaxWorld || x.rank < 0 || x.rank >= x.world || x.epoch < 1 || !x.timeouts)
+        return set_error(SHEMS_ERR_ARG, "ddpg_apply_xchg: bad exchange record");
+    static_assert(SHEMS_ACTOR_PARAMS <= kXchgNmax && SHEMS_CRITIC_PARAMS <= kXchgNmax, "inbox slot holds either gradient");
+    const AdamCtx c = adam_ctx(d, critic, AdamScalars{eta, bp1, bp2, 1.0 / (double)x.world, d_publish});
+    hipLaunchKernelGGL(k_adam_xchg, dim3((c.n + 1023) / 1024), dim3(256), 0, st, c, x);
+    return hip_ok(hipGetLastError(), "k_adam_xchg launch");
 }
 int ddpg_last_launch_grid() { return GR_NW + GR_NG + GR_NR; }
 unsigned *ddpg_timeout_word(const shems_ddpg *d) { return reinterpret_cast<unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT; }

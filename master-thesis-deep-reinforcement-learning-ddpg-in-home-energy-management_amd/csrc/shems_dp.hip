@@ -60,9 +60,22 @@ int nccl_ok(ncclResult_t r, const char *what)
 }
 }  // namespace
 
+// The direct exchange's memory (XchgArgs, shems_internal.h): this rank's inbox and flags (fine-grained device memory, exported with
+// hipIpcGetMemHandle) and the peers' as mapped here.
+struct Direct {
+    float *inbox[kXchgMaxWorld] = {};
+    unsigned long long *flags[kXchgMaxWorld] = {};
+    bool opened[kXchgMaxWorld] = {};
+    int connected = 0;                    // peers mapped so far
+    unsigned long long epoch = 0;         // exchanges enqueued so far
+    unsigned *timeouts = nullptr;         // device word
+    size_t inbox_bytes = 0, flags_bytes = 0;
+};
+
 struct shems_dp {
     ncclComm_t comm;
     int rank, world, device;
+    Direct *direct;                       // non-null: gradients travel through peer-mapped inboxes, not RCCL
 };
 
 extern "C" {
@@ -84,7 +97,7 @@ int shems_dp_create(const char *id128, int rank, int world, shems_dp **out)
     if (int rc = need_rccl("shems_dp_create")) return rc;
     shems_dp *dp = new (std::nothrow) shems_dp;
     if (!dp) return set_error(SHEMS_ERR_NOMEM, "shems_dp_create: out of host memory");
-    dp->rank = rank; dp->world = world; dp->comm = nullptr;
+    dp->rank = rank; dp->world = world; dp->comm = nullptr; dp->direct = nullptr;
     if (int rc = hip_ok(hipGetDevice(&dp->device), "hipGetDevice")) { delete dp; return rc; }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
@@ -98,8 +111,87 @@ int shems_dp_destroy(shems_dp *dp)
     if (!dp) return SHEMS_OK;
     int rc = SHEMS_OK;
     if (dp->comm && g_rccl.h) rc = nccl_ok(g_rccl.CommDestroy(dp->comm), "ncclCommDestroy");
+    if (Direct *x = dp->direct) {
+        for (int q = 0; q < dp->world; ++q) {
+            if (q == dp->rank) continue;
+            if (x->opened[q]) { (void)hipIpcCloseMemHandle(x->inbox[q]); (void)hipIpcCloseMemHandle(x->flags[q]); }
+        }
+        if (x->inbox[dp->rank]) (void)hipFree(x->inbox[dp->rank]);
+        if (x->flags[dp->rank]) (void)hipFree(x->flags[dp->rank]);
+        if (x->timeouts) (void)hipFree(x->timeouts);
+        delete x;
+    }
     delete dp;
     return rc;
+}
+
+/* The direct exchange (no RCCL): every rank creates its record, publishes its two IPC handles (128 bytes: inbox, flags), maps every
+ * peer's, and from then on shems_ddpg_update_dp exchanges gradients through the inboxes (k_adam_xchg, csrc/shems_ddpg.hip).  The caller
+ * must make sure every rank has connected every peer before the first update (a barrier of its own). */
+int shems_dp_create_direct(int rank, int world, shems_dp **out)
+{
+    if (!out || world < 1 || world > kXchgMaxWorld || rank < 0 || rank >= world)
+        return set_error(SHEMS_ERR_ARG, "shems_dp_create_direct: rank %d of %d (at most %d replicas)", rank, world, kXchgMaxWorld);
+    shems_dp *dp = new (std::nothrow) shems_dp;
+    Direct *x = new (std::nothrow) Direct;
+    if (!dp || !x) { delete dp; delete x; return set_error(SHEMS_ERR_NOMEM, "shems_dp_create_direct: out of host memory"); }
+    dp->rank = rank; dp->world = world; dp->comm = nullptr; dp->direct = x;
+    int rc = hip_ok(hipGetDevice(&dp->device), "hipGetDevice");
+    x->inbox_bytes = (size_t)2 * world * kXchgNmax * sizeof(float);
+    x->flags_bytes = (size_t)2 * world * kXchgWgs * sizeof(unsigned long long);
+    // fine-grained: stores of a peer (another GPU, or another process on this one) become visible while kernels run
+    if (!rc) rc = hip_ok(hipExtMallocWithFlags((void **)&x->inbox[rank], x->inbox_bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(inbox)");
+    if (!rc) rc = hip_ok(hipExtMallocWithFlags((void **)&x->flags[rank], x->flags_bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(flags)");
+    if (!rc) rc = hip_ok(hipMalloc((void **)&x->timeouts, sizeof(unsigned)), "hipMalloc(timeouts)");
+    if (!rc) rc = hip_ok(hipMemset(x->inbox[rank], 0, x->inbox_bytes), "hipMemset(inbox)");
+    if (!rc) rc = hip_ok(hipMemset(x->flags[rank], 0, x->flags_bytes), "hipMemset(flags)");
+    if (!rc) rc = hip_ok(hipMemset(x->timeouts, 0, sizeof(unsigned)), "hipMemset(timeouts)");
+    if (!rc) rc = hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (rc) { shems_dp_destroy(dp); return rc; }
+    *out = dp;
+    return SHEMS_OK;
+}
+
+int shems_dp_direct_handles(shems_dp *dp, char *out128)
+{
+    if (!dp || !dp->direct || !out128) return set_error(SHEMS_ERR_ARG, "shems_dp_direct_handles: not a direct-exchange record");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "two 64-byte IPC handles");
+    hipIpcMemHandle_t h[2];
+    if (int rc = hip_ok(hipIpcGetMemHandle(&h[0], dp->direct->inbox[dp->rank]), "hipIpcGetMemHandle(inbox)")) return rc;
+    if (int rc = hip_ok(hipIpcGetMemHandle(&h[1], dp->direct->flags[dp->rank]), "hipIpcGetMemHandle(flags)")) return rc;
+    std::memcpy(out128, h, sizeof h);
+    return SHEMS_OK;
+}
+
+int shems_dp_direct_connect(shems_dp *dp, int peer, const char *handles128)
+{
+    if (!dp || !dp->direct || !handles128 || peer < 0 || peer >= dp->world || peer == dp->rank)
+        return set_error(SHEMS_ERR_ARG, "shems_dp_direct_connect: bad peer %d", peer);
+    Direct *x = dp->direct;
+    if (x->opened[peer]) return SHEMS_OK;
+    hipIpcMemHandle_t h[2];
+    std::memcpy(h, handles128, sizeof h);
+    if (int rc = hip_ok(hipIpcOpenMemHandle((void **)&x->inbox[peer], h[0], hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(inbox)")) return rc;
+    if (int rc = hip_ok(hipIpcOpenMemHandle((void **)&x->flags[peer], h[1], hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle(flags)")) {
+        (void)hipIpcCloseMemHandle(x->inbox[peer]); x->inbox[peer] = nullptr;
+        return rc;
+    }
+    x->opened[peer] = true;
+    x->connected += 1;
+    return SHEMS_OK;
+}
+
+/* Exchange waits that gave up since the last call (read and cleared; synchronises `stream`).  Non-zero: a peer never delivered -- the
+ * updates since then used an incomplete sum and the replicas have diverged. */
+int shems_dp_direct_timeouts(shems_dp *dp, int64_t *out, void *stream)
+{
+    if (!dp || !dp->direct || !out) return set_error(SHEMS_ERR_ARG, "shems_dp_direct_timeouts: not a direct-exchange record");
+    unsigned v = 0;
+    if (int rc = hip_ok(hipMemcpyAsync(&v, dp->direct->timeouts, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream), "memcpy timeouts")) return rc;
+    if (int rc = hip_ok(hipStreamSynchronize((hipStream_t)stream), "sync")) return rc;
+    if (v) if (int rc = hip_ok(hipMemsetAsync(dp->direct->timeouts, 0, sizeof v, (hipStream_t)stream), "memset timeouts")) return rc;
+    *out = (int64_t)v;
+    return SHEMS_OK;
 }
 
 int shems_dp_info(const shems_dp *dp, int *rank, int *world, char *lib, int32_t cap)
@@ -107,13 +199,14 @@ int shems_dp_info(const shems_dp *dp, int *rank, int *world, char *lib, int32_t 
     if (!dp) return set_error(SHEMS_ERR_ARG, "shems_dp_info: NULL");
     if (rank) *rank = dp->rank;
     if (world) *world = dp->world;
-    if (lib && cap > 1) snprintf(lib, (size_t)cap, "%s", g_rccl.where);
+    if (lib && cap > 1) snprintf(lib, (size_t)cap, "%s", dp->direct ? "direct exchange (peer-mapped inboxes, no RCCL)" : g_rccl.where);
     return SHEMS_OK;
 }
 
 int shems_dp_allreduce_sum(shems_dp *dp, float *d_buf, int64_t n, void *stream)
 {
     if (!dp || !d_buf || n < 1) return set_error(SHEMS_ERR_ARG, "shems_dp_allreduce_sum: bad arguments");
+    if (!dp->comm) return set_error(SHEMS_ERR_STATE, "shems_dp_allreduce_sum: this record carries the direct exchange (no RCCL communicator): gradients are exchanged inside shems_ddpg_update_dp");
     return nccl_ok(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, dp->comm, (hipStream_t)stream), "ncclAllReduce");
 }
 
@@ -124,6 +217,21 @@ int shems_ddpg_update_dp(const shems_ddpg *d, const shems_replay *ring, int64_t 
                          float *d_publish, shems_dp *dp, void *stream)
 {
     if (!d) return set_error(SHEMS_ERR_ARG, "shems_ddpg_update_dp: NULL");
+    if (dp && dp->direct) {
+        // direct exchange: the ADAM sweep of each network pushes / waits / sums in rank order (k_adam_xchg); two launches less than RCCL's form
+        Direct *x = dp->direct;
+        if (x->connected != dp->world - 1) return set_error(SHEMS_ERR_STATE, "shems_ddpg_update_dp: %d of %d peers connected", x->connected, dp->world - 1);
+        XchgArgs a;
+        std::memset(&a, 0, sizeof a);
+        for (int q = 0; q < dp->world; ++q) { a.inbox[q] = x->inbox[q]; a.flags[q] = x->flags[q]; }
+        a.rank = dp->rank; a.world = dp->world; a.timeouts = x->timeouts;
+        if (int rc = shems_ddpg_critic_grad_ex(d, ring, ring_len, seed, tick, excl_pos, excl_count, stream)) return rc;
+        a.epoch = ++x->epoch;
+        if (int rc = ddpg_apply_xchg(d, true, eta_crit, bp1_crit, bp2_crit, nullptr, a, (hipStream_t)stream)) return rc;
+        if (int rc = shems_ddpg_actor_grad(d, stream)) return rc;
+        a.epoch = ++x->epoch;
+        return ddpg_apply_xchg(d, false, eta_act, bp1_act, bp2_act, d_publish, a, (hipStream_t)stream);
+    }
     const double gs = dp ? 1.0 / (double)dp->world : 1.0;
     if (int rc = shems_ddpg_critic_grad_ex(d, ring, ring_len, seed, tick, excl_pos, excl_count, stream)) return rc;
     if (dp) if (int rc = shems_dp_allreduce_sum(dp, d->grad_critic, SHEMS_CRITIC_PARAMS, stream)) return rc;

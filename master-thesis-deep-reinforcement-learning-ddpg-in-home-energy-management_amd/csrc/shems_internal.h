@@ -106,4 +106,27 @@ int ddpg_update_sync(const shems_ddpg *d, const shems_replay *ring, int64_t ring
                      float *d_publish, const DevSync &first, const DevSync &last, hipStream_t st);
 int ddpg_last_launch_grid();
 unsigned *ddpg_timeout_word(const shems_ddpg *d);
+
+// ---- data-parallel replicas: the direct gradient exchange (csrc/shems_dp.hip owns the memory, csrc/shems_ddpg.hip the kernel) ---------
+// Every rank owns an INBOX [2 parities][world][kXchgNmax] float32 and FLAGS [2][world][kXchgWgs] uint64 in fine-grained device memory that
+// every peer has mapped (hipIpcOpenMemHandle).  The ADAM sweep of an exchange (k_adam_xchg, one workgroup per 1 024 consecutive
+// parameters) PUSHES its range of the local gradient into slot [parity][my rank] of every peer's inbox, releases at system scope, stamps
+// the peers' flag [parity][my rank][workgroup] with the exchange's epoch, WAITS (bounded) for the same workgroup's flag from every peer
+// in its own flags, then sums the slots IN RANK ORDER (its own gradient in its own position: every replica adds the same numbers in the
+// same order, so the replicas stay bit-identical) and applies ADAM with grad_scale 1 / world.  No collective launch, no launch at all
+// beyond the sweep the data-parallel form has anyway.  Epochs count exchanges (critic, actor, critic, ...), parity = epoch & 1: a slot
+// is rewritten two exchanges later, by which time its owner has consumed it (a rank pushes epoch e + 1 only after consuming epoch e,
+// and epoch e + 2 only after every peer's e + 1 has arrived).
+constexpr int kXchgMaxWorld = 8;
+constexpr int kXchgNmax = 129024;                     // 126 x 1 024 >= SHEMS_ACTOR_PARAMS
+constexpr int kXchgWgs = kXchgNmax / 1024;
+struct XchgArgs {
+    float *inbox[kXchgMaxWorld];                      // inbox[q]: rank q's inbox as mapped in this process (inbox[rank]: the local allocation)
+    unsigned long long *flags[kXchgMaxWorld];
+    int rank, world;
+    unsigned long long epoch;                         // this exchange (>= 1)
+    unsigned *timeouts;                               // device word: waits that gave up
+};
+// ADAM + soft update of one network behind a direct exchange of its gradient (grad_scale 1 / world inside).
+int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, double bp2, float *d_publish, const XchgArgs &x, hipStream_t st);
 }

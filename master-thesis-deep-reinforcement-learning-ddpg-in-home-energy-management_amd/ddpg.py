@@ -587,10 +587,11 @@ class Agent:
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
-    def enable_data_parallel(self, dist, native=None):
+    def enable_data_parallel(self, dist, native=None, direct=False):
         """Replicas (one per GPU, each with its own env shard and ring) all-reduce gradients over RCCL.  native: a shems_dp communicator
-        (parallel.native_comm) -- the all-reduces then run in the update's own stream, from native code."""
-        self.sync = GradSync(dist, native=native)
+        (parallel.native_comm) -- the all-reduces then run in the update's own stream, from native code; direct: that record exchanges
+        through peer-mapped inboxes instead (parallel.direct_comm)."""
+        self.sync = GradSync(dist, native=native, direct=direct)
         self.sync.broadcast(self.actor, self.critic, self.actor_t, self.critic_t)   # identical initial weights
 
     def _allreduce(self, g):
@@ -803,10 +804,18 @@ class TrainWorkload:
         self.hidden = (int(hidden[0]), int(hidden[1]))       # other than (250, 500): another point of the reference's grids (bench.py --hidden)
         self.agent = Agent(seed=1231, rng_seed=self.env_seed, hidden=self.hidden)   # same initial weights on every rank (config: seed 1231)
         if dist is not None:
-            from .parallel import native_comm
-            import sys
-            self.agent.enable_data_parallel(dist, native=None if self.agent.wide else native_comm(dist, log=lambda m: print(m, file=sys.stderr, flush=True)))
+            from .parallel import direct_comm, native_comm
             import os
+            import sys
+            log = lambda m: print(m, file=sys.stderr, flush=True)
+            native, direct = None, False
+            if not self.agent.wide:
+                if os.environ.get("SHEMS_DP") == "direct":          # opt-in: gradients through peer-mapped inboxes, no collective launch
+                    native = direct_comm(dist, log=log)
+                    direct = native is not None
+                if native is None:
+                    native = native_comm(dist, log=log)
+            self.agent.enable_data_parallel(dist, native=native, direct=direct)
             if os.environ.get("SHEMS_DP_OVERLAP") in ("0", "1"):   # A/B knob: "1" = the critic's all-reduce asynchronous, under the actor's E products
                 self.agent.dp_overlap = os.environ["SHEMS_DP_OVERLAP"] == "1"
         self.ring = ReplayRing(self.mem_size)
@@ -925,6 +934,13 @@ class TrainWorkload:
             self.torch.cuda.synchronize()
         if self._native is not None:
             _capi.check(self.agent.L.shems_train_loop_release(C.byref(self._native)))
+        if self.agent.sync.direct:
+            n = C.c_int64(0)
+            self.agent.L.shems_dp_direct_timeouts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+            self.agent.L.shems_dp_direct_timeouts.restype = C.c_int
+            _capi.check(self.agent.L.shems_dp_direct_timeouts(self.agent.sync.native, C.byref(n), self.agent._stream()))
+            if n.value:
+                raise RuntimeError(f"{n.value} waits of the direct gradient exchange gave up: a peer never delivered, the replicas have diverged")
         self.env.check_error()
         if self.agent.sync_timeouts():
             raise RuntimeError("a device-side wait of the pipelined loop gave up: the steps since the last check are invalid")
@@ -986,7 +1002,9 @@ class TrainWorkload:
                 loc_avg = time_launches(torch, updates_only, reps)[0] if self.updates else 0.0
                 self.agent.sync = sync
                 gc, ga = torch.zeros_like(self.agent.grad_critic), torch.zeros_like(self.agent.grad_actor)
-                if sync.native is not None:         # the exchange as the update issues it: RCCL in this stream, from native code
+                if sync.direct:                     # no all-reduce exists on its own: the exchange is inside the ADAM sweeps
+                    ar = lambda g: None
+                elif sync.native is not None:       # the exchange as the update issues it: RCCL in this stream, from native code
                     Lc = self.agent.L
                     Lc.shems_dp_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
                     Lc.shems_dp_allreduce_sum.restype = C.c_int
@@ -1029,8 +1047,10 @@ class TrainWorkload:
                 "overlap": {LOOP_ORDERED: False, LOOP_PIPELINED: "pipelined", LOOP_PIPELINED_EXACT: "exact"}[self.overlap_mode],
                 "loop": self.loop,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
-                "dp_exchange": None if self.agent.sync.world == 1 else ("RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)"
-                                                                       if self.agent.sync.native is not None else "torch.distributed all_reduce (its own stream)"),
+                "dp_exchange": None if self.agent.sync.world == 1 else (
+                    "direct exchange through peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg), no collective launch" if self.agent.sync.direct else
+                    "RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)" if self.agent.sync.native is not None else
+                    "torch.distributed all_reduce (its own stream)"),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8 if self.hidden == (L1, L2) else 20 * (10 * self.hidden[0] + self.hidden[0] * self.hidden[1] + 1.5 * self.hidden[1]) * BATCH_SIZE / 1e6,
                 "hidden": list(self.hidden), "data_parallel": getattr(self, "dp", None)}

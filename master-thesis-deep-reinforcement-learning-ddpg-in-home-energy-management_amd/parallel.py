@@ -94,16 +94,70 @@ def native_comm(dist, timeout_s=120.0, log=None):
     return handle
 
 
+def direct_comm(dist, log=None):
+    """A shems_dp record that exchanges gradients DIRECTLY through peer-mapped inboxes (csrc/shems_dp.hip: shems_dp_create_direct; the
+    exchange itself is the ADAM sweep k_adam_xchg) -- no RCCL, no collective launch.  Opt-in (SHEMS_DP=direct).  Collective: every rank
+    calls it; the 128-byte IPC handle blocks travel by all_gather_object; the ranks vote, and if any of them could not map every peer the
+    attempt is dropped on every rank (returns None).  Works for xGMI peers of one node and -- the rehearsal form -- for several processes on
+    ONE device.  At most 8 replicas."""
+    import ctypes as C
+    import torch
+    from . import _capi
+    if dist is None or not dist.is_initialized() or dist.get_world_size() < 2:
+        return None
+    L = _capi.lib()
+    L.shems_dp_create_direct.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.shems_dp_direct_handles.argtypes = [C.c_void_p, C.c_char_p]
+    L.shems_dp_direct_connect.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    L.shems_dp_destroy.argtypes = [C.c_void_p]
+    for fn in ("shems_dp_create_direct", "shems_dp_direct_handles", "shems_dp_direct_connect", "shems_dp_destroy"):
+        getattr(L, fn).restype = C.c_int
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    handle = C.c_void_p()
+    mine, blob = 0.0, None
+    try:
+        buf = C.create_string_buffer(128)
+        if world <= 8 and L.shems_dp_create_direct(rank, world, C.byref(handle)) == 0 and L.shems_dp_direct_handles(handle, buf) == 0:
+            blob = bytes(buf.raw)
+    except Exception as e:                          # noqa: BLE001
+        if log:
+            log(f"rank {rank}: direct exchange attempt raised {e!r}")
+    blobs = [None] * world
+    dist.all_gather_object(blobs, blob)
+    try:
+        if blob is not None and all(b is not None for b in blobs):
+            mine = 1.0
+            for q, b in enumerate(blobs):
+                if q != rank and L.shems_dp_direct_connect(handle, q, b) != 0:
+                    mine = 0.0
+                    break
+    except Exception as e:                          # noqa: BLE001
+        mine = 0.0
+        if log:
+            log(f"rank {rank}: mapping the peers' inboxes raised {e!r}")
+    vote = torch.tensor([mine], device=dev)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)       # also the barrier: nobody updates before everybody has mapped everybody
+    if float(vote.item()) < 0.5:
+        if log:
+            log(f"rank {rank}: no direct exchange ({L.shems_last_error().decode('utf-8', 'replace') if not mine else 'another rank failed'})")
+        if handle.value:
+            L.shems_dp_destroy(handle)
+        return None
+    return handle
+
+
 class GradSync:
     """Keeps learner replicas identical.  `dist` is `torch.distributed` (initialised) or None.  `native`: a shems_dp communicator
     (native_comm) -- the gradient all-reduces of replay() are then RCCL calls in the update's own stream, issued from native code
     (shems_ddpg_update_dp / shems_train_steps), and torch.distributed only carries the rendezvous, the broadcasts and the scalars."""
 
-    def __init__(self, dist=None, native=None):
+    def __init__(self, dist=None, native=None, direct=False):
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
         self.native = native
+        self.direct = bool(direct) and native is not None      # `native` exchanges through peer-mapped inboxes (direct_comm), not RCCL
 
     @property
     def grad_scale(self):

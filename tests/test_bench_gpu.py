@@ -139,6 +139,23 @@ def test_async_gradient_exchange_gives_the_same_bytes():
     assert out[0] == out[1]
 
 
+def test_direct_gradient_exchange_two_ranks_on_one_device():
+    """The direct exchange (SHEMS_DP=direct: peer-mapped inboxes, per-slice epoch flags, the sum in rank order inside the ADAM sweep -- no
+    collective launch) rehearsed as far as one GPU allows: two rank processes on device 0 map each other's inboxes with hipIpcOpenMemHandle
+    (profiles/r04_ipc_probe.json, tools/ipc_kernel_pingpong.hip: kernels of two processes do run concurrently there and see each other's
+    stores).  With two replicas the rank-order sum IS the all-reduce's sum (a + b), so the learner must end with the bytes of the
+    torch.distributed (gloo) path; no exchange wait may have given up (TrainWorkload.finish raises otherwise)."""
+    out = {}
+    for how in ("torch", "direct"):
+        d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "48", "--warmup", "6", "--envs", "4096", "--prewarm-s", "0"],
+                 env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP": how})
+        assert d["n_gpus"] == 2 and d["value"] > 0
+        out[how] = d
+    assert out["direct"]["dp_exchange"].startswith("direct exchange") and out["direct"]["loop"] == "native"
+    assert out["torch"]["dp_exchange"].startswith("torch.distributed") and out["torch"]["loop"] == "host"
+    assert out["direct"]["learner_crc32"] == out["torch"]["learner_crc32"], (out["direct"]["learner_crc32"], out["torch"]["learner_crc32"])
+
+
 def test_rccl_stream_ordering_on_a_one_rank_group():
     """The data-parallel replay() on real RCCL streams (a one-rank NCCL group: RCCL refuses two ranks on one device): asynchronous critic
     all-reduce with the actor's E products under it + wait(), everything in program order, and no collective at all must leave
