@@ -934,7 +934,7 @@ class TrainWorkload:
             self.torch.cuda.synchronize()
         if self._native is not None:
             _capi.check(self.agent.L.shems_train_loop_release(C.byref(self._native)))
-        if self.agent.sync.direct:
+        if getattr(self.agent.sync, "direct", False):
             n = C.c_int64(0)
             self.agent.L.shems_dp_direct_timeouts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
             self.agent.L.shems_dp_direct_timeouts.restype = C.c_int
@@ -946,6 +946,14 @@ class TrainWorkload:
             raise RuntimeError("a device-side wait of the pipelined loop gave up: the steps since the last check are invalid")
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
             raise RuntimeError("non-finite network parameters after the timed steps")
+        # replicas: every rank's learner must hold the same bytes (they started identical and added the same gradients in the same order);
+        # gathered here, where every rank passes, and reported by rank 0 (`replica_crc32_distinct`: 1 = identical)
+        self.replica_crcs = None
+        sync = self.agent.sync
+        if sync.dist is not None:
+            crcs = [None] * sync.dist.get_world_size()
+            sync.dist.all_gather_object(crcs, self._learner_crc())
+            self.replica_crcs = crcs
 
     def kernel_pass(self, reps):
         """HIP-event timing of the dominant kernel (the fused actor/step launch) IN THE LOOP IT RUNS IN.
@@ -1002,7 +1010,7 @@ class TrainWorkload:
                 loc_avg = time_launches(torch, updates_only, reps)[0] if self.updates else 0.0
                 self.agent.sync = sync
                 gc, ga = torch.zeros_like(self.agent.grad_critic), torch.zeros_like(self.agent.grad_actor)
-                if sync.direct:                     # no all-reduce exists on its own: the exchange is inside the ADAM sweeps
+                if getattr(sync, "direct", False):  # no all-reduce exists on its own: the exchange is inside the ADAM sweeps
                     ar = lambda g: None
                 elif sync.native is not None:       # the exchange as the update issues it: RCCL in this stream, from native code
                     Lc = self.agent.L
@@ -1039,16 +1047,21 @@ class TrainWorkload:
                     method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
                            + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))
 
-    def extra(self):
+    def _learner_crc(self):
         import zlib
-        crc = zlib.crc32(self.agent.actor.detach().cpu().numpy().tobytes()) ^ zlib.crc32(self.agent.critic_t.detach().cpu().numpy().tobytes())
-        return {"updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": self.mem_size,
+        return zlib.crc32(self.agent.actor.detach().cpu().numpy().tobytes()) ^ zlib.crc32(self.agent.critic_t.detach().cpu().numpy().tobytes())
+
+    def extra(self):
+        crc = self._learner_crc()
+        rc = getattr(self, "replica_crcs", None)
+        return {"replica_crc32_distinct": None if rc is None else len(set(rc)),
+                "updates_per_step": self.updates, "batch_size": BATCH_SIZE, "mem_size": self.mem_size,
                 "replay_mode": "scaled (capacity 72 N, every env inserts)" if self.scaled_replay else "window (MEM_SIZE = 24 000, 333 envs insert per step)",
                 "overlap": {LOOP_ORDERED: False, LOOP_PIPELINED: "pipelined", LOOP_PIPELINED_EXACT: "exact"}[self.overlap_mode],
                 "loop": self.loop,
                 "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
                 "dp_exchange": None if self.agent.sync.world == 1 else (
-                    "direct exchange through peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg), no collective launch" if self.agent.sync.direct else
+                    "direct exchange through peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg), no collective launch" if getattr(self.agent.sync, "direct", False) else
                     "RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)" if self.agent.sync.native is not None else
                     "torch.distributed all_reduce (its own stream)"),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),

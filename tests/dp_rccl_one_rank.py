@@ -43,6 +43,7 @@ class HalfWorld(P.GradSync):
         self.dist = dist if collective else None
         self.world, self.rank = 2, 0
         self.native = native
+        self.direct = False
 
 
 NATIVE = P.native_comm(dist)

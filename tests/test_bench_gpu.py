@@ -98,6 +98,7 @@ def _check_data_parallel_fields(d, world):
     # round 4: how the gradients travel.  Two ranks on ONE device cannot have an RCCL communicator ("Duplicate GPU detected"), so the
     # rehearsal must have fallen back -- on every rank, by vote -- to torch.distributed, and the line says which path ran
     assert d["dp_exchange"].startswith("torch.distributed") and d["loop"] == "host"
+    assert d["replica_crc32_distinct"] == 1                             # every rank's learner ended with the same bytes (gathered in finish())
 
 
 def test_bench_starts_its_own_ranks_without_torchrun():
@@ -154,6 +155,12 @@ def test_direct_gradient_exchange_two_ranks_on_one_device():
     assert out["direct"]["dp_exchange"].startswith("direct exchange") and out["direct"]["loop"] == "native"
     assert out["torch"]["dp_exchange"].startswith("torch.distributed") and out["torch"]["loop"] == "host"
     assert out["direct"]["learner_crc32"] == out["torch"]["learner_crc32"], (out["direct"]["learner_crc32"], out["torch"]["learner_crc32"])
+    assert out["direct"]["replica_crc32_distinct"] == 1 and out["torch"]["replica_crc32_distinct"] == 1
+    # four replicas (four rank processes on the one device): the rank-order sum of four gradients is no longer gloo's order, so only the
+    # replicas are held to each other -- all four learners bit-identical after 54 exchanged updates, no wait gave up
+    d4 = _run([sys.executable, "bench.py", "--gpus", "4", "--steps", "48", "--warmup", "6", "--envs", "2048", "--prewarm-s", "0"],
+              env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP": "direct"})
+    assert d4["n_gpus"] == 4 and d4["dp_exchange"].startswith("direct exchange") and d4["replica_crc32_distinct"] == 1
 
 
 def test_rccl_stream_ordering_on_a_one_rank_group():

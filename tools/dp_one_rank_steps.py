@@ -14,6 +14,7 @@ class HalfWorld(P.GradSync):
         self.dist = dist if collective else None
         self.world, self.rank = 2, 0
         self.native = native
+        self.direct = False
 native = P.native_comm(dist)                                     # a ONE-rank shems_dp communicator: RCCL in the update's own stream, from native code
 assert native is not None, "no native communicator"
 out = {}
