@@ -50,7 +50,10 @@ void load_rccl()
 int need_rccl(const char *fn)
 {
     std::call_once(g_rccl_once, load_rccl);
-    if (!g_rccl.h) return set_error(SHEMS_ERR_STATE, "%s: RCCL (librccl.so.1) could not be loaded: %s", fn, dlerror() ? dlerror() : "symbols missing");
+    if (!g_rccl.h) {
+        const char *why = dlerror();
+        return set_error(SHEMS_ERR_STATE, "%s: RCCL (librccl.so.1) could not be loaded: %s", fn, why ? why : "library or symbols missing");
+    }
     return SHEMS_OK;
 }
 int nccl_ok(ncclResult_t r, const char *what)
