@@ -570,6 +570,10 @@ def main():
             print(json.dumps(out), flush=True)
         else:
             os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if hasattr(wl, "close"):
+        if dist is not None:
+            dist.barrier()                        # nobody tears its end of a communicator down while a peer still exchanges
+        wl.close()
     if dist is not None:
         dist.destroy_process_group()
 

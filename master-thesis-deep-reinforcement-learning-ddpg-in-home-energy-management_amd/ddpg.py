@@ -955,6 +955,19 @@ class TrainWorkload:
             sync.dist.all_gather_object(crcs, self._learner_crc())
             self.replica_crcs = crcs
 
+    def close(self):
+        """End of the run: give the native communicator / the direct exchange's mappings back (every rank calls it; idempotent)."""
+        sync = self.agent.sync
+        h = getattr(sync, "native", None)
+        if h is not None:
+            self.torch.cuda.synchronize()
+            self.agent.L.shems_dp_destroy.argtypes = [C.c_void_p]
+            self.agent.L.shems_dp_destroy.restype = C.c_int
+            sync.native, sync.direct = None, False
+            if self._native is not None:
+                self._native.dp = None
+            self.agent.L.shems_dp_destroy(h)
+
     def kernel_pass(self, reps):
         """HIP-event timing of the dominant kernel (the fused actor/step launch) IN THE LOOP IT RUNS IN.
 
