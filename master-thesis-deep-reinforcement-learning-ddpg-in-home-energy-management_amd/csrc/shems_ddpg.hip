@@ -1082,13 +1082,34 @@ __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
     }
 }
 
+// Two consecutive elements per thread (8-byte accesses): twice the workgroups of adam_vec4 -- a sweep of 129 k elements then covers 252 of the
+// 256 CUs instead of 126 (round 4; the default of the data-parallel sweep).  i0 is a multiple of 2.
+__device__ __forceinline__ void adam_vec2(const AdamCtx &c, int i0)
+{
+    if (i0 + 1 < c.n) {
+        const float2 g2 = *reinterpret_cast<const float2 *>(c.g + i0);
+        float2 m2 = *reinterpret_cast<const float2 *>(c.mt + i0), v2 = *reinterpret_cast<const float2 *>(c.vt + i0);
+        float2 p2 = *reinterpret_cast<const float2 *>(c.p + i0), t2 = *reinterpret_cast<const float2 *>(c.target + i0);
+        adam_math(c, g2.x, m2.x, v2.x, p2.x, t2.x);
+        adam_math(c, g2.y, m2.y, v2.y, p2.y, t2.y);
+        *reinterpret_cast<float2 *>(c.mt + i0) = m2; *reinterpret_cast<float2 *>(c.vt + i0) = v2;
+        *reinterpret_cast<float2 *>(c.p + i0) = p2; *reinterpret_cast<float2 *>(c.target + i0) = t2;
+        if (c.publish) *reinterpret_cast<float2 *>(c.publish + i0) = p2;
+    } else {
+        for (int i = i0; i < c.n; ++i) adam_elem(c, i, c.g[i]);
+    }
+}
+
 // Data-parallel form only (a gradient all-reduce sits between the gradient launch and this sweep).
+template <int EPT>
 __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
 {
     gshift(c, blockIdx.z * gstride);
-    const int i0 = 4 * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
-    if (i0 < c.n) adam_vec4(c, i0);
+    const int i0 = EPT * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
+    if (i0 < c.n) { if constexpr (EPT == 4) adam_vec4(c, i0); else adam_vec2(c, i0); }
 }
+// default 2: 40.1-40.3 against 40.6-40.9 us per split-form update, alternating runs (SHEMS_ADAM_EPT=4: the 16-byte form)
+static int adam_ept() { static const int e = []() { const char *v = getenv("SHEMS_ADAM_EPT"); return v && atoi(v) == 4 ? 4 : 2; }(); return e; }
 
 // Data-parallel form with the DIRECT exchange (XchgArgs, shems_internal.h): push my range of the gradient to every peer, wait for
 // theirs, sum in rank order, ADAM.  One workgroup = 1 024 consecutive parameters = 256 threads x 4; the same range on every rank.
@@ -1794,7 +1815,8 @@ static int adam_launch(const shems_ddpg *d, bool critic, const AdamScalars &s, h
 {
     if (int rc = check_adam(s.bp1, s.bp2, "adam")) return rc;
     const AdamCtx c = adam_ctx(d, critic, s);
-    hipLaunchKernelGGL(k_adam_soft, dim3((c.n + 1023) / 1024, 1, L), dim3(256), 0, st, c, gs);
+    if (adam_ept() == 2) hipLaunchKernelGGL(k_adam_soft<2>, dim3((c.n + 511) / 512, 1, L), dim3(256), 0, st, c, gs);
+    else hipLaunchKernelGGL(k_adam_soft<4>, dim3((c.n + 1023) / 1024, 1, L), dim3(256), 0, st, c, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -1807,7 +1829,7 @@ int adam_soft_sweep(float *p, const float *g, float *m, float *v, float *target,
     for (const void *q : {(const void *)p, (const void *)g, (const void *)m, (const void *)v, (const void *)target, (const void *)publish})
         if (((uintptr_t)q & 15) != 0) return set_error(SHEMS_ERR_ARG, "adam_soft_sweep: buffers must be 16-byte aligned");
     const AdamCtx c{p, g, m, v, target, publish, n, 0, eta, bp1, bp2, gscale, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), tau};
-    hipLaunchKernelGGL(k_adam_soft, dim3((n + 1023) / 1024, 1, 1), dim3(256), 0, st, c, (int64_t)0);
+    hipLaunchKernelGGL(k_adam_soft<4>, dim3((n + 1023) / 1024, 1, 1), dim3(256), 0, st, c, (int64_t)0);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 }  // namespace shems
