@@ -124,16 +124,29 @@ void free_sync(LoopSync *s)
     delete s;
 }
 
-int sync_of(shems_train_loop *L, LoopSync **out)
+// The in-kernel form serves SHEMS_LOOP_PIPELINED at <= 16 384 envs when asked for; everything else is queue-level.
+bool want_device(const shems_train_loop *L)
 {
+    const char *how = getenv("SHEMS_LOOP_SYNC");
+    return how && !strcmp(how, "device") && L->mode == SHEMS_LOOP_PIPELINED && L->view.n_envs <= 16384;
+}
+
+int sync_of(shems_train_loop *L, LoopSync **out, hipStream_t a, hipStream_t b)
+{
+    if (L->sync && static_cast<LoopSync *>(L->sync)->device != want_device(L)) {
+        // the caller changed the mode (or the batch) on a live record: the other form's objects do not exist -- drain and start over
+        if (int rc = hip_ok(hipStreamSynchronize(a), "hipStreamSynchronize")) return rc;
+        if (int rc = hip_ok(hipStreamSynchronize(b), "hipStreamSynchronize")) return rc;
+        free_sync(static_cast<LoopSync *>(L->sync));
+        L->sync = nullptr;
+    }
     if (!L->sync) {
         LoopSync *s = new (std::nothrow) LoopSync;
         if (!s) return set_error(SHEMS_ERR_NOMEM, "shems_train_steps: out of host memory");
         if (int rc = hip_ok(hipGetDevice(&s->dev_id), "hipGetDevice")) { delete s; return rc; }
         int can = 0;
         const char *how = getenv("SHEMS_LOOP_SYNC");
-        const bool dev_allowed = how && !strcmp(how, "device");
-        if (dev_allowed && L->mode == SHEMS_LOOP_PIPELINED && L->view.n_envs <= 16384) {
+        if (want_device(L)) {
             if (int rc = hip_ok(hipMalloc((void **)&s->d_words, kDevSyncBytes), "hipMalloc(sync words)")) { delete s; return rc; }
             if (int rc = hip_ok(hipMemset(s->d_words, 0, kDevSyncBytes), "hipMemset(sync words)")) { free_sync(s); return rc; }
             s->device = true;
@@ -214,7 +227,7 @@ int shems_train_steps(shems_train_loop *L, int64_t k, void *stream, void *stream
     hipStream_t A = (hipStream_t)stream, B = (hipStream_t)stream2;
     LoopSync *S = nullptr;
     if (L->mode != SHEMS_LOOP_ORDERED)
-        if (int rc = sync_of(L, &S)) return rc;
+        if (int rc = sync_of(L, &S, A, B)) return rc;
     const int64_t n = L->view.n_envs, cap = L->ring.capacity;
     if (S && S->next_t >= 0 && S->next_t != L->t)
         if (int rc = S->restart(A, B, L->t)) return rc;

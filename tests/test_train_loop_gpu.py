@@ -211,3 +211,29 @@ def test_every_way_of_carrying_the_pipeline_dependencies_gives_the_same_bytes():
         assert r.returncode == 0, r.stderr[-2000:]
         got[how] = [ln for ln in r.stdout.splitlines() if ln.startswith("SYNC")][-1]
     assert len(set(got.values())) == 1, got
+
+
+def test_mode_change_on_a_live_loop_record():
+    """A caller may flip shems_train_loop.mode between calls (the record is caller-owned): the loop's dependency objects of the other form
+    are made afresh behind a drain.  Pipelined with in-kernel waits (SHEMS_LOOP_SYNC=device) -> order-exact (queue-level) -> pipelined;
+    child process: the knob is read when the objects are made."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, importlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import util as U, torch
+S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg")
+wl = D.TrainWorkload(S, torch, 4096, seed=5, updates=1, loop="native", overlap="pipelined")
+wl.steps(20)
+L = wl._native_loop(); L.mode = D.LOOP_PIPELINED_EXACT; wl.overlap_mode = D.LOOP_PIPELINED_EXACT
+wl.steps(20)
+L = wl._native_loop(); L.mode = D.LOOP_PIPELINED; wl.overlap_mode = D.LOOP_PIPELINED
+wl.steps(20)
+wl.finish()
+assert wl.t == 60 and wl.agent.updates == 60 and bool(torch.isfinite(wl.agent.actor).all())
+print("MODES ok")
+""" % (root, os.path.join(root, "tests"))
+    e = dict(os.environ); e["SHEMS_LOOP_SYNC"] = "device"
+    r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "MODES ok" in r.stdout, r.stderr[-2000:]
