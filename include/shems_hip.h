@@ -235,7 +235,7 @@ int shems_actor_forward_dev(const shems_act_params *p, const float *d_obs, int64
 int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_a, double *d_rewards,
                        float *d_rewards_f32, double *d_block_reward, double *d_returns_acc,
                        const shems_replay *ring, const shems_ring_window *window, void *stream);
-/* The same fused step for the envs [env_lo, env_lo + env_count) of the view only (the other envs are not touched).  Every env
+/* The same fused step (DDPG.jl:195-234) for the envs [env_lo, env_lo + env_count) of the view only (the other envs are not touched).  Every env
  * draws its noise from (seed, tick, ITS index in the view) and the ring window is still defined on the whole batch, so stepping a
  * batch range by range -- in any order, on any streams -- leaves the same bytes as one shems_act_step_dev over the view.  The training
  * loop's order-exact pipelined mode steps the window's envs first with it (shems_train_steps). */

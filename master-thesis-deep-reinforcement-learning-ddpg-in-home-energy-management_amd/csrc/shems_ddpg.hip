@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
 }
 
 // Two consecutive elements per thread (8-byte accesses): twice the workgroups of adam_vec4 -- a sweep of 129 k elements then covers 252 of the
-// 256 CUs instead of 126 (round 4; the default of the data-parallel sweep).  i0 is a multiple of 2.
+// 256 CUs instead of 126 (round 4, SHEMS_ADAM_EPT=2: an A/B knob, not the default).  i0 is a multiple of 2.
 __device__ __forceinline__ void adam_vec2(const AdamCtx &c, int i0)
 {
     if (i0 + 1 < c.n) {
@@ -1108,8 +1108,9 @@ __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
     const int i0 = EPT * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
     if (i0 < c.n) { if constexpr (EPT == 4) adam_vec4(c, i0); else adam_vec2(c, i0); }
 }
-// default 2: 40.1-40.3 against 40.6-40.9 us per split-form update, alternating runs (SHEMS_ADAM_EPT=4: the 16-byte form)
-static int adam_ept() { static const int e = []() { const char *v = getenv("SHEMS_ADAM_EPT"); return v && atoi(v) == 4 ? 4 : 2; }(); return e; }
+// default 4 (16-byte accesses).  SHEMS_ADAM_EPT=2 measured 40.1-40.3 against 40.6-40.9 us per split-form update on one box and 40.2-43.6
+// against 40.2-41.4 on another (alternating runs both times): inside the noise of this 7-launch form, so the round-3 form stays
+static int adam_ept() { static const int e = []() { const char *v = getenv("SHEMS_ADAM_EPT"); return v && atoi(v) == 2 ? 2 : 4; }(); return e; }
 
 // Data-parallel form with the DIRECT exchange (XchgArgs, shems_internal.h): push my range of the gradient to every peer, wait for
 // theirs, sum in rank order, ADAM.  One workgroup = 1 024 consecutive parameters = 256 threads x 4; the same range on every rank.
