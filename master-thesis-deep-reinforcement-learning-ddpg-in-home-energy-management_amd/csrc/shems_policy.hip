@@ -1181,24 +1181,37 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
     BVec bf_[3];
     /* k-step K = 8 c + ks: operands in register buffer K % 3, requested two k-steps ago.  One scheduling region per k-step:        */
     /* [TM MFMAs] [A read of K + 2] [TM MFMAs] [B read of K + 2]; one LDS-DMA piece (asm) of chunk c + RD - 1 closes k-steps 0..3.   */
+/* Ablations of the layer-2 loop (diagnostic builds only, wrong results by construction; tools/README.md): which of its resources a     */
+/* co-resident kernel of another launch contends for -- -DABL_G_NODMA=1 (no W2 LDS-DMA), ABL_G_NOLDS=1 (no operand reads), ABL_G_NOMFMA=1. */
+#ifndef ABL_G_NODMA
+#define ABL_G_NODMA 0
+#endif
+#ifndef ABL_G_NOLDS
+#define ABL_G_NOLDS 0
+#endif
+#ifndef ABL_G_NOMFMA
+#define ABL_G_NOMFMA 0
+#endif
 #define G_KSTEP(c, ks)                                                                                          \
     do {                                                                                                        \
         const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
-        if (K2_ < kGKsteps) {                                                                                   \
+        if (K2_ < kGKsteps && !ABL_G_NOLDS) {                                                                   \
             const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
             af_[K2_ % 3] = *reinterpret_cast<const f32x2 *>(Wg + (c2_ % RD) * kGChunkFloats + kr_ * 64 + 2 * li); \
             bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + (c2_ * kKC + kr_) * BM + TM * li);              \
         }                                                                                                       \
+        if (!ABL_G_NOMFMA) {                                                                                    \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
             acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][0], fvec_get<TM>(bf_[K_ % 3], b), acc[0][b], 0, 0, 0); \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
             acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][1], fvec_get<TM>(bf_[K_ % 3], b), acc[1][b], 0, 0, 0); \
+        } else { _Pragma("unroll") for (int b = 0; b < TM; ++b) { acc[0][b][0] += af_[K_ % 3][0] * fvec_get<TM>(bf_[K_ % 3], b); acc[1][b][0] += af_[K_ % 3][1]; } } \
         __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
         __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if ((ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
+        if (!ABL_G_NODMA && (ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
     } while (0)
     /* Two waves per SIMD (NW = 8; waves w and w + 4 share one): the issue arbiter serves the older wave first -- waves 0..3 finish the  */
     /* layer after 19.7 k cycles, waves 4..7 after 35.3 k (32 k of matrix work per SIMD).  Swapping s_setprio between the two every    */

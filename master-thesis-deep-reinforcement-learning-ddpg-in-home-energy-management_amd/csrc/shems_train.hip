@@ -261,7 +261,8 @@ int shems_train_steps(shems_train_loop *L, int64_t k, void *stream, void *stream
                 // K1 of the step's first update: act(t - 1) has finished (ring rows; pub[(t + 1) & 1] no longer read); only the step's last
                 // update publishes and arrives
                 if (last) S->upd_wgs += (unsigned long long)ddpg_last_launch_grid();
-                DevSync first = {u == 0 ? S->flags(0) : nullptr, step_wgs_before, nullptr, nullptr, 0, tmo};
+                static const bool nowait1 = []() { const char *e = getenv("SHEMS_LOOP_DIAG_NOWAIT_K1"); return e && atoi(e) == 1; }();   // timing diagnostics only: drops a real dependency
+                DevSync first = {u == 0 && !nowait1 ? S->flags(0) : nullptr, step_wgs_before, nullptr, nullptr, 0, tmo};
                 DevSync lastl = {nullptr, 0, last ? S->cnt(1) : nullptr, S->flags(1), S->upd_wgs, tmo};
                 if (int rc = ddpg_update_sync(&L->ddpg, &L->ring, ring_len, L->sample_seed, (uint32_t)(L->updates & 0xFFFFFFFFll), use_ring ? w.pos : 0,
                                               use_ring ? w.count : 0, L->eta_crit, L->bp_crit[0], L->bp_crit[1], L->eta_act, L->bp_act[0], L->bp_act[1],
