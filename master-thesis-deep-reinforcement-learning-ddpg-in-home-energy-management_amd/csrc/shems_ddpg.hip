@@ -850,6 +850,9 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef UPD_PRIO
+    __builtin_amdgcn_s_setprio(UPD_PRIO);          // diagnostic builds (tools/corun_probe.py): wave priority of the update's kernels
+#endif
     dev_wait(A.sy);                                // pipelined loop, K1 only: every ring row this update may sample has landed
     constexpr int kPerJob = NT * (BP / 32) + 6;    // K1: a one-dimensional grid of 3 x (64 tile + 6 publishing) workgroups
     const int job = A.prep == 1 ? (int)blockIdx.x / kPerJob : 0, bx = (int)blockIdx.x - job * kPerJob;
@@ -950,6 +953,9 @@ __device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_mid(MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef UPD_PRIO
+    __builtin_amdgcn_s_setprio(UPD_PRIO);
+#endif
     const int64_t off = blockIdx.z * A.gstride;
     if ((int)blockIdx.x < A.nfwd) {
         FwdJob J = A.fwd;
@@ -1580,6 +1586,9 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_grad(GradArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef UPD_PRIO
+    __builtin_amdgcn_s_setprio(UPD_PRIO);
+#endif
     gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
     if (A.in == SIN) grad_body<SIN, 2>(A, smem, (int)blockIdx.x); else grad_body<CIN, 1>(A, smem, (int)blockIdx.x);
     dev_arrive(A.sy, false);                       // the published actor copy is stored write-through (AdamCtx::publish): draining is enough
