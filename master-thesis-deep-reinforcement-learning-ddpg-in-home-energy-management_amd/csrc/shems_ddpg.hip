@@ -469,8 +469,16 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
         }
         return;
     }
+    // Tile -> (n-tile, m-tile): the four batch-column tiles of one n-tile read the same 32-KB W2 panel.  Workgroup ids go round the 8 XCDs, so
+    // (round 4) an n-tile's four workgroups sit 8 ids apart -- one XCD, one L2: the panel is fetched from the Infinity Cache once, not four times.
+#ifdef FWD_NOREMAP
     const int ntile = bx / kMTiles, n0 = ntile * 32;
     const int mbase = 32 * (bx % kMTiles);
+#else
+    static_assert(kMTiles == 4 && NT % 8 == 0, "tile map: 4 m-tiles per n-tile, n-tiles in blocks of 8");
+    const int ntile = (bx & 7) + 8 * (bx >> 5), n0 = ntile * 32;
+    const int mbase = 32 * ((bx >> 3) & 3);
+#endif
     const float *__restrict__ P = J.P;
 
     // ---- every global load of the workgroup goes out before the first one is consumed (one exposed latency).  The small operands of
@@ -682,7 +690,11 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
     float *Mt = pp + 4 * 64;                   // [16 n][32 m]
     float *red = Mt + 16 * 32;                 // [4 quarters][2 j][2 mb][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+#ifdef FWD_NOREMAP
     const int ntile = bx >> 2, n0 = ntile * 16, mbase = 32 * (bx & 3);
+#else
+    const int ntile = (bx & 7) + 8 * (bx >> 5), n0 = ntile * 16, mbase = 32 * ((bx >> 3) & 3);      // an n-tile's four workgroups on one XCD (see fwd_body)
+#endif
     const float *__restrict__ P = J.P;
     STAMP(3, 0);
     // ---- one burst of loads: epilogue constants, input tile, layer-1 image, upstream gradient, then the W2 panel ----
