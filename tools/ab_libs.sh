@@ -1,4 +1,4 @@
-# A/B of library variants inside ONE gpurun call (same box): usage  bash tools/r03_ab.sh "<envs list>" libA.so libB.so ...
+# A/B of library variants inside ONE gpurun call (same box): usage  bash tools/ab_libs.sh "<envs list>" libA.so libB.so ...
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp

@@ -21,3 +21,22 @@ period=(int(a[-1]["Start_Timestamp"])-int(a[0]["Start_Timestamp"]))/1e3/(len(a)-
 print("variant '%s': period %.1f us  act span %s  K1 %s  K2 %s  K3/K5 %s  K4 %s"%("$v", period, dur("k_actg"), dur("k_fwd","53760"), dur("k_mid"), dur("k_grad"), dur("k_fwd","32768")))
 PY
 done
+
+# ---- second part: the same loop with K1's in-kernel wait switched off (timing diagnostics only) ----
+for nw in 0 1; do
+  SHEMS_LOOP_DIAG_NOWAIT_K1=$nw SHEMS_LOOP_SYNC=device timeout -k 10 200 python3 $R/bench.py --envs 4096 --overlap pipelined --steps 2880 --prewarm-s 1 --no-cpu-baseline > $O/b$nw.json 2>$O/err.txt || tail -3 $O/err.txt
+  python3 -c "
+import json; d=json.loads(open('$O/b$nw.json').read().strip().splitlines()[-1]); print('nowait_k1=$nw bench', round(d['ms_per_step']*1e3,2),'us/step')"
+  SHEMS_LOOP_DIAG_NOWAIT_K1=$nw SHEMS_LOOP_SYNC=device rocprofv3 --kernel-trace --output-format csv -d $O/ktw$nw -- python3 $R/bench.py --envs 4096 --overlap pipelined --steps 300 --warmup 50 --prewarm-s 0.1 --no-cpu-baseline > $O/logw$nw.txt 2>&1 || { tail -5 $O/logw$nw.txt; continue; }
+  cp $(find $O/ktw$nw -name "*kernel_trace.csv" | head -1) $O/tracew$nw.csv; rm -rf $O/ktw$nw
+  python3 - <<PY
+import csv
+rows=list(csv.DictReader(open("$O/tracew$nw.csv")))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+idx=[i for i,r in enumerate(rows) if 'k_actg' in r["Kernel_Name"]]
+i0=idx[len(idx)//2]; t0=int(rows[i0]["Start_Timestamp"])
+print("== nowait_k1=$nw")
+for r in rows[i0:i0+13]:
+    print("%-30s q=%s %8.2f -> %8.2f (%6.2f us) grid %s"%(r["Kernel_Name"][:30], r.get("Queue_Id"), (int(r["Start_Timestamp"])-t0)/1e3,(int(r["End_Timestamp"])-t0)/1e3,(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3, r["Grid_Size_X"]))
+PY
+done
