@@ -33,6 +33,7 @@ def _worker(rank, world, port, out_dir):
     # the gradients then travel through torch.distributed
     msgs = []
     assert P.native_comm(dist, timeout_s=30.0, log=msgs.append) is None and msgs
+    assert P.direct_comm(dist, log=msgs.append) is None  # the direct exchange needs device memory too: dropped on every rank, by vote
     os.environ["SHEMS_DP"] = "torch"
     assert P.native_comm(dist) is None                  # switched off: no attempt, no collective
     del os.environ["SHEMS_DP"]
