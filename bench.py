@@ -523,6 +523,8 @@ def main():
         roof["traffic_ratio"] = traffic / k["algorithmic_bytes"] if traffic and k.get("algorithmic_bytes") else None
         if k.get("avg_us_is"):
             roof["kernel_avg_us_is"] = k["avg_us_is"]
+        if k.get("back_to_back_us") is not None:
+            roof["kernel_back_to_back_us"] = k["back_to_back_us"]      # the same launch timed directly, back to back: the cross-check of the difference
         if world == 1 and not args.no_cpu_baseline and args.hidden.lower() == "250x500":      # (the CPU port is timed at the headline architecture)
             t_cpu0 = time.perf_counter()
             cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)

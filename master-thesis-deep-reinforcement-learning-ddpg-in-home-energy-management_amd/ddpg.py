@@ -1017,6 +1017,10 @@ class TrainWorkload:
                 upd_avg, upd_med, _ = time_launches(torch, updates_only, reps)
             else:
                 upd_avg = upd_med = 0.0
+            # cross-check of the difference above: the fused launch alone, back to back (no update between two of them: the chip holds a
+            # lower clock under the uninterrupted MFMA load, so this reads a few per cent ABOVE the in-loop figure -- rocprofv3 showed 139.6
+            # against 133.3 us inside one trace in round 2 -- but it is a direct timing of the kernel with nothing subtracted)
+            alone_avg = time_launches(torch, lambda i: self._act(i), min(reps, 96))[0] if not self.agent.wide else None
             if world > 1:
                 self.agent.sync = GradSync(None)         # same 7 launches, no exchange
                 self.agent.fused = False
@@ -1056,6 +1060,7 @@ class TrainWorkload:
         return dict(kernel=kname, avg_us=step_avg - upd_avg, median_us=step_med - upd_med, launches=n,
                     bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3,
                     algorithmic_bytes=None if self.agent.wide else act_algorithmic_bytes(self.n, self.win),
+                    back_to_back_us=alone_avg,
                     avg_us_is="vector step minus replay(): the fused launch together with the gap in front of it, not a timing of the kernel alone (rocprofv3's per-kernel average in profiles/ is the cross-check)",
                     method="HIP events over groups of 8 vector steps minus groups of 8 replay() alone (the kernel inside its loop, launch gap included)"
                            + ("; data parallel: the gradient exchange is inside both, figures are the max over ranks" if world > 1 else ""))

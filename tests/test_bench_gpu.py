@@ -38,6 +38,7 @@ def test_bench_json_contract_small():
     assert r["kernel"] == "shems::k_actg<1, 4, 2, 2>" and "|" not in r["kernel"]
     assert r["algorithmic_bytes"] == 92 * 8192 + 4 * 129002 + 85 * 333 and "hbm_gbs" in r and "traffic_ratio" in r
     assert "minus replay" in r["kernel_avg_us_is"]
+    assert 0.7 * r["kernel_avg_us"] < r["kernel_back_to_back_us"] < 1.5 * r["kernel_avg_us"]      # the direct timing agrees with the difference
     assert d["gpu_section_s"] > 0 and d["roofline_pass_s"] > 0 and d["cpu_baseline_s"] == 0.0
     assert d["overlap"] is False and d["loop"] == "native"
 
