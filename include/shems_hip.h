@@ -301,10 +301,6 @@ typedef struct shems_ddpg {
 enum { SHEMS_DDPG_DEFER_ACTOR_E = 1 };
 
 int shems_ddpg_workspace_floats(int64_t *out);
-/* The pipelined training loop's opt-in device-side form (shems_train_steps, SHEMS_LOOP_SYNC=device) makes launches wait, bounded, inside
- * the kernel.  *out = how many workgroups gave up such a wait on this workspace since the last call (read and cleared; 0 in every
- * supported use; non-zero = the steps enqueued since then are invalid).  Synchronises `stream`. */
-int shems_ddpg_sync_timeouts(const struct shems_ddpg *d, int64_t *out, void *stream);
 /* The whole replay() for one replica.  grad_actor / grad_critic still receive the complete gradients.  excl_pos / excl_count:
  * as shems_ddpg_critic_grad_ex (0, 0 = none).  d_publish: optional second copy [129002] of the updated actor (see
  * shems_ddpg_actor_apply_pub), or NULL. */
@@ -382,7 +378,7 @@ int shems_ddpg_update_dp(const shems_ddpg *d, const shems_replay *ring, int64_t 
  * mode SHEMS_LOOP_PIPELINED_EXACT : the envs of step t's ring window are stepped FIRST (their own launch on `stream`), replay(t) then
  *                             runs on `stream2` and samples the ring WITH those inserts while the rest of the batch is stepped on
  *                             `stream`: the same bytes as SHEMS_LOOP_ORDERED.
- * The struct is caller-owned state: fields marked in/out are advanced by the call.  `sync` holds the loop's events and is created on
+ * The struct is caller-owned state: fields marked in/out are advanced by the call.  `sync` holds the loop's two signal-memory words (stream memory operations) and is created on
  * first use of a pipelined mode; release it with shems_train_loop_release (it does not touch the device buffers). */
 enum { SHEMS_LOOP_ORDERED = 0, SHEMS_LOOP_PIPELINED = 1, SHEMS_LOOP_PIPELINED_EXACT = 2 };
 typedef struct shems_train_loop {
@@ -438,6 +434,18 @@ int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, co
 int shems_ddpg_group_update(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
                             uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit,
                             double eta_act, double bp1_act, double bp2_act, void *stream);
+/* The same function in its THROUGHPUT form (csrc/shems_gupd.hip): for groups wide enough that nothing is latency-bound any more
+ * (the thesis protocol runs 40 seeds x 10 chargers = 400 learners, RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87) -- plain
+ * back-propagation on small tiles, 4 workgroups resident per CU, eight launches for the whole group.  Same sampler, same ADAM
+ * arithmetic; the products sum in another order than the five-launch form above, so per learner the two agree to fp32
+ * accumulation accuracy (every gradient block within 2e-6 of its max-abs of a float64 evaluation), not bit for bit.
+ * flags: SHEMS_TP_STORE_GRAD also leaves the gradients in grad_actor / grad_critic (otherwise they are never materialised;
+ * the b3 / layer-1 / W2 / b2 / W3 elements are consumed by ADAM in the lane that finishes them).  Uses d0->ws with a layout of
+ * its own: do not mix the two forms on one workspace within one update. */
+enum { SHEMS_TP_STORE_GRAD = 1 };
+int shems_ddpg_group_update_tp(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
+                               uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit,
+                               double eta_act, double bp1_act, double bp2_act, int32_t flags, void *stream);
 int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g,
                                  int64_t ring_len, uint64_t seed, uint32_t tick, void *stream);
 int shems_ddpg_group_critic_apply(const shems_ddpg *d0, const shems_group *g, double eta, double bp1, double bp2,

@@ -22,6 +22,7 @@ UNITS = [
     ("shems_env.hip", ["-ffp-contract=off"]),
     ("shems_policy.hip", []),
     ("shems_ddpg.hip", []),
+    ("shems_gupd.hip", []),
     ("shems_track.hip", ["-ffp-contract=off"]),
     ("shems_wide.hip", []),
     ("shems_train.hip", []),
@@ -79,7 +80,9 @@ def build(force=False, verbose=False, defines=(), tag=""):
 
 if __name__ == "__main__":
     import sys
-    if "--stamp" in sys.argv:
+    if "--stamp-act" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, defines=("SHEMS_STAMP_ACT",), tag="_stampact"))
+    elif "--stamp" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, defines=("SHEMS_STAMP",), tag="_stamp"))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -39,6 +39,7 @@
 
 #include "philox.h"
 #include "shems_internal.h"
+#include "shems_adam.h"
 
 namespace shems {
 
@@ -96,9 +97,9 @@ constexpr int64_t SL_SIZE = SL_EP + NQ * H1N * BP;
 enum { SLOT_ACTOR_T = 0, SLOT_CRITIC_T = 1, SLOT_CRITIC = 2, SLOT_ACTOR = 3, SLOT_CRITIC2 = 4, N_SLOTS = 5 };
 static_assert(WS_W1T % 4 == 0 && WS_SLOT0 % 4 == 0 && SL_SIZE % 4 == 0, "16-byte aligned blocks");
 __host__ __device__ inline float *w1t_of(float *ws, int net) { return ws + WS_W1T + (int64_t)net * 12 * 256; }   // net = SLOT_* < 4
-constexpr int64_t WS_SYNC = WS_SLOT0 + N_SLOTS * SL_SIZE;      // three 128-byte lines; the third holds SY_TIMEOUT: device-side waits of the pipelined
-constexpr int64_t WS_FLOATS = WS_SYNC + 96;                    // training loop that gave up (DevSync, shems_internal.h; shems_ddpg_sync_timeouts).  Round 3's
-constexpr int SY_TIMEOUT = 64;                                 // merged K4 + K5 launch used the first two (measured slower, profiles/r03_update_merge.txt; removed)
+constexpr int64_t WS_SYNC = WS_SLOT0 + N_SLOTS * SL_SIZE;      // 96 reserved words (rounds 3 / 4 kept the bookkeeping of two removed launch forms here;
+constexpr int64_t WS_FLOATS = WS_SYNC + 96;                    // the size stays so that existing callers' allocations and snapshots keep their layout)
+static_assert(WS_FLOATS == kTpWsFloats, "shems_internal.h states the workspace size for shems_gupd.hip");
 
 __host__ __device__ inline float *slot(float *ws, int s) { return ws + WS_SLOT0 + (int64_t)s * SL_SIZE; }
 
@@ -143,15 +144,6 @@ struct XSrc {
     float *publish;        // optional [2][BP]: where workgroup 0 stores the computed action
 };
 
-// Learner groups (shems_group): learner l's copy of every device buffer is learner 0's pointer + l * stride bytes.
-template <class T>
-__device__ __forceinline__ T *gsh(T *p, int64_t off)
-{
-    // byte arithmetic on the pointer itself (no round trip through an integer): the compiler keeps the global address space of the
-    // kernel argument it came from and emits global_load / global_store instead of flat accesses
-    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
-    return p ? reinterpret_cast<T *>(reinterpret_cast<B *>(p) + off) : p;
-}
 __device__ __forceinline__ void gshift(XSrc &x, int64_t off)
 {
     x.X = gsh(x.X, off); x.A = gsh(x.A, off); x.P3 = gsh(x.P3, off); x.b3 = gsh(x.b3, off); x.publish = gsh(x.publish, off);
@@ -397,7 +389,7 @@ struct FwdJob {
     const float *d3q;      // QG: [BP] upstream gradient of q (-1/B, 0 in the pad columns)
     float *DAP;            // QG: [NT][2][BP] partial d loss / d a_pi
 };
-struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; DevSync sy; };   // sy: K1 of a pipelined loop waits for the step kernel that filled the ring    // prep: 1 = this launch opens the update (K1), 2 = K4
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int prep; PrepArgs pa; };   // prep: 1 = this launch opens the update (K1), 2 = K4
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
     J.w1t = gsh(J.w1t, off); J.P = gsh(J.P, off); gshift(J.x, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off);
@@ -471,14 +463,9 @@ __device__ __forceinline__ void fwd_body(const FwdJob &J, float *smem, const Pre
     }
     // Tile -> (n-tile, m-tile): the four batch-column tiles of one n-tile read the same 32-KB W2 panel.  Workgroup ids go round the 8 XCDs, so
     // (round 4) an n-tile's four workgroups sit 8 ids apart -- one XCD, one L2: the panel is fetched from the Infinity Cache once, not four times.
-#ifdef FWD_NOREMAP
-    const int ntile = bx / kMTiles, n0 = ntile * 32;
-    const int mbase = 32 * (bx % kMTiles);
-#else
     static_assert(kMTiles == 4 && NT % 8 == 0, "tile map: 4 m-tiles per n-tile, n-tiles in blocks of 8");
     const int ntile = (bx & 7) + 8 * (bx >> 5), n0 = ntile * 32;
     const int mbase = 32 * ((bx >> 3) & 3);
-#endif
     const float *__restrict__ P = J.P;
 
     // ---- every global load of the workgroup goes out before the first one is consumed (one exposed latency).  The small operands of
@@ -690,11 +677,7 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
     float *Mt = pp + 4 * 64;                   // [16 n][32 m]
     float *red = Mt + 16 * 32;                 // [4 quarters][2 j][2 mb][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
-#ifdef FWD_NOREMAP
-    const int ntile = bx >> 2, n0 = ntile * 16, mbase = 32 * (bx & 3);
-#else
     const int ntile = (bx & 7) + 8 * (bx >> 5), n0 = ntile * 16, mbase = 32 * ((bx >> 3) & 3);      // an n-tile's four workgroups on one XCD (see fwd_body)
-#endif
     const float *__restrict__ P = J.P;
     STAMP(3, 0);
     // ---- one burst of loads: epilogue constants, input tile, layer-1 image, upstream gradient, then the W2 panel ----
@@ -862,10 +845,6 @@ __device__ __forceinline__ void qg16_body(const FwdJob &J, float *smem, int bx)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef UPD_PRIO
-    __builtin_amdgcn_s_setprio(UPD_PRIO);          // diagnostic builds (tools/corun_probe.py): wave priority of the update's kernels
-#endif
-    dev_wait(A.sy);                                // pipelined loop, K1 only: every ring row this update may sample has landed
     constexpr int kPerJob = NT * (BP / 32) + 6;    // K1: a one-dimensional grid of 3 x (64 tile + 6 publishing) workgroups
     const int job = A.prep == 1 ? (int)blockIdx.x / kPerJob : 0, bx = (int)blockIdx.x - job * kPerJob;
     FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];      // (no dynamic indexing of the kernarg block: that goes through scratch)
@@ -965,9 +944,6 @@ __device__ __forceinline__ void e_body(const EJob &E, int b, float *smem)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_mid(MidArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef UPD_PRIO
-    __builtin_amdgcn_s_setprio(UPD_PRIO);
-#endif
     const int64_t off = blockIdx.z * A.gstride;
     if ((int)blockIdx.x < A.nfwd) {
         FwdJob J = A.fwd;
@@ -982,51 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     e_body(E, e % (KT * NQ), smem);
 }
 
-// ---- Flux 0.12.1 ADAM + soft target update -----------------------------------------------------------------------------
-//   mt = b1*mt + (1-b1)*g ; vt = b2*vt + (1-b2)*g^2 ; delta = mt/(1-bp1) / (sqrt(vt/(1-bp2)) + eps) * eta ; p -= delta
-//   (Float64 scalars broadcast over Float32 arrays: each element is computed in f64 and stored as f32; g^2 is the Float32 square)
-//   then target = (1f0 - tau) * target + tau * p   (DDPG.jl:99-103)
-struct AdamCtx {
-    float *p; const float *g; float *mt, *vt, *target; float *publish;
-    int n, in; double eta, bp1, bp2, gscale;
-    double k1, ic2;        // eta / (1 - bp1), 1 / (1 - bp2): host-side Float64 quotients
-    float tau;
-};
-__device__ __forceinline__ void gshift(AdamCtx &c, int64_t off)
-{
-    c.p = gsh(c.p, off); c.g = gsh(c.g, off); c.mt = gsh(c.mt, off); c.vt = gsh(c.vt, off); c.target = gsh(c.target, off);
-    c.publish = gsh(c.publish, off);
-}
-
-// One element of ADAM + soft update on values: (m, v, p, target) in, updated in place.
-__device__ __forceinline__ void adam_math(const AdamCtx &c, float graw, float &m, float &v, float &p, float &t)
-{
-    // Julia evaluates the broadcast expressions without fusing multiplies into adds; keeping the compiler from contracting also
-    // makes the inlined copies of this function (gradient tiles / sweep) round identically.
-#pragma clang fp contract(off)
-    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
-    const float gf = (float)((double)graw * c.gscale);          // averaged gradient, as every replica holds it
-    const float m1 = (float)(b1 * (double)m + (1.0 - b1) * (double)gf);
-    const float g2 = gf * gf;                                    // Flux 0.12.1 `Δ^2` on a Float32 array: literal_pow = Δ*Δ in Float32, then promoted
-    const float v1 = (float)(b2 * (double)v + (1.0 - b2) * (double)g2);
-    // delta = Float32(mt / (1 - bp1) / (sqrt(vt / (1 - bp2)) + eps) * eta), every operation in Float64 (Flux's scalars are Float64).
-    // Evaluated as (mt * k1) / s with s = sqrt(vt * ic2) + eps, k1 = eta / (1 - bp1), ic2 = 1 / (1 - bp2), the quotient by a
-    // reciprocal refined to <= 1 ulp (two Newton steps + a residual correction): three Float64 divisions become none.  The Float64
-    // value differs from the reference's left-to-right evaluation by a few ulp(Float64) at most, i.e. the Float32 it rounds to
-    // differs only when it falls within ~1e-15 of a Float32 rounding boundary (about one element in 1e7, by one Float32 ulp of delta).
-    const double sq = sqrt((double)v1 * c.ic2) + eps;
-    double y = __builtin_amdgcn_rcp(sq);
-    y = __builtin_fma(__builtin_fma(-sq, y, 1.0), y, y);
-    y = __builtin_fma(__builtin_fma(-sq, y, 1.0), y, y);
-    const double tnum = (double)m1 * c.k1;
-    double qd = tnum * y;
-    qd = __builtin_fma(__builtin_fma(-sq, qd, tnum), y, qd);
-    const float delta = (float)qd;
-    const float pn = p - delta;
-    const float one_m_tau = 1.0f - c.tau;
-    t = one_m_tau * t + c.tau * pn;
-    m = m1; v = v1; p = pn;
-}
+// ---- Flux 0.12.1 ADAM + soft target update: AdamCtx / adam_math live in shems_adam.h (shared with shems_gupd.hip) ----
 __device__ __forceinline__ void adam_elem(const AdamCtx &c, int i, float graw)
 {
     float m = c.mt[i], v = c.vt[i], p = c.p[i], t = c.target[i];
@@ -1100,35 +1032,15 @@ __device__ __forceinline__ void adam_vec4(const AdamCtx &c, int i0)
     }
 }
 
-// Two consecutive elements per thread (8-byte accesses): twice the workgroups of adam_vec4 -- a sweep of 129 k elements then covers 252 of the
-// 256 CUs instead of 126 (round 4, SHEMS_ADAM_EPT=2: an A/B knob, not the default).  i0 is a multiple of 2.
-__device__ __forceinline__ void adam_vec2(const AdamCtx &c, int i0)
-{
-    if (i0 + 1 < c.n) {
-        const float2 g2 = *reinterpret_cast<const float2 *>(c.g + i0);
-        float2 m2 = *reinterpret_cast<const float2 *>(c.mt + i0), v2 = *reinterpret_cast<const float2 *>(c.vt + i0);
-        float2 p2 = *reinterpret_cast<const float2 *>(c.p + i0), t2 = *reinterpret_cast<const float2 *>(c.target + i0);
-        adam_math(c, g2.x, m2.x, v2.x, p2.x, t2.x);
-        adam_math(c, g2.y, m2.y, v2.y, p2.y, t2.y);
-        *reinterpret_cast<float2 *>(c.mt + i0) = m2; *reinterpret_cast<float2 *>(c.vt + i0) = v2;
-        *reinterpret_cast<float2 *>(c.p + i0) = p2; *reinterpret_cast<float2 *>(c.target + i0) = t2;
-        if (c.publish) *reinterpret_cast<float2 *>(c.publish + i0) = p2;
-    } else {
-        for (int i = i0; i < c.n; ++i) adam_elem(c, i, c.g[i]);
-    }
-}
-
 // Data-parallel form only (a gradient all-reduce sits between the gradient launch and this sweep).
-template <int EPT>
 __global__ __launch_bounds__(256) void k_adam_soft(AdamCtx c, int64_t gstride)
 {
     gshift(c, blockIdx.z * gstride);
-    const int i0 = EPT * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
-    if (i0 < c.n) { if constexpr (EPT == 4) adam_vec4(c, i0); else adam_vec2(c, i0); }
+    const int i0 = 4 * ((int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x);
+    if (i0 < c.n) adam_vec4(c, i0);
 }
-// default 4 (16-byte accesses).  SHEMS_ADAM_EPT=2 measured 40.1-40.3 against 40.6-40.9 us per split-form update on one box and 40.2-43.6
-// against 40.2-41.4 on another (alternating runs both times): inside the noise of this 7-launch form, so the round-3 form stays
-static int adam_ept() { static const int e = []() { const char *v = getenv("SHEMS_ADAM_EPT"); return v && atoi(v) == 2 ? 2 : 4; }(); return e; }
+// (two elements per thread -- twice the workgroups, 252 of the 256 CUs covered -- was measured inside the noise of the 7-launch form in
+// round 4, 40.1-43.6 against 40.2-41.4 us, and removed)
 
 // Data-parallel form with the DIRECT exchange (XchgArgs, shems_internal.h): push my range of the gradient to every peer, wait for
 // theirs, sum in rank order, ADAM.  One workgroup = 1 024 consecutive parameters = 256 threads x 4; the same range on every rank.
@@ -1298,29 +1210,22 @@ struct GradArgs {
     shems_ddpg dd;         // for the heads
     AdamCtx c;
     int64_t gstride;       // learner groups: byte stride between learners (0 = single learner)
-    DevSync sy;            // K5 of a pipelined loop: tells the step kernel waiting for the published actor that one more workgroup is done
 };
 __device__ __forceinline__ void gshift(GradArgs &B, int64_t off)
 {
     B.w1t = gsh(B.w1t, off); B.P = gsh(B.P, off); gshift(B.x, off); B.H2 = gsh(B.H2, off); B.w3f = gsh(B.w3f, off);
     B.grad = gsh(B.grad, off); B.E0 = gsh(B.E0, off); B.E1 = gsh(B.E1, off); gshift(B.dd, off); gshift(B.c, off);
 }
-// W tiles are 32 k x 32 n (128 workgroups), G workgroups take 32 rows (16 workgroups).  -DGR_WN=16 builds the finer tiling tried in
-// round 3: W tiles 32 k x 16 n (256 workgroups: two 16 x 16 blocks, waves (w >> 1) pick the block, (w & 1) the batch half, the halves
-// added through LDS in a fixed order), G workgroups of 16 rows (32) -- half the H2 / ADAM state staged per workgroup, half the MFMA
-// chain and half the ADAM work per tile.  Correct (every update test green) and measured SLOWER: 36.1-36.2 us per update against
-// 35.8-35.9 on the same box, alternating runs -- 351 workgroups on 256 CUs double up, and the head's 16 / 32 KB of partials every
-// workgroup re-reads do not shrink with the tile.
-#ifndef GR_WN
-#define GR_WN 32
-#endif
-static_assert(GR_WN == 16 || GR_WN == 32, "W tile width");
-enum { GR_NTW = 512 / GR_WN, GR_NW = KT * GR_NTW, GR_NG = GR_WN == 16 ? 32 : 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };
+// W tiles are 32 k x 32 n (128 workgroups), G workgroups take 32 rows (16 workgroups).  (A finer tiling -- W tiles 32 k x 16 n, 256
+// workgroups, G workgroups of 16 rows -- was built in round 3, verified and measured slower, 36.1-36.2 us per update against 35.8-35.9:
+// 351 workgroups on 256 CUs double up, and the head's partials every workgroup re-reads do not shrink with the tile.  Removed in round 5.)
+constexpr int GR_WN = 32;
+enum { GR_NTW = 512 / GR_WN, GR_NW = KT * GR_NTW, GR_NG = 16, GR_GROWS = 512 / GR_NG, GR_GU = GR_GROWS / 4, GR_NR = (H1N + 3) / 4 };
 
 constexpr int GR_PS = BP + 4;                                // W: row stride of the two operand panels (b128 reads of 16 rows: conflict free)
 constexpr int GR_BT = GR_WN * GR_PS;                         // W: [GR_WN n][132] D2 panel
 constexpr int GR_AT = 32 * GR_PS;                            // W: [32 k][132] h1 panel
-constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3 + (GR_WN == 16 ? 4 * 256 : 0)) * 4;
+constexpr int GR_LDS = (GR_BT + GR_AT + W1K * BP + W1K * 32 + AIN * BP + 2 * 32 + 8 + GR_GROWS * 3) * 4;
 
 // D2 element: (sum_o W3[n][o] d3[o][m]) * (h2 > 0)
 __device__ __forceinline__ float d2_val(float h2, float w3a, float w3b, float d3a, float d3b)
@@ -1386,7 +1291,6 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
     float *w3s = d3 + AIN * BP;                // W3 rows of the n-tile (W) / of the 32 rows (G), [32][2] (out == 1: [.][1] zero)
     float *red = w3s + 2 * 32;                 // [8]
     float *gbuf = red + 8;                     // G: [GR_GROWS rows][3] sums
-    [[maybe_unused]] float *wx = gbuf + GR_GROWS * 3;      // W (16-wide tiles): [4 waves][4 r][64 lanes] block halves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const bool is_w = bx < GR_NW, is_g = !is_w && bx < GR_NW + GR_NG;
     const int kt = bx / GR_NTW, nt = bx % GR_NTW;                  // W: (k-tile of 32, n-tile of GR_WN)
@@ -1427,7 +1331,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
     // The H2 panel does not depend on the error signal: its loads go out before the head is evaluated, so the two global latencies
     // overlap instead of following each other.
     constexpr int HVN = GR_WN / 2;              // H2 rows per thread
-    constexpr int WOWN = GR_WN == 16 ? 2 : 4;   // elements of gW2 a lane finishes and owns
+    constexpr int WOWN = 4;                     // elements of gW2 a lane finishes and owns
     float hv[HVN];
     int widx[WOWN];
 #pragma unroll
@@ -1438,10 +1342,8 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         for (int u = 0; u < HVN; ++u) hv[u] = A.H2[min(nt * GR_WN + 2 * u + half, H2N - 1) * BP + mcol];
 #pragma unroll
         for (int r = 0; r < WOWN; ++r) {
-            // 32-wide tiles: wave w finishes the 16 x 16 block (k half w >> 1, n half w & 1), D[i = 4 g + r][j = c], r < 4.
-            // 16-wide tiles: waves 2 b, 2 b + 1 share block b (k half b); wave (w & 1) owns rows r' = 2 (w & 1) + r of every lane's four.
-            const int rr = GR_WN == 16 ? 2 * (wave & 1) + r : r;
-            const int k = kt * 32 + 16 * (wave >> 1) + 4 * (lane >> 4) + rr, n = nt * GR_WN + (GR_WN == 16 ? 0 : 16 * (wave & 1)) + (lane & 15);
+            // wave w finishes the 16 x 16 block (k half w >> 1, n half w & 1), D[i = 4 g + r][j = c], r < 4
+            const int k = kt * 32 + 16 * (wave >> 1) + 4 * (lane >> 4) + r, n = nt * GR_WN + 16 * (wave & 1) + (lane & 15);
             widx[r] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;
         }
         adam_load<WOWN>(A.c, widx, ar);         // moments, parameter, target: requested with the first burst, consumed after the tile (requested
@@ -1457,7 +1359,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         wq = *reinterpret_cast<const f32x4 *>(A.w1t + (t >> 3) * W1C + kt * 32 + 4 * (t & 7));
     }
     {
-        const int t = min(tid, 2 * (GR_WN == 16 ? 16 : 32) - 1), o = t & 1;                   // (W and G need the same number of rows in either tiling)
+        const int t = min(tid, 2 * 32 - 1), o = t & 1;                                        // (W and G need the same number of rows)
         w3v = A.w3f[(nrow0 + (t >> 1)) * OUT + min(o, OUT - 1)];                              // frozen copy: 512 rows, zero padded
     }
     HeadRegs hr;
@@ -1467,7 +1369,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         if (tid < 96) *reinterpret_cast<f32x4 *>(w1 + (tid >> 3) * 32 + 4 * (tid & 7)) = wq;
     }
     if (A.head == 1) head_loss(A.dd, hr, d3, red, publisher, fz); else head_actor(A.dd, hr, d3, red, publisher, fz);
-    if (tid < 2 * (GR_WN == 16 ? 16 : 32)) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
+    if (tid < 2 * 32) w3s[tid] = (tid & 1) < OUT ? w3v : 0.0f;
     STAMP(kRegion, 1);
     __syncthreads();
     STAMP(kRegion, 2);
@@ -1500,49 +1402,21 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
         f32x4 blk;
         {
             const int g = lane >> 4, c = lane & 15;
-            if constexpr (GR_WN == 32) {
-                const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g, *pb = Bt + (16 * (wave & 1) + c) * GR_PS + 4 * g;
-                f32x4 av[8], bv[8];
+            const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g, *pb = Bt + (16 * (wave & 1) + c) * GR_PS + 4 * g;
+            f32x4 av[8], bv[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
-                    bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
-                }
-                f32x4 acc[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
-                blk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            } else {
-                // block (k half w >> 1) x the tile's 16 columns, batch half (w & 1): q = 4 (w & 1) .. + 3; the halves meet in LDS and are
-                // added as (half 0) + (half 1) by both waves of the pair
-                const int bh = wave & 1;
-                const float *pa = At + (16 * (wave >> 1) + c) * GR_PS + 4 * g + 64 * bh, *pb = Bt + c * GR_PS + 4 * g + 64 * bh;
-                f32x4 av[4], bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
-                    bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
-                }
-                f32x4 acc[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
-                const f32x4 part = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wx[(wave * 4 + r) * 64 + lane] = part[r];
-                __syncthreads();
-                f32x4 p0, p1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { p0[r] = wx[((wave & ~1) * 4 + r) * 64 + lane]; p1[r] = wx[((wave | 1) * 4 + r) * 64 + lane]; }
-                blk = p0 + p1;
+            for (int q = 0; q < 8; ++q) {
+                av[q] = *reinterpret_cast<const f32x4 *>(pa + 16 * q);
+                bv[q] = *reinterpret_cast<const f32x4 *>(pb + 16 * q);
             }
+            f32x4 acc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], bv[q][e], acc[e], 0, 0, 0);
+            blk = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         STAMP(kRegion, 5);
         {
@@ -1550,7 +1424,7 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
             float val[WOWN];
 #pragma unroll
             for (int r = 0; r < WOWN; ++r) {
-                val[r] = GR_WN == 16 ? blk[2 * (wave & 1) + r] : blk[r];
+                val[r] = blk[r];
                 if (widx[r] >= 0) gW2[widx[r] - off_w2(IN)] = val[r];
             }
             STAMP(kRegion, 6);
@@ -1598,12 +1472,8 @@ __device__ __forceinline__ void grad_body(const GradArgs &A, float *smem, const 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_grad(GradArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef UPD_PRIO
-    __builtin_amdgcn_s_setprio(UPD_PRIO);
-#endif
     gshift(A, blockIdx.z * A.gstride);             // learner blockIdx.z (stride 0 for a single learner)
     if (A.in == SIN) grad_body<SIN, 2>(A, smem, (int)blockIdx.x); else grad_body<CIN, 1>(A, smem, (int)blockIdx.x);
-    dev_arrive(A.sy, false);                       // the published actor copy is stored write-through (AdamCtx::publish): draining is enough
 }
 
 // ---- min_max_buffer (MPS:50-53) -----------------------------------------------------------------------------------
@@ -1687,19 +1557,12 @@ __global__ __launch_bounds__(256) void k_action_distance(const float *__restrict
 constexpr int FWD_LDS = FwdShape<false>::LDS, QG_LDS = FWD_LDS > QG16_LDS ? FWD_LDS : QG16_LDS;
 constexpr int MID_LDS = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
 static_assert(QG_LDS <= 160 * 1024, "one workgroup's LDS");
-// Pipelined loop with device-side dependencies: the five launches of an update ask for ONE LDS size.  A CU's LDS is handed out in
-// contiguous blocks; a step workgroup (92 KB) that starts while a 57-KB gradient workgroup sits at the bottom of the CU's LDS is placed
-// above it, and the hole that workgroup leaves then never fits K1 / K2 (63.5 KB) for as long as the step workgroup lives -- traced in
-// round 4: K1 took 26 us instead of 6, waiting for CUs.  With one size every hole an update workgroup leaves fits the next one.
-constexpr int UPD_LDS_ = FWD_LDS > E_LDS ? FWD_LDS : E_LDS;
-constexpr int UPD_LDS = (UPD_LDS_ > GR_LDS ? UPD_LDS_ : GR_LDS) > QG16_LDS ? (UPD_LDS_ > GR_LDS ? UPD_LDS_ : GR_LDS) : QG16_LDS;
-
 static int set_lds_attrs()
 {
     static std::atomic<uint64_t> m_fwd{0}, m_mid{0}, m_grad{0};          // per device: see lds_optin
     if (int rc = lds_optin(m_fwd, reinterpret_cast<const void *>(&k_fwd), QG_LDS, "attr k_fwd")) return rc;
     if (int rc = lds_optin(m_mid, reinterpret_cast<const void *>(&k_mid), MID_LDS, "attr k_mid")) return rc;
-    if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), UPD_LDS, "attr k_grad")) return rc;
+    if (int rc = lds_optin(m_grad, reinterpret_cast<const void *>(&k_grad), GR_LDS, "attr k_grad")) return rc;
     return SHEMS_OK;
 }
 
@@ -1759,8 +1622,7 @@ static int actor_e_launch(const shems_ddpg *d, unsigned L, int64_t gs, hipStream
 }
 
 static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick,
-                       int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream,
-                       const DevSync *first = nullptr)
+                       int64_t excl_pos, int64_t excl_count, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_critic_grad")) return rc;
     if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
@@ -1784,8 +1646,7 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     f.job[2] = FwdJob{nullptr, d->actor, SIN, 2, 2, none, SA + SL_H2, SA + SL_P3, nullptr, nullptr};
     f.prep = 1;
     f.pa = PrepArgs{*d, *ring, ring_len, seed, tick, excl_pos, excl_count};
-    if (first) f.sy = *first;
-    hipLaunchKernelGGL(k_fwd, dim3(3 * (fgx + 6), 1, L), dim3(256), first ? UPD_LDS : flds, st, f);      // + 6 publishing workgroups per job (see fwd_body)
+    hipLaunchKernelGGL(k_fwd, dim3(3 * (fgx + 6), 1, L), dim3(256), flds, st, f);      // + 6 publishing workgroups per job (see fwd_body)
     // K2: critic_target on [s'; actor_target(s')] | E of the critic | E of the actor's two outputs
     MidArgs m;
     std::memset(&m, 0, sizeof m);
@@ -1795,19 +1656,19 @@ static int critic_side(const shems_ddpg *d, const shems_replay *ring, int64_t ri
     m.e[1] = EJob{d->actor, SIN, 2, 0, SA + SL_H2, SA + SL_EP};
     m.e[2] = EJob{d->actor, SIN, 2, 1, SA + SL_H2, ws + WS_EA1};
     const bool defer_ea = !fuse && (d->flags & SHEMS_DDPG_DEFER_ACTOR_E) != 0;       // the caller runs shems_ddpg_actor_prepare later
-    hipLaunchKernelGGL(k_mid, dim3(fgx + (defer_ea ? 1 : 3) * KT * NQ, 1, L), dim3(256), first ? UPD_LDS : MID_LDS, st, m);
+    hipLaunchKernelGGL(k_mid, dim3(fgx + (defer_ea ? 1 : 3) * KT * NQ, 1, L), dim3(256), MID_LDS, st, m);
     // K3: critic gradient (+ ADAM + soft update)
     GradArgs g;
     std::memset(&g, 0, sizeof g);
     g.w1t = w1t_of(ws, SLOT_CRITIC); g.P = d->critic; g.in = CIN; g.out = 1; g.x = x_sa; g.H2 = SC + SL_H2; g.w3f = ws + WS_FW3C;
     g.grad = d->grad_critic; g.E0 = SC + SL_EP; g.E1 = nullptr; g.head = 1; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, true, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
-    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), first ? UPD_LDS : GR_LDS, st, g);
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg critic-side launches");
 }
 
 // K4 + K5: the actor side (DDPG.jl:137-140), through the critic as it stands now (already updated)
-static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream, const DevSync *last = nullptr)
+static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamScalars *fuse, void *stream)
 {
     if (int rc = check_ddpg(d, "shems_ddpg_actor_grad")) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1827,9 +1688,8 @@ static int actor_side(const shems_ddpg *d, unsigned L, int64_t gs, const AdamSca
     g.w1t = w1t_of(ws, SLOT_ACTOR); g.P = d->actor; g.in = SIN; g.out = 2; g.x = x_s; g.H2 = SA + SL_H2; g.w3f = ws + WS_FW3A;
     g.grad = d->grad_actor; g.E0 = SA + SL_EP; g.E1 = ws + WS_EA1; g.head = 2; g.fuse = fuse ? 1 : 0; g.dd = *d; g.gstride = gs;
     g.c = adam_ctx(d, false, fuse ? *fuse : AdamScalars{0, 0.5, 0.5, 1.0, nullptr});
-    if (last) g.sy = *last;
-    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), last ? UPD_LDS : QG16_LDS, st, f);
-    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), last ? UPD_LDS : GR_LDS, st, g);
+    hipLaunchKernelGGL(k_fwd, dim3(fgx, 1, L), dim3(256), QG16_LDS, st, f);
+    hipLaunchKernelGGL(k_grad, dim3(GR_NW + GR_NG + GR_NR, 1, L), dim3(256), GR_LDS, st, g);
     return hip_ok(hipGetLastError(), "ddpg actor-side launches");
 }
 
@@ -1837,8 +1697,7 @@ static int adam_launch(const shems_ddpg *d, bool critic, const AdamScalars &s, h
 {
     if (int rc = check_adam(s.bp1, s.bp2, "adam")) return rc;
     const AdamCtx c = adam_ctx(d, critic, s);
-    if (adam_ept() == 2) hipLaunchKernelGGL(k_adam_soft<2>, dim3((c.n + 511) / 512, 1, L), dim3(256), 0, st, c, gs);
-    else hipLaunchKernelGGL(k_adam_soft<4>, dim3((c.n + 1023) / 1024, 1, L), dim3(256), 0, st, c, gs);
+    hipLaunchKernelGGL(k_adam_soft, dim3((c.n + 1023) / 1024, 1, L), dim3(256), 0, st, c, gs);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 
@@ -1851,7 +1710,7 @@ int adam_soft_sweep(float *p, const float *g, float *m, float *v, float *target,
     for (const void *q : {(const void *)p, (const void *)g, (const void *)m, (const void *)v, (const void *)target, (const void *)publish})
         if (((uintptr_t)q & 15) != 0) return set_error(SHEMS_ERR_ARG, "adam_soft_sweep: buffers must be 16-byte aligned");
     const AdamCtx c{p, g, m, v, target, publish, n, 0, eta, bp1, bp2, gscale, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), tau};
-    hipLaunchKernelGGL(k_adam_soft<4>, dim3((n + 1023) / 1024, 1, 1), dim3(256), 0, st, c, (int64_t)0);
+    hipLaunchKernelGGL(k_adam_soft, dim3((n + 1023) / 1024, 1, 1), dim3(256), 0, st, c, (int64_t)0);
     return hip_ok(hipGetLastError(), "k_adam_soft launch");
 }
 }  // namespace shems
@@ -1866,20 +1725,6 @@ int shems_debug_set_stamps(void *d_buf)
     return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p), "set stamps");
 }
 #endif
-
-/* Device-side waits (the pipelined training loop with SHEMS_LOOP_SYNC=device) that gave up since the last call: reads AND clears one
- * word of the workspace, synchronising with `stream`.  Non-zero = the steps enqueued since then are invalid. */
-int shems_ddpg_sync_timeouts(const shems_ddpg *d, int64_t *out, void *stream)
-{
-    if (!d || !d->ws || !out) return set_error(SHEMS_ERR_ARG, "shems_ddpg_sync_timeouts: NULL");
-    unsigned v = 0;
-    unsigned *w = reinterpret_cast<unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT;
-    if (int rc = hip_ok(hipMemcpyAsync(&v, w, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream), "memcpy sync")) return rc;
-    if (int rc = hip_ok(hipStreamSynchronize((hipStream_t)stream), "sync")) return rc;
-    if (v) if (int rc = hip_ok(hipMemsetAsync(w, 0, sizeof v, (hipStream_t)stream), "memset sync")) return rc;
-    *out = (int64_t)v;
-    return SHEMS_OK;
-}
 
 int shems_ddpg_workspace_floats(int64_t *out)
 {
@@ -1914,16 +1759,6 @@ int shems_ddpg_update(const shems_ddpg *d, const shems_replay *ring, int64_t rin
 }  // extern "C"
 
 namespace shems {
-int ddpg_update_sync(const shems_ddpg *d, const shems_replay *ring, int64_t ring_len, uint64_t seed, uint32_t tick, int64_t excl_pos,
-                     int64_t excl_count, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act, double bp2_act,
-                     float *d_publish, const DevSync &first, const DevSync &last, hipStream_t st)
-{
-    if (int rc = check_adam(bp1_crit, bp2_crit, "ddpg_update_sync")) return rc;
-    if (int rc = check_adam(bp1_act, bp2_act, "ddpg_update_sync")) return rc;
-    const AdamScalars sc{eta_crit, bp1_crit, bp2_crit, 1.0, nullptr}, sa{eta_act, bp1_act, bp2_act, 1.0, d_publish};
-    if (int rc = critic_side(d, ring, ring_len, seed, tick, excl_pos, excl_count, 1, 0, &sc, st, &first)) return rc;
-    return actor_side(d, 1, 0, &sa, st, &last);
-}
 int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, double bp2, float *d_publish, const XchgArgs &x, hipStream_t st)
 {
     if (int rc = check_ddpg(d, "ddpg_apply_xchg")) return rc;
@@ -1935,8 +1770,6 @@ int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, do
     hipLaunchKernelGGL(k_adam_xchg, dim3((c.n + 1023) / 1024), dim3(256), 0, st, c, x);
     return hip_ok(hipGetLastError(), "k_adam_xchg launch");
 }
-int ddpg_last_launch_grid() { return GR_NW + GR_NG + GR_NR; }
-unsigned *ddpg_timeout_word(const shems_ddpg *d) { return reinterpret_cast<unsigned *>(d->ws + WS_SYNC) + SY_TIMEOUT; }
 }  // namespace shems
 
 extern "C" {

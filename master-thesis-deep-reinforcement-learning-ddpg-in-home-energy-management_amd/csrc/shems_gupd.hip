@@ -1,0 +1,787 @@
+// shems_gupd.hip -- replay() (DDPG.jl:121-145) for a GROUP of independent learners, throughput form.
+//
+// The thesis protocol trains 40 seeds x 10 chargers = 400 independent learners (RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87).
+// shems_ddpg.hip's five launches are shaped for ONE learner's latency (one exposed memory latency per launch, 1-2 workgroups per
+// CU, E-product identities that trade FLOPs and 3 MB of slabs per learner for fewer grid-wide dependencies).  With hundreds of
+// learners per launch nothing is latency-bound any more: per learner the update is 308 MFLOP (ten 250x500x128 products) against
+// ~11 MB of parameter / moment traffic, i.e. ~2 us at the fp32 MFMA peak and ~1.6 us at 6.3 TB/s -- both roofs within a factor
+// of two of each other.  This file is the same arithmetic laid out for that regime:
+//
+//   * plain back-propagation (no E slabs): per learner ten products, every one a stream of 32-deep weight chunks through a small
+//     LDS ring against operands that live in REGISTERS in the MFMA layout (layer 1 is recomputed per chunk on the matrix pipe --
+//     K = 12 -- and its D layout IS the next product's B operand; error signals are loaded from HBM straight into operand layout);
+//   * 17-34 KB of LDS and <= 128 VGPRs per workgroup: 4 workgroups (16 waves) resident per CU, so one workgroup's barrier / global
+//     latency is covered by the others' MFMAs without any hand scheduling;
+//   * activations that must cross a launch (relu(layer 2) of the two differentiated networks, 256 KB each) are written once and
+//     read from L2 / Infinity Cache; layer-1 activations are never stored; gradients are never stored (ADAM + the soft target
+//     update are applied by the lane that holds the finished element; SHEMS_TP_STORE_GRAD keeps the gradient for the tests).
+//
+// Launches (grid y = learner; all learners advance in lockstep, sharing the ADAM scalars):
+//   P0 k_tp_prep   sample (StatsBase.sample with replacement, MPS:33) + gather + normalize (MPS:56); frozen layer-1 images of the
+//                  four networks and frozen output layers (the in-place updates below must not be read half-way)
+//   P1 k_tp_fwd    actor_target(s') | critic(s, a) | actor(s)                                      (DDPG.jl:131, 114-119)
+//   P2 k_tp_fwd    critic_target(s', a')                                                           (DDPG.jl:132)
+//   P3 k_tp_d1     y, dq = d mse / dq; D1 = mask1 .* (W2 D2); layer-1 gradient + ADAM; b3 gradient + ADAM   (DDPG.jl:133-137)
+//   P4 k_tp_gw2    gW2 = h1 D2' + ADAM + soft update per tile; gb2, gW3 + ADAM
+//   P5 k_tp_fwd<QG> updated critic on [s; actor(s)], forward and input gradient per n-tile          (DDPG.jl:117-119, 140)
+//   P6 k_tp_d1     actor: through tanh, D1, layer-1 gradient + ADAM
+//   P7 k_tp_gw2    actor: gW2 + ADAM + soft update, gb2, gW3                                        (DDPG.jl:140-143)
+// Summation orders differ from the latency form (64-wide n-tiles, chunked contractions): per learner the results agree with it to
+// fp32 accumulation accuracy, not bit for bit -- the parity test holds every gradient block of every learner to the float64
+// evaluation with the same bound as the latency form (tests/test_group_gpu.py).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <type_traits>
+
+#include "philox.h"
+#include "shems_adam.h"
+#include "shems_internal.h"
+
+namespace shems {
+namespace tp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BP = 128;
+constexpr int H1N = SHEMS_L1, H2N = SHEMS_L2;
+constexpr int SIN = 9, CIN = 11;
+constexpr int NT = 8;              // n-tiles of 64 over the 500 (512) layer-2 units
+constexpr int W1K = 12, W1C = 256; // layer-1 image: rows 0..in-1 = W1, row 11 = b1, everything else zero; columns >= 250 zero
+
+__host__ __device__ constexpr int off_b1(int in) { return in * H1N; }
+__host__ __device__ constexpr int off_w2(int in) { return in * H1N + H1N; }
+__host__ __device__ constexpr int off_b2(int in) { return off_w2(in) + H1N * H2N; }
+__host__ __device__ constexpr int off_w3(int in) { return off_b2(in) + H2N; }
+__host__ __device__ constexpr int off_b3(int in, int out) { return off_w3(in) + H2N * out; }
+
+// ---- workspace carve (floats, inside shems_ddpg.ws; see kTpWsFloats) -----------------------------------------------------------
+constexpr int64_t TP_X = 0;                            // [12][BP]  rows 0..8 normalize(s), 9..10 stored action, 11 = 1
+constexpr int64_t TP_X2 = TP_X + W1K * BP;             // [12][BP]  rows 0..8 normalize(s'), 9..10 zero, 11 = 1
+constexpr int64_t TP_R = TP_X2 + W1K * BP;             // [BP]
+constexpr int64_t TP_DONE = TP_R + BP;                 // [BP]
+constexpr int64_t TP_IDX = TP_DONE + BP;               // [BP] int32 sampled ring slots (-1 in the pad columns)
+constexpr int64_t TP_W1I = TP_IDX + BP;                // [4 nets][12][256] frozen layer-1 images
+constexpr int64_t TP_FW3C = TP_W1I + 4 * W1K * W1C;    // [512][2] frozen critic W3 ([.][1] and rows >= 500 zero)
+constexpr int64_t TP_FW3A = TP_FW3C + 1024;            // [512][2] frozen actor W3
+constexpr int64_t TP_FB3 = TP_FW3A + 1024;             // [8] frozen b3: critic, critic_target, actor[0], actor[1], actor_target[0], [1]
+constexpr int64_t TP_P3 = TP_FB3 + 8;                  // [5 passes][NT][2][BP] layer-3 partial sums per n-tile
+constexpr int64_t TP_DAP = TP_P3 + 5 * NT * 2 * BP;    // [NT][2][BP] partial d loss / d a_pi per n-tile (P5)
+constexpr int64_t TP_D3C = TP_DAP + NT * 2 * BP;       // [2][BP] dq (row 1 zero)
+constexpr int64_t TP_D3A = TP_D3C + 2 * BP;            // [2][BP] error at the actor's pre-tanh output
+constexpr int64_t TP_API = TP_D3A + 2 * BP;            // [2][BP] a_pi = actor(s)
+constexpr int64_t TP_H2C = TP_API + 2 * BP;            // [512][BP] relu(layer 2) of the critic (rows >= 500 zero)
+constexpr int64_t TP_H2A = TP_H2C + 512 * BP;          // [512][BP] ... of the actor
+constexpr int64_t TP_FLOATS = TP_H2A + 512 * BP;
+static_assert(TP_FLOATS <= kTpWsFloats, "the throughput form's carve fits the workspace every caller allocates");
+static_assert(TP_W1I % 4 == 0 && TP_H2C % 4 == 0 && TP_P3 % 4 == 0, "16-byte aligned blocks");
+enum { NET_ACTOR_T = 0, NET_CRITIC_T = 1, NET_CRITIC = 2, NET_ACTOR = 3, PASS_CRITIC2 = 4 };
+__host__ __device__ inline float *p3_of(float *ws, int pass) { return ws + TP_P3 + (int64_t)pass * NT * 2 * BP; }
+__host__ __device__ inline float *w1i_of(float *ws, int net) { return ws + TP_W1I + (int64_t)net * W1K * W1C; }
+
+// rows of a 32 x 32 MFMA accumulator held by register r of a lane in half lh
+__device__ __forceinline__ int drow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+__device__ __forceinline__ float half_sum32(float x)      // sum over the 32 lanes of a half wave, in every lane of that half
+{
+    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_sum64(float x) { x = half_sum32(x); return x + __shfl_xor(x, 32, 64); }
+
+__device__ __forceinline__ void adam_at(const AdamCtx &c, int i, float g, bool store_grad)
+{
+    float m = c.mt[i], v = c.vt[i], p = c.p[i], t = c.target[i];
+    adam_math(c, g, m, v, p, t);
+    c.mt[i] = m; c.vt[i] = v; c.p[i] = p; c.target[i] = t;
+    if (store_grad) const_cast<float *>(c.g)[i] = g;
+}
+
+// ================================================================================================================================
+// P0: sample + gather + normalize; frozen images
+// ================================================================================================================================
+struct PrepArgs {
+    shems_ddpg d;
+    shems_replay ring;
+    int64_t ring_len, gstride;
+    uint64_t seed;
+    uint32_t tick;
+};
+__device__ __forceinline__ void gshift(shems_ddpg &d, int64_t off)
+{
+    d.actor = gsh(d.actor, off); d.critic = gsh(d.critic, off); d.actor_t = gsh(d.actor_t, off); d.critic_t = gsh(d.critic_t, off);
+    d.m_actor = gsh(d.m_actor, off); d.v_actor = gsh(d.v_actor, off); d.m_critic = gsh(d.m_critic, off); d.v_critic = gsh(d.v_critic, off);
+    d.grad_actor = gsh(d.grad_actor, off); d.grad_critic = gsh(d.grad_critic, off);
+    d.s_min = gsh(d.s_min, off); d.s_max = gsh(d.s_max, off); d.ws = gsh(d.ws, off); d.losses = gsh(d.losses, off);
+}
+__device__ __forceinline__ void gshift(shems_replay &r, int64_t off)
+{
+    r.s = gsh(r.s, off); r.a = gsh(r.a, off); r.r = gsh(r.r, off); r.s2 = gsh(r.s2, off); r.done = gsh(r.done, off);
+}
+
+__global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A)
+{
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const int64_t off = (int64_t)l * A.gstride;
+    shems_ddpg d = A.d;
+    shems_replay ring = A.ring;
+    gshift(d, off); gshift(ring, off);
+    const uint64_t seed = A.seed + (uint64_t)l;               // learner l: Philox key seed + l (as the latency form)
+    float *ws = d.ws;
+    if (tid < BP) {
+        const int m = tid;
+        const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, A.tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
+        const int64_t j = (int64_t)(w % (uint32_t)A.ring_len);
+        const bool live = m < d.batch;
+#pragma unroll
+        for (int k = 0; k < SIN; ++k) {
+            const float lo = d.s_min[k], den = (d.s_max[k] - lo) + 1e-8f;                 // MPS:56
+            ws[TP_X + k * BP + m] = live ? (ring.s[j * SIN + k] - lo) / den : 0.0f;
+            ws[TP_X2 + k * BP + m] = live ? (ring.s2[j * SIN + k] - lo) / den : 0.0f;
+        }
+        ws[TP_X + 9 * BP + m] = live ? ring.a[j * 2] : 0.0f;
+        ws[TP_X + 10 * BP + m] = live ? ring.a[j * 2 + 1] : 0.0f;
+        ws[TP_X + 11 * BP + m] = 1.0f;
+        ws[TP_X2 + 9 * BP + m] = 0.0f; ws[TP_X2 + 10 * BP + m] = 0.0f; ws[TP_X2 + 11 * BP + m] = 1.0f;
+        ws[TP_R + m] = live ? ring.r[j] : 0.0f;
+        ws[TP_DONE + m] = live ? (ring.done[j] ? 1.0f : 0.0f) : 0.0f;
+        reinterpret_cast<int32_t *>(ws + TP_IDX)[m] = live ? (int32_t)j : -1;
+    }
+    // frozen layer-1 images of the four networks
+#pragma unroll
+    for (int net = 0; net < 4; ++net) {
+        const float *P = net == NET_ACTOR_T ? d.actor_t : net == NET_CRITIC_T ? d.critic_t : net == NET_CRITIC ? d.critic : d.actor;
+        const int in = (net == NET_CRITIC_T || net == NET_CRITIC) ? CIN : SIN;
+        float *img = w1i_of(ws, net);
+        for (int e = tid; e < W1K * W1C; e += 256) {
+            const int j = e >> 8, k = e & 255;
+            const bool used = k < H1N && (j < in || j == W1K - 1);
+            img[e] = used ? P[(j == W1K - 1 ? in : j) * H1N + k] : 0.0f;
+        }
+    }
+    // frozen output layers
+    for (int e = tid; e < 1024; e += 256) {
+        const int n = e >> 1, o = e & 1;
+        ws[TP_FW3C + e] = (n < H2N && o == 0) ? d.critic[off_w3(CIN) + n] : 0.0f;
+        ws[TP_FW3A + e] = n < H2N ? d.actor[off_w3(SIN) + e] : 0.0f;
+    }
+    if (tid < 8)
+        ws[TP_FB3 + tid] = tid == 0 ? d.critic[off_b3(CIN, 1)] : tid == 1 ? d.critic_t[off_b3(CIN, 1)]
+                         : tid == 2 ? d.actor[off_b3(SIN, 2)] : tid == 3 ? d.actor[off_b3(SIN, 2) + 1]
+                         : tid == 4 ? d.actor_t[off_b3(SIN, 2)] : tid == 5 ? d.actor_t[off_b3(SIN, 2) + 1] : 0.0f;
+}
+
+// ================================================================================================================================
+// P1 / P2 / P5: forward through layers 1 + 2 for one 64-wide n-tile and the whole batch; layer 3 as per-tile partial sums.
+// QG (P5): the same workgroup then back-propagates the constant upstream gradient of -mean(q) through its own 64 hidden units.
+// ================================================================================================================================
+struct FwdJob {
+    const float *P;        // parameter block of the network
+    const float *X;        // [12][BP] input block (workspace)
+    const float *w1i;      // frozen layer-1 image (workspace), or null: pack it from P (a network updated earlier in this update)
+    const float *ap3;      // rows 9, 10 = tanh(ab3 + sum of these [NT][2][BP] partials) of an actor pass, or null (rows as stored in X)
+    const float *ab3;      // [2]
+    float *api;            // n-tile 0 publishes the computed action here ([2][BP]), or null
+    float *H2;             // [512][BP] relu(layer 2) (rows >= 500 stored as zero), or null
+    float *P3;             // [NT][2][BP]
+    float *DAP;            // QG: [NT][2][BP]
+    int in, out;
+};
+struct FwdArgs { FwdJob job[3]; int64_t gstride; int batch; };
+__device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
+{
+    J.P = gsh(J.P, off); J.X = gsh(J.X, off); J.w1i = gsh(J.w1i, off); J.ap3 = gsh(J.ap3, off); J.ab3 = gsh(J.ab3, off);
+    J.api = gsh(J.api, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off); J.DAP = gsh(J.DAP, off);
+}
+
+// W2 chunk c of an n-tile: rows k = 32 c .. 32 c + 31, columns n0 .. n0 + 63 (256 B per row), two float4 per thread.  Rows >= 250 are
+// copies of row 249 (clamped address): they only meet layer-1 activations that are exactly zero (the image has no columns >= 250)
+// or output rows whose relu mask is off.  Columns >= 500 of the last tile read on into the next row / b2 (inside the parameter
+// block) and only feed outputs that are discarded.
+__device__ __forceinline__ void fwd_chunk_load(const float *__restrict__ W2, int n0, int c, f32x4 (&v)[2])
+{
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = it * 256 + (int)threadIdx.x, k = min(32 * c + (e >> 4), H1N - 1);
+        v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + n0 + 4 * (e & 15));
+    }
+}
+template <int S>
+__device__ __forceinline__ void fwd_chunk_store(float *buf, const f32x4 (&v)[2])
+{
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = it * 256 + (int)threadIdx.x;
+        float *p = buf + (e >> 4) * S + 4 * (e & 15);
+        if constexpr (S % 4 == 0) *reinterpret_cast<f32x4 *>(p) = v[it];
+        else { p[0] = v[it][0]; p[1] = v[it][1]; p[2] = v[it][2]; p[3] = v[it][3]; }
+    }
+}
+
+// layer-1 pre-activations of hidden units 32 c .. 32 c + 31 x this wave's 32 batch columns, D layout (row = unit, column = sample)
+__device__ __forceinline__ f32x16 l1_tile(const float *w1s, int c, const float (&xreg)[6], int li, int lh)
+{
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+    float a[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) a[s] = w1s[(2 * s + lh) * W1C + 32 * c + li];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xreg[s], t, 0, 0, 0);
+    return t;
+}
+
+template <bool QG> struct FwdShape {
+    static constexpr int S = QG ? 65 : 64;         // chunk row stride: the backward pass reads the chunk along n (odd stride: conflict free)
+    static constexpr int LDS = (W1K * W1C + 64 * 4 + 2 * 32 * S) * 4;
+};
+
+template <bool QG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tp_fwd(FwdArgs A)
+{
+    typedef FwdShape<QG> SH;
+    constexpr int S = SH::S;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *w1s = smem;                           // [12][256]
+    float *ep = w1s + W1K * W1C;                 // [64][4]: b2, W3[.][0], W3[.][1], valid
+    float *ring = ep + 64 * 4;                   // [2][32][S]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int job = (int)blockIdx.x / NT, nt = (int)blockIdx.x % NT, n0 = 64 * nt;
+    FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];
+    gshift(J, (int64_t)blockIdx.y * A.gstride);
+    const float *__restrict__ P = J.P;
+    const float *__restrict__ W2 = P + off_w2(J.in);
+    const int m = 32 * w + li;
+
+    f32x4 pv[2];
+    fwd_chunk_load(W2, n0, 0, pv);
+    // layer-1 image -> LDS
+    if (J.w1i) {
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(J.w1i) + tid;
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(w1s) + tid;
+        const f32x4 a = g4[0], b = g4[256], c = g4[512];
+        l4[0] = a; l4[256] = b; l4[512] = c;
+    } else {
+        const int k = min(tid, H1N - 1);
+        float v[W1K];
+#pragma unroll
+        for (int j = 0; j < W1K; ++j) v[j] = P[(j == W1K - 1 ? J.in : min(j, J.in - 1)) * H1N + k];
+#pragma unroll
+        for (int j = 0; j < W1K; ++j) w1s[j * W1C + tid] = ((j < J.in || j == W1K - 1) && tid < H1N) ? v[j] : 0.0f;
+    }
+    if (tid < 64) {
+        const int n = n0 + tid, nc = min(n, H2N - 1);
+        const float valid = n < H2N ? 1.0f : 0.0f;
+        const float b2 = P[off_b2(J.in) + nc], w30 = P[off_w3(J.in) + nc * J.out], w31 = J.out == 2 ? P[off_w3(J.in) + nc * 2 + 1] : 0.0f;
+        ep[tid * 4 + 0] = b2; ep[tid * 4 + 1] = w30 * valid; ep[tid * 4 + 2] = w31 * valid; ep[tid * 4 + 3] = valid;
+    }
+    // this lane's B operands of layer 1: x[2 s + lh][m]
+    float xreg[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) xreg[s] = J.X[(2 * s + lh) * BP + m];
+    if (J.ap3) {                                 // rows 9, 10 from an actor pass: a[o][m] = tanh(b3[o] + partials)
+        float a0 = J.ab3[0], a1 = J.ab3[1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { a0 += J.ap3[(t * 2 + 0) * BP + m]; a1 += J.ap3[(t * 2 + 1) * BP + m]; }
+        a0 = tanhf(a0); a1 = tanhf(a1);          // Dense(500, 2, tanh)
+        if (lh == 1) xreg[4] = a0; else xreg[5] = a1;          // row 9 = (s 4, lh 1), row 10 = (s 5, lh 0)
+        if (J.api && nt == 0) J.api[lh * BP + m] = lh ? a1 : a0;
+    }
+    fwd_chunk_store<S>(ring, pv);
+    __syncthreads();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+    float da0 = 0.0f, da1 = 0.0f;
+    const float d3q = m < A.batch ? -1.0f / (float)A.batch : 0.0f;          // d(-mean q)/dq
+    // One pass over the n-tile's eight weight chunks; chunk it + 1 is requested before chunk it is consumed and lands in the other half
+    // of the ring.  BWD = false: layer 2 forward; BWD = true (QG only): the input gradient through this n-tile.
+    auto pass = [&](auto bwd, int it0, bool wrap) {
+        constexpr bool BWD = decltype(bwd)::value;
+#pragma unroll 1
+        for (int it = it0; it < it0 + 8; ++it) {
+            const int c = it & 7;
+            const float *buf = ring + (it & 1) * 32 * S;
+            const bool more = wrap || c < 7;
+            if (more) fwd_chunk_load(W2, n0, (it + 1) & 7, pv);
+            const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
+            if constexpr (!BWD) {
+                // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers
+                const float *pa = buf + 4 * lh * S + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float b = fmaxf(t[r], 0.0f);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S], b, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S + 32], b, acc[1], 0, 0, 0);
+                }
+            } else {
+                // backward through this n-tile: D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m], rows k = 32 c .. + 31; M = acc (see below)
+                f32x16 g;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+                const float *pa = buf + li * S + 4 * lh;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[32 * tt + (r & 3) + 8 * (r >> 2)], acc[tt][r], g, 0, 0, 0);
+                const float *pw = w1s + 9 * W1C + 32 * c + 4 * lh;             // W1[9 + o][k]: the action rows (columns >= 250 zero)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = t[r] > 0.0f ? g[r] : 0.0f;                // layer-1 relu mask
+                    da0 = fmaf(pw[(r & 3) + 8 * (r >> 2)], v, da0);
+                    da1 = fmaf(pw[W1C + (r & 3) + 8 * (r >> 2)], v, da1);
+                }
+            }
+            if (more) fwd_chunk_store<S>(ring + ((it + 1) & 1) * 32 * S, pv);
+            __syncthreads();
+        }
+    };
+    pass(std::false_type{}, 0, QG);
+    // epilogue of the forward pass: bias, relu, store, layer-3 partials; QG: M[n][m] = d3q[m] W3[n] (h2 > 0) replaces acc
+    auto epilogue = [&](auto keep) {
+        constexpr bool KEEP = decltype(keep)::value;
+        float p0 = 0.0f, p1 = 0.0f;
+        const float *epl = ep + 16 * lh;
+        float *hp = J.H2 + (n0 + 4 * lh) * BP + m;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nb = 32 * tt + (r & 3) + 8 * (r >> 2);              // + 4 lh = the tile row
+                const f32x4 e = *reinterpret_cast<const f32x4 *>(epl + nb * 4);
+                const float h = fmaxf(acc[tt][r] + e[0], 0.0f) * e[3];
+                if constexpr (KEEP) hp[nb * BP] = h;
+                p0 = fmaf(h, e[1], p0);
+                p1 = fmaf(h, e[2], p1);
+                if (QG) acc[tt][r] = h > 0.0f ? e[1] * d3q : 0.0f;
+            }
+        p0 += __shfl_xor(p0, 32, 64);
+        p1 += __shfl_xor(p1, 32, 64);
+        if (lh == 0) { J.P3[(nt * 2 + 0) * BP + m] = p0; J.P3[(nt * 2 + 1) * BP + m] = p1; }
+    };
+    if (J.H2) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    if constexpr (QG) pass(std::true_type{}, 8, false);
+    if (QG) {
+        da0 += __shfl_xor(da0, 32, 64);
+        da1 += __shfl_xor(da1, 32, 64);
+        if (lh == 0) { J.DAP[(nt * 2 + 0) * BP + m] = da0; J.DAP[(nt * 2 + 1) * BP + m] = da1; }
+    }
+}
+
+// ================================================================================================================================
+// The network being differentiated (P3 / P4: critic, P6 / P7: actor)
+// ================================================================================================================================
+struct NetArgs {
+    shems_ddpg d;          // learner 0's record (heads, losses, workspace)
+    AdamCtx c;
+    int64_t gstride;
+    int head;              // 1 = critic loss head, 2 = actor head
+    int store_grad;
+};
+template <int IN> struct NetOf {
+    static constexpr bool critic = IN == CIN;
+    static constexpr int OUT = critic ? 1 : 2;
+    __device__ static const float *X(const float *ws) { return ws + TP_X; }
+    __device__ static const float *w1i(float *ws) { return w1i_of(ws, critic ? NET_CRITIC : NET_ACTOR); }
+    __device__ static const float *w3f(const float *ws) { return ws + (critic ? TP_FW3C : TP_FW3A); }
+    __device__ static const float *H2(const float *ws) { return ws + (critic ? TP_H2C : TP_H2A); }
+    __device__ static float *d3(float *ws) { return ws + (critic ? TP_D3C : TP_D3A); }
+};
+
+// ---- heads: the error signal at the output layer, d3 [2][BP] into LDS (every thread of the workgroup takes part); the publishing
+// workgroup also stores it for P4 / P7, reports the loss and applies the b3 gradient ----
+__device__ __forceinline__ void head_critic(const NetArgs &A, const shems_ddpg &d, const AdamCtx &c, float *d3s, float *red, bool publisher)
+{
+    float *ws = d.ws;
+    const int t = threadIdx.x, m = t & 127;
+    float dq = 0.0f, diff = 0.0f;
+    if (t < BP) {
+        const float *Pt = p3_of(ws, NET_CRITIC_T), *Pc = p3_of(ws, NET_CRITIC);
+        float q2 = ws[TP_FB3 + 1], q = ws[TP_FB3 + 0];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { q2 += Pt[(i * 2) * BP + m]; q += Pc[(i * 2) * BP + m]; }
+        const float y = ws[TP_R + m] + d.gamma * (1.0f - ws[TP_DONE + m]) * q2;            // DDPG.jl:133
+        diff = m < d.batch ? q - y : 0.0f;
+        dq = 2.0f * diff / (float)d.batch;                                                  // d mse / d q
+    }
+    d3s[t] = t < BP ? dq : 0.0f;
+    if (publisher) {
+        d.ws[TP_D3C + t] = t < BP ? dq : 0.0f;
+        const float s1 = wave_sum64(diff * diff), s2 = wave_sum64(dq);
+        if ((t & 63) == 0) { red[t >> 6] = s1; red[4 + (t >> 6)] = s2; }
+        __syncthreads();
+        if (t == 0) {
+            d.losses[0] = (red[0] + red[1]) / (float)d.batch;                               // Flux.mse
+            adam_at(c, off_b3(CIN, 1), red[4] + red[5], A.store_grad != 0);
+        }
+    }
+}
+__device__ __forceinline__ void head_actor(const NetArgs &A, const shems_ddpg &d, const AdamCtx &c, float *d3s, float *red, bool publisher)
+{
+    float *ws = d.ws;
+    const int t = threadIdx.x, o = t >> 7, m = t & 127;
+    float da = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) da += ws[TP_DAP + (int64_t)(p * 2 + o) * BP + m];
+    const float a = ws[TP_API + t];
+    const float g = da * (1.0f - a * a);                       // through tanh
+    d3s[t] = g;
+    if (publisher) {
+        ws[TP_D3A + t] = g;
+        float q = 0.0f;
+        if (o == 0 && m < d.batch) {
+            const float *Pq = p3_of(ws, PASS_CRITIC2);
+            q = d.critic[off_b3(CIN, 1)];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) q += Pq[(i * 2) * BP + m];
+        }
+        const float sg = wave_sum64(g), sq = wave_sum64(q);
+        if ((t & 63) == 0) { red[t >> 6] = sg; red[4 + (t >> 6)] = sq; }
+        __syncthreads();
+        if (t == 0) {
+            d.losses[1] = -(red[4] + red[5]) / (float)d.batch;     // loss_act = -mean(critic(vcat(s, actor(s))))
+            adam_at(c, off_b3(SIN, 2), red[0] + red[1], A.store_grad != 0);
+            adam_at(c, off_b3(SIN, 2) + 1, red[2] + red[3], A.store_grad != 0);
+        }
+    }
+}
+
+// ================================================================================================================================
+// P3 / P6: D1' [m][k] = mask1 .* sum_n D2[n][m] W2[k][n] for one 64-wide k-tile and the whole batch, D2[n][m] = (sum_o W3[n][o]
+// d3[o][m]) (h2[n][m] > 0) generated from relu(layer 2) as it is loaded -- straight into MFMA operand layout, no LDS; the weights
+// stream through an LDS ring in 32-deep n-chunks.  The product is computed TRANSPOSED (rows = samples, columns = hidden units): its
+// D layout is then the B operand of the layer-1 gradient gW1[j][k] = sum_m x[j][m] D1[k][m], which follows on the matrix pipe without
+// any LDS round trip (the bias gradient is the row of ones of the input block).  ADAM + soft update for the k-tile's layer-1 columns.
+// ================================================================================================================================
+constexpr int D1_S = 33;
+constexpr int D1_LDS = (2 * 64 * D1_S + 1024 + 2 * BP + 8) * 4;
+static_assert(2 * 64 * D1_S >= 4 * 2 * 8 * 64, "the ring holds the four waves' gW1 partials");
+
+template <int IN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
+{
+    typedef NetOf<IN> N;
+    constexpr int OUT = N::OUT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ring = smem;                          // [2][64 k][33]
+    float *w3s = ring + 2 * 64 * D1_S;           // [512][2] frozen W3
+    float *d3s = w3s + 1024;                     // [2][BP]
+    float *red = d3s + 2 * BP;                   // [8]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int kt = blockIdx.x, k0 = 64 * kt;
+    const int64_t off = (int64_t)blockIdx.y * A.gstride;
+    shems_ddpg d = A.d;
+    AdamCtx c = A.c;
+    gshift(d, off); gshift(c, off);
+    float *ws = d.ws;
+    const float *__restrict__ P = c.p;
+    const float *__restrict__ W2 = P + off_w2(IN);
+    const float *__restrict__ H2 = N::H2(ws);
+    const int m = 32 * w + li;
+
+    // A chunk q: W2[k0 .. k0 + 63][32 q .. 32 q + 31] (128 B per row), two float4 per thread; rows >= 250 clamped (their outputs are
+    // never stored), columns >= 500 of the last chunk meet D2 rows that are exactly zero
+    auto a_load = [&](int q, f32x4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = it * 256 + tid, k = min(k0 + (e >> 3), H1N - 1);
+            v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + 32 * q + 4 * (e & 7));
+        }
+    };
+    auto a_store = [&](float *buf, const f32x4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = it * 256 + tid;
+            float *p = buf + (e >> 3) * D1_S + 4 * (e & 7);
+            p[0] = v[it][0]; p[1] = v[it][1]; p[2] = v[it][2]; p[3] = v[it][3];
+        }
+    };
+    // B operand source of chunk q: h2[32 q + 2 s + lh][m]
+    auto h_load = [&](int q, float (&h)[16]) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) h[s] = H2[(int64_t)(32 * q + 2 * s + lh) * BP + m];
+    };
+    f32x4 pv[2];
+    float hc[16], hn[16];
+    a_load(0, pv);
+    h_load(0, hc);
+    {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(N::w3f(ws))[tid];
+        reinterpret_cast<f32x4 *>(w3s)[tid] = v;
+    }
+    if (A.head == 1) head_critic(A, d, c, d3s, red, kt == 0); else head_actor(A, d, c, d3s, red, kt == 0);
+    a_store(ring, pv);
+    __syncthreads();
+    const float d30 = d3s[m], d31 = d3s[BP + m];
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+#pragma unroll 1
+    for (int q = 0; q < 16; ++q) {
+        const float *buf = ring + (q & 1) * 64 * D1_S;
+        if (q < 15) { a_load(q + 1, pv); h_load(q + 1, hn); }
+        const float *pb = buf + li * D1_S + lh;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * (32 * q + 2 * s + lh));
+            const float gsum = OUT == 2 ? fmaf(w3.y, d31, w3.x * d30) : w3.x * d30;
+            const float d2 = hc[s] > 0.0f ? gsum : 0.0f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[2 * s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[32 * D1_S + 2 * s], acc[1], 0, 0, 0);
+        }
+        if (q < 15) a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hc[s] = hn[s];
+    }
+    // ---- layer-1 relu mask: pre-activations transposed, rows = samples of this wave's column tile, columns = the k-tile's units ----
+    const float *w1i = N::w1i(ws);
+    const float *X = N::X(ws);
+    float xa[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) xa[s] = X[(2 * s + lh) * BP + m];
+    // A operands of the layer-1 gradient: x[j = li][32 w + drow(r, lh)] (rows >= 12 zero)
+    f32x4 xq[4];
+    {
+        const float keep = li < W1K ? 1.0f : 0.0f;
+        const float *px = X + min(li, W1K - 1) * BP + 32 * w + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const f32x4 *>(px + 8 * q) * keep;
+    }
+    float *redp = ring;                          // [4 waves][2 tt][8 r][64 lanes]  (the ring is free: the loop ended with a barrier)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float wb[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wb[s] = w1i[(2 * s + lh) * W1C + k0 + 32 * tt + li];
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wb[s], t, 0, 0, 0);
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dv = t[r] > 0.0f ? acc[tt][r] : 0.0f;                 // D1'[m = drow(r, lh)][k = li]
+            g = __builtin_amdgcn_mfma_f32_32x32x2f32(xq[r >> 2][r & 3], dv, g, 0, 0, 0);
+        }
+        // rows j = drow(r, lh) < 12: r = 0..3 (both halves), r = 4..7 (lh = 0)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) redp[((w * 2 + tt) * 8 + r) * 64 + lane] = g[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int sidx = u * 256 + tid, ln = sidx & 63, rr = (sidx >> 6) & 7, tt = sidx >> 9;
+        const float *pr = redp + (tt * 8 + rr) * 64 + ln;
+        const float gsum = ((pr[0] + pr[2 * 8 * 64]) + pr[2 * 2 * 8 * 64]) + pr[3 * 2 * 8 * 64];
+        const int j = drow(rr, ln >> 5), k = k0 + 32 * tt + (ln & 31);
+        if (k < H1N && (j < IN || j == W1K - 1)) adam_at(c, j == W1K - 1 ? off_b1(IN) + k : j * H1N + k, gsum, A.store_grad != 0);
+    }
+}
+
+// ================================================================================================================================
+// P4 / P7: gW2[k][n] = sum_m h1[k][m] D2[n][m] for one 64 x 64 tile, ADAM + soft target update by the lane that holds the element;
+// the k-tile-0 workgroups also finish gb2[n] = sum_m D2[n][m] and gW3[n][o] = sum_m h2[n][m] d3[o][m] of their n-tile.
+// h1' (samples x units) is recomputed on the matrix pipe per 32-sample block -- its D layout is the A operand; D2 goes through LDS.
+// ================================================================================================================================
+constexpr int GW_S = BP + 1;
+constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3) * 4;
+
+template <int IN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
+{
+    typedef NetOf<IN> N;
+    constexpr int OUT = N::OUT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *d2s = smem;                           // [64 n][129]
+    float *d3s = d2s + 64 * GW_S;                // [2][BP]
+    float *w3s = d3s + 2 * BP;                   // [64][2]
+    float *rs = w3s + 64 * 2;                    // [64][3] row sums: gb2, gW3[.][0], gW3[.][1]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int nt = (int)blockIdx.x & 7, kt = (int)blockIdx.x >> 3, n0 = 64 * nt, k0 = 64 * kt;
+    const int kw = w >> 1, nw = w & 1;
+    const int64_t off = (int64_t)blockIdx.y * A.gstride;
+    shems_ddpg d = A.d;
+    AdamCtx c = A.c;
+    gshift(d, off); gshift(c, off);
+    float *ws = d.ws;
+    const float *__restrict__ H2 = N::H2(ws);
+    const bool store_grad = A.store_grad != 0;
+
+    // this lane's 16 elements of the tile: (k = k0 + 32 kw + drow(r, lh), n = n0 + 32 nw + li); their moments / parameter / target are
+    // requested right before the product (below) and consumed after it
+    const int nn = n0 + 32 * nw + li;
+    const int kb = k0 + 32 * kw + 4 * lh;
+    f32x4 hv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid;
+        hv[it] = *reinterpret_cast<const f32x4 *>(H2 + (int64_t)(n0 + (e >> 5)) * BP + 4 * (e & 31));
+    }
+    d3s[tid] = N::d3(ws)[tid];
+    if (tid < 128) w3s[tid] = N::w3f(ws)[2 * n0 + tid];
+    const float *w1i = N::w1i(ws);
+    float wb[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wb[s] = w1i[(2 * s + lh) * W1C + k0 + 32 * kw + li];
+    __syncthreads();
+    // D2 panel + row sums
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid, nl = e >> 5, m4 = 4 * (e & 31);
+        const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * nl);
+        float sb = 0.0f, s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float h = hv[it][i], e0 = d3s[m4 + i], e1 = d3s[BP + m4 + i];
+            const float gsum = OUT == 2 ? fmaf(w3.y, e1, w3.x * e0) : w3.x * e0;
+            const float d2 = h > 0.0f ? gsum : 0.0f;
+            d2s[nl * GW_S + m4 + i] = d2;
+            sb += d2; s0 = fmaf(h, e0, s0); s1 = fmaf(h, e1, s1);
+        }
+        if (kt == 0) {                           // (workgroup-uniform)
+            sb = half_sum32(sb); s0 = half_sum32(s0); s1 = half_sum32(s1);
+            if (li == 0) { rs[nl * 3 + 0] = sb; rs[nl * 3 + 1] = s0; rs[nl * 3 + 2] = s1; }
+        }
+    }
+    __syncthreads();
+    float am[16], av[16], ap[16], at[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = min(kb + (r & 3) + 8 * (r >> 2), H1N - 1);
+        const int e = off_w2(IN) + k * H2N + min(nn, H2N - 1);
+        am[r] = c.mt[e]; av[r] = c.vt[e]; ap[r] = c.p[e]; at[r] = c.target[e];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float *X = N::X(ws);
+    const float *pb = d2s + (32 * nw + li) * GW_S + 4 * lh;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float xa[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) xa[s] = X[(2 * s + lh) * BP + 32 * mt + li];
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wb[s], t, 0, 0, 0);       // h1'[m][k] pre-activations
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), pb[32 * mt + (r & 3) + 8 * (r >> 2)], acc, 0, 0, 0);
+    }
+    // ADAM + soft update on this lane's 16 elements
+    {
+        float *gW = const_cast<float *>(c.g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kb + (r & 3) + 8 * (r >> 2);
+            adam_math(c, acc[r], am[r], av[r], ap[r], at[r]);
+            if (k < H1N && nn < H2N) {
+                const int e = off_w2(IN) + k * H2N + nn;
+                c.mt[e] = am[r]; c.vt[e] = av[r]; c.p[e] = ap[r]; c.target[e] = at[r];
+                if (store_grad) gW[e] = acc[r];
+            }
+        }
+    }
+    if (kt == 0 && tid < 64 * 3) {               // one element per thread: (row, b2 | W3[.][0] | W3[.][1])
+        const int nl = tid / 3, col = tid - nl * 3, n = n0 + nl;
+        if (n < H2N && col - 1 < OUT) adam_at(c, col == 0 ? off_b2(IN) + n : off_w3(IN) + n * OUT + (col - 1), rs[tid], store_grad);
+    }
+}
+
+static int set_attrs()
+{
+    static std::atomic<uint64_t> m0{0}, m1{0}, m2{0}, m3{0}, m4{0}, m5{0};
+    // (all below 64 KB: the opt-in is a no-op kept for the day a tile grows)
+    if (int rc = lds_optin(m0, reinterpret_cast<const void *>(&k_tp_fwd<false>), FwdShape<false>::LDS, "attr k_tp_fwd")) return rc;
+    if (int rc = lds_optin(m1, reinterpret_cast<const void *>(&k_tp_fwd<true>), FwdShape<true>::LDS, "attr k_tp_fwd<QG>")) return rc;
+    if (int rc = lds_optin(m2, reinterpret_cast<const void *>(&k_tp_d1<CIN>), D1_LDS, "attr k_tp_d1")) return rc;
+    if (int rc = lds_optin(m3, reinterpret_cast<const void *>(&k_tp_d1<SIN>), D1_LDS, "attr k_tp_d1")) return rc;
+    if (int rc = lds_optin(m4, reinterpret_cast<const void *>(&k_tp_gw2<CIN>), GW_LDS, "attr k_tp_gw2")) return rc;
+    if (int rc = lds_optin(m5, reinterpret_cast<const void *>(&k_tp_gw2<SIN>), GW_LDS, "attr k_tp_gw2")) return rc;
+    return SHEMS_OK;
+}
+
+}  // namespace tp
+}  // namespace shems
+
+using namespace shems;
+using namespace shems::tp;
+
+extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_replay *ring, const shems_group *g, int64_t ring_len, uint64_t seed,
+                                          uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,
+                                          double bp2_act, int32_t flags, void *stream)
+{
+    const char *fn = "shems_ddpg_group_update_tp";
+    if (!g || g->count < 1 || g->count > 65535 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
+        return set_error(SHEMS_ERR_ARG, "%s: shems_group needs 1 <= count <= 65535 and a 16-byte-multiple stride", fn);
+    if (!d || !d->actor || !d->critic || !d->actor_t || !d->critic_t || !d->m_actor || !d->v_actor || !d->m_critic || !d->v_critic ||
+        !d->s_min || !d->s_max || !d->ws || !d->losses)
+        return set_error(SHEMS_ERR_ARG, "%s: shems_ddpg has a NULL buffer", fn);
+    if ((flags & SHEMS_TP_STORE_GRAD) && (!d->grad_actor || !d->grad_critic)) return set_error(SHEMS_ERR_ARG, "%s: STORE_GRAD needs gradient buffers", fn);
+    if (flags & ~SHEMS_TP_STORE_GRAD) return set_error(SHEMS_ERR_ARG, "%s: unknown flag bits", fn);
+    if (d->batch < 1 || d->batch > BP) return set_error(SHEMS_ERR_ARG, "%s: batch must be in 1..128 (got %d)", fn, d->batch);
+    for (const float *p : {(const float *)d->actor, (const float *)d->critic, (const float *)d->actor_t, (const float *)d->critic_t, (const float *)d->ws})
+        if (((uintptr_t)p & 15) != 0) return set_error(SHEMS_ERR_ARG, "%s: parameter blocks and the workspace must be 16-byte aligned", fn);
+    if (!ring || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done || ring_len < 1 || ring_len > ring->capacity)
+        return set_error(SHEMS_ERR_ARG, "%s: bad replay ring / length", fn);
+    for (double bp : {bp1_crit, bp2_crit, bp1_act, bp2_act})
+        if (!(bp > 0.0 && bp < 1.0)) return set_error(SHEMS_ERR_ARG, "%s: beta powers must be in (0,1)", fn);
+    if (int rc = set_attrs()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned L = (unsigned)g->count;
+    const int64_t gs = g->count > 1 ? g->stride_bytes : 0;
+    const int sg = (flags & SHEMS_TP_STORE_GRAD) ? 1 : 0;
+    float *ws = d->ws;
+
+    PrepArgs pa{*d, *ring, ring_len, gs, seed, tick};
+    hipLaunchKernelGGL(k_tp_prep, dim3(L), dim3(256), 0, st, pa);
+
+    FwdArgs f;
+    std::memset(&f, 0, sizeof f);
+    f.gstride = gs; f.batch = d->batch;
+    f.job[0] = FwdJob{d->actor_t, ws + TP_X2, w1i_of(ws, NET_ACTOR_T), nullptr, nullptr, nullptr, nullptr, p3_of(ws, NET_ACTOR_T), nullptr, SIN, 2};
+    f.job[1] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, NET_CRITIC), nullptr, nullptr, nullptr, ws + TP_H2C, p3_of(ws, NET_CRITIC), nullptr, CIN, 1};
+    f.job[2] = FwdJob{d->actor, ws + TP_X, w1i_of(ws, NET_ACTOR), nullptr, nullptr, nullptr, ws + TP_H2A, p3_of(ws, NET_ACTOR), nullptr, SIN, 2};
+    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(3 * NT, L), dim3(256), FwdShape<false>::LDS, st, f);
+    // critic_target on [s'; actor_target(s')]
+    std::memset(&f.job, 0, sizeof f.job);
+    f.job[0] = FwdJob{d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
+                      p3_of(ws, NET_CRITIC_T), nullptr, CIN, 1};
+    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(NT, L), dim3(256), FwdShape<false>::LDS, st, f);
+
+    auto adam_ctx = [&](bool critic) {
+        const double eta = critic ? eta_crit : eta_act, bp1 = critic ? bp1_crit : bp1_act, bp2 = critic ? bp2_crit : bp2_act;
+        return critic ? AdamCtx{d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, nullptr, SHEMS_CRITIC_PARAMS, (int)CIN,
+                                eta, bp1, bp2, 1.0, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), d->tau}
+                      : AdamCtx{d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, nullptr, SHEMS_ACTOR_PARAMS, (int)SIN,
+                                eta, bp1, bp2, 1.0, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), d->tau};
+    };
+    NetArgs nc{*d, adam_ctx(true), gs, 1, sg};
+    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(4, L), dim3(256), D1_LDS, st, nc);
+    hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(4 * NT, L), dim3(256), GW_LDS, st, nc);
+    // updated critic on [s; actor(s)]: forward + input gradient
+    std::memset(&f.job, 0, sizeof f.job);
+    f.job[0] = FwdJob{d->critic, ws + TP_X, nullptr, p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
+                      ws + TP_DAP, CIN, 1};
+    hipLaunchKernelGGL(k_tp_fwd<true>, dim3(NT, L), dim3(256), FwdShape<true>::LDS, st, f);
+    NetArgs na{*d, adam_ctx(false), gs, 2, sg};
+    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(4, L), dim3(256), D1_LDS, st, na);
+    hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(4 * NT, L), dim3(256), GW_LDS, st, na);
+    return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
+}

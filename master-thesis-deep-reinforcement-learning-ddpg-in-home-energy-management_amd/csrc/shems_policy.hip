@@ -111,8 +111,6 @@ struct ActArgs {
     int gcount;
     int64_t gstride;
     int64_t genvs;
-    DevSync sy;                // pipelined training loop: wait for the update that publishes p.actor / tell the next update the ring is complete
-    int force_split;           // 1: the two-workgroups-per-tile form whatever the size (leaves LDS for a co-resident update workgroup)
 };
 
 template <class T>
@@ -215,12 +213,12 @@ __device__ __forceinline__ float2 gauss_pair(uint64_t seed, uint32_t tick, int64
     return make_float2(r * c, r * s);
 }
 
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
 #define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define PSTAMP(i)
 #endif
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
 #define TSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PSTAMP(i); } while (0)
 #else
 #define TSTAMP(i)
@@ -392,21 +390,6 @@ constexpr int free_keep(int c)
     return n;
 }
 
-#ifndef ABL_NOL1
-#define ABL_NOL1 0
-#endif
-#ifndef ABL_NODMA
-#define ABL_NODMA 0
-#endif
-#ifndef ABL_NOBAR
-#define ABL_NOBAR 0
-#endif
-#ifndef ABL_NOLDS
-#define ABL_NOLDS 0
-#endif
-#ifndef ABL_NOSCHED
-#define ABL_NOSCHED 0
-#endif
 template <int TM, int NW, int RD>
 __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 {
@@ -741,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
 #define CHUNK_BODY(c, ISSUE, ODD, NKS)                                                                             \
     do {                                                                                                        \
         const int cur_ = (c) & 1, nxt_ = cur_ ^ 1;                                                              \
-        if (ODD && !ABL_NOL1) L1_GROUP(((c) + 1) >> 1);                                                         \
+        if (ODD) L1_GROUP(((c) + 1) >> 1);                                                                      \
         const float *Wb_ = Wc + cur_ * kWcFloats + nbase;                                                       \
         const float *Hb_ = Hc + (((c) >> 1) & 1) * (32 * BM) + ((c) & 1) * (kKC * BM) + TM * li;                \
         AVec af_[2];                                                                                            \
@@ -760,22 +743,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
             _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                  \
                 if (NA == 4 ? ks < kDmaKs : ((ks & 1) == 0 && h_ == 0)) {                                       \
                     const int pc_ = NA == 4 ? wave + 4 * (2 * ks + h_) : wave + 8 * (ks >> 1);                  \
-                    if (ISSUE == 0 && !ABL_NODMA && NA == 4) {                                                  \
+                    if (ISSUE == 0 && NA == 4) {                                                                \
                         /* wave w moves the 8 consecutive pieces 8w..8w+7: one 64-bit address per chunk, the */   \
                         /* piece selected by the instruction's immediate offset (-4096 .. 3072, both sides)  */   \
                         glds16_piece(wbase_ + (size_t)(c) * kChunkBytes,                                        \
                                      reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + (8 * wave + 4) * 1024, 2 * ks + h_); \
-                    } else if (ISSUE == 0 && !ABL_NODMA)                                                        \
+                    } else if (ISSUE == 0)                                                                      \
                         glds16(W2g + ((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16,                          \
                                reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                   \
-                    else if (ISSUE == 1 && !ABL_NODMA)   /* short last chunk: source clamped to the end of W2 */ \
+                    else if (ISSUE == 1)                 /* short last chunk: source clamped to the end of W2 */ \
                         glds16(W2g + min(((c) + 1) * kChunkBytes + pc_ * 1024 + lane * 16, kTotalBytes - 16),   \
                                reinterpret_cast<char *>(Wc + nxt_ * kWcFloats) + pc_ * 1024);                   \
                 }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
-        if (!ABL_NOSCHED) sched_chunk<TM, NA, ISSUE != 2 && !ABL_NODMA, NKS>();                   \
-        if (!ABL_NOBAR) __syncthreads();                                                                        \
+        sched_chunk<TM, NA, ISSUE != 2, NKS>();                                                   \
+        __syncthreads();                                                                                        \
     } while (0)
 
     // Free-running form: chunk c of a wave = 8 k-steps on its own ring buffer c % RD and rows [16 c, +16) of the resident h1; the
@@ -790,7 +773,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
         /* a half-resident h1 (TM = 4): nothing of the second half is requested before it has been laid down */ \
         const int klim_ = (HR < 256 && (c) < kChunks / 2) ? (kChunks / 2) * (kKC / 2) : kFreeKsteps;            \
-        if (K2_ < klim_ && !ABL_NOLDS) {                                                                        \
+        if (K2_ < klim_) {                                                                                      \
             const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
             af_[K2_ % 3] = act_load_a<NA>(Wf + (c2_ % RD) * kFreeChunkFloats + kr_ * 128, li);                  \
             bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + ((c2_ * kKC) % HR + kr_) * BM + TM * li);       \
@@ -800,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                           \
             _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[K_ % 3], a), fvec_get<TM>(bf_[K_ % 3], b), acc[a][b], 0, 0, 0); \
-        if (!ABL_NOSCHED) {                                                                                     \
+        {                                                                                                       \
             __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
             __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                 \
@@ -810,10 +793,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                      \
             _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                      \
                 acc[2 + h_][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fvec_get<NA>(af_[K_ % 3], 2 + h_), fvec_get<TM>(bf_[K_ % 3], b), acc[2 + h_][b], 0, 0, 0); \
-            if (!ABL_NOSCHED) __builtin_amdgcn_sched_barrier(0);                                                \
-            if (!ABL_NODMA && (ks) < kDmaKs && 2 * (ks) + h_ < FREE_NPIECES((c) + RD - 1)) {                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            if ((ks) < kDmaKs && 2 * (ks) + h_ < FREE_NPIECES((c) + RD - 1)) {                                  \
                 FREE_PIECE((c) + RD - 1, 2 * (ks) + h_);                                                        \
-                if (!ABL_NOSCHED) __builtin_amdgcn_sched_barrier(0);                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
             }                                                                                                   \
         }                                                                                                       \
     } while (0)
@@ -946,7 +929,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
         reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, PRE ? xP + tid * kPreDw : PRE2 ? w1 + tid * kPreDw : nullptr);
     }
     PSTAMP(12);
-#ifndef ABL_STAMP
+#ifndef SHEMS_STAMP_ACT
     if (A.block_reward) {
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Wc);     // Wc is dead by now
@@ -1010,13 +993,12 @@ template <int TM, int NW, int NS, int RD>
 __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
 {
     static_assert(NW * NS == 8 && (NW == 4 || NW == 8), "8 column groups per env tile: 8 waves, or two workgroups of 4");
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
 #define GSTAMP(i, cond) do { if (threadIdx.x == 0 && (cond)) { reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)] = __builtin_amdgcn_s_memtime(); reinterpret_cast<unsigned long long *>(A.block_reward)[2*(i)+1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define GSTAMP(i, cond)
 #endif
     GSTAMP(0, blockIdx.x == 0);
-    dev_wait(A.sy);                                           // pipelined loop: the update that publishes A.p.actor has finished
     static_assert(RD >= 2 && RD <= 4 && TM >= 1 && TM <= 2, "ring of 2..4 chunks; relu(layer 1) fully resident (TM <= 2)");
     constexpr int NT_ = 64 * NW, BM = 32 * TM, HR = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1181,37 +1163,24 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
     BVec bf_[3];
     /* k-step K = 8 c + ks: operands in register buffer K % 3, requested two k-steps ago.  One scheduling region per k-step:        */
     /* [TM MFMAs] [A read of K + 2] [TM MFMAs] [B read of K + 2]; one LDS-DMA piece (asm) of chunk c + RD - 1 closes k-steps 0..3.   */
-/* Ablations of the layer-2 loop (diagnostic builds only, wrong results by construction; tools/README.md): which of its resources a     */
-/* co-resident kernel of another launch contends for -- -DABL_G_NODMA=1 (no W2 LDS-DMA), ABL_G_NOLDS=1 (no operand reads), ABL_G_NOMFMA=1. */
-#ifndef ABL_G_NODMA
-#define ABL_G_NODMA 0
-#endif
-#ifndef ABL_G_NOLDS
-#define ABL_G_NOLDS 0
-#endif
-#ifndef ABL_G_NOMFMA
-#define ABL_G_NOMFMA 0
-#endif
 #define G_KSTEP(c, ks)                                                                                          \
     do {                                                                                                        \
         const int K_ = 8 * (c) + (ks), K2_ = K_ + 2;                                                            \
-        if (K2_ < kGKsteps && !ABL_G_NOLDS) {                                                                   \
+        if (K2_ < kGKsteps) {                                                                                   \
             const int c2_ = K2_ >> 3, kr_ = 2 * (K2_ & 7) + lh;                                                 \
             af_[K2_ % 3] = *reinterpret_cast<const f32x2 *>(Wg + (c2_ % RD) * kGChunkFloats + kr_ * 64 + 2 * li); \
             bf_[K2_ % 3] = *reinterpret_cast<const BVec *>(Hc + (c2_ * kKC + kr_) * BM + TM * li);              \
         }                                                                                                       \
-        if (!ABL_G_NOMFMA) {                                                                                    \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
             acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][0], fvec_get<TM>(bf_[K_ % 3], b), acc[0][b], 0, 0, 0); \
         _Pragma("unroll") for (int b = 0; b < TM; ++b)                                                          \
             acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_[K_ % 3][1], fvec_get<TM>(bf_[K_ % 3], b), acc[1][b], 0, 0, 0); \
-        } else { _Pragma("unroll") for (int b = 0; b < TM; ++b) { acc[0][b][0] += af_[K_ % 3][0] * fvec_get<TM>(bf_[K_ % 3], b); acc[1][b][0] += af_[K_ % 3][1]; } } \
         __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
         __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                                                     \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (!ABL_G_NODMA && (ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
+        if ((ks) < g_pieces((c) + RD - 1)) { G_PIECE((c) + RD - 1, (ks) < kGPieces ? (ks) : 0); __builtin_amdgcn_sched_barrier(0); } \
     } while (0)
     /* Two waves per SIMD (NW = 8; waves w and w + 4 share one): the issue arbiter serves the older wave first -- waves 0..3 finish the  */
     /* layer after 19.7 k cycles, waves 4..7 after 35.3 k (32 k of matrix work per SIMD).  Swapping s_setprio between the two every    */
@@ -1232,7 +1201,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep0_) : "memory");          // this wave's chunk 0 has landed
         __builtin_amdgcn_sched_barrier(0);
     }
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
     if (lane == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(A.block_reward)[48 + wave] = __builtin_amdgcn_s_memtime();    // every wave's loop start
 #endif
 #pragma unroll
@@ -1249,7 +1218,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
     G_CHUNK(15, (kH1 - (kChunks - 1) * kKC) / 2);                              // rows 240..249 only = 5 k-steps
 
     GSTAMP(10, blockIdx.x == 0);
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
     if (lane == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long *>(A.block_reward)[32 + wave] = __builtin_amdgcn_s_memtime();    // every wave's loop end
 #endif
     // ---- layer 3 of this group, canonical order (see act_col) ---------------------------------------------------------------------
@@ -1323,7 +1292,7 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
     GSTAMP(11, tile == 0 && fin);
     if (fin) reward = act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, xP + tid * kPreDw);
     GSTAMP(12, tile == 0 && fin);
-#ifndef ABL_STAMP
+#ifndef SHEMS_STAMP_ACT
     if (NS == 1 && A.block_reward) {
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Wc);     // the rings are dead by now
@@ -1331,7 +1300,6 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
         if (tid == 0) A.block_reward[tile] = s;
     }
 #endif
-    dev_arrive(A.sy, true);                                   // ring rows and env state of this workgroup are visible: one more workgroup done
 }
 
 // =====================================================================================================================
@@ -1365,7 +1333,6 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
 {
     constexpr int TM = 2, BM = 64, NA = 4, NT_ = 256, HR = 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    dev_wait(A.sy);                                           // pipelined loop: the update that publishes A.p.actor has finished
     float *Wc = reinterpret_cast<float *>(smem);             // [4 waves][RD][4 rows][128] private W2 rings
     float *Hc = Wc + 4 * k2RD * k2CF + 16;                   // [128][BM] relu(layer 1), one half at a time
     float *xT = Hc + HR * BM;                                // [10][BM]
@@ -1625,7 +1592,7 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
         const float p0 = tl[kH2P + kH2P * kOut + 0] + (hs[0][0] + hs[1][0]), p1 = tl[kH2P + kH2P * kOut + 1] + (hs[0][1] + hs[1][1]);
         reward = act_env_tail(A, i, p0, p1, learner, goff, nullptr, xP + tid * kPreDw);
     }
-#ifndef ABL_STAMP
+#ifndef SHEMS_STAMP_ACT
     if (A.block_reward) {
         __syncthreads();
         double *red64 = reinterpret_cast<double *>(Hc);      // h1 is dead by now
@@ -1633,7 +1600,6 @@ __global__ __launch_bounds__(256, 2) void k_act2(ActArgs A)
         if (tid == 0) A.block_reward[bid] = s;
     }
 #endif
-    dev_arrive(A.sy, true);
 }
 
 static int launch_act2(const ActArgs &a, hipStream_t st)
@@ -1712,8 +1678,7 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
         if (tiles > kSplitMaxTiles) return set_error(SHEMS_ERR_ARG, "k_actg: %lld env tiles exceed the split form's scratch", (long long)tiles);
         if (split_scratch(st, &x) != SHEMS_OK) {
             // no exchange slab for this (device, stream) -- the 33rd distinct stream of a long-lived process, or hipMalloc failed: the
-            // one-workgroup-per-tile form needs none and writes the same bytes (unless the caller asked for THIS form's LDS footprint)
-            if (a.force_split || a.sy.wait_flags || a.sy.arrive_count) return SHEMS_ERR_ARG;      // (message set by split_scratch)
+            // one-workgroup-per-tile form needs none and writes the same bytes
             return launch_actg<1, 8, 1, RD>(a, st);
         }
     }
@@ -1741,25 +1706,17 @@ static int act_tile_envs(int64_t m, bool grouped = false)
 
 static int dispatch_act(const ActArgs &a, hipStream_t st)
 {
-    static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int form = act_form(), form4 = act_form4();
-#ifdef ABL_STAMP
+#ifdef SHEMS_STAMP_ACT
     const bool want_sum = false;                              // stamp builds: block_reward is the stamp buffer
 #else
     const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
     const int64_t cnt = a.m - a.m0;                           // envs of this launch (a range launch: every form writes the same bytes)
-    if (a.sy.wait_flags || a.sy.arrive_count || a.force_split) {
-        // device-side dependencies live in the two forms the pipelined loop runs: the split form (one 92-KB workgroup per CU at a time)
-        // up to 16 384 envs when asked for, else two-per-CU 64-env tiles
-        if (a.gcount > 1 || a.block_reward) return set_error(SHEMS_ERR_ARG, "act: device-side dependencies are not available to learner groups / per-tile sums");
-        if (a.force_split && (cnt + 31) / 32 <= kSplitMaxTiles) return launch_actg<1, 4, 2, 3>(a, st);
-        return launch_act2(a, st);
-    }
     if (form4 == 2 && form < 0 && cnt > 8192 && a.gcount <= 1) return launch_act2(a, st);
     if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
     const int tm = pick_tm(cnt);
-    if (tm == 4) return nw == 8 ? launch_act<4, 8>(a, st) : form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
+    if (tm == 4) return form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
     if (tm == 2) return form == 0 || form4 == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
     if (form == 0) return launch_act<1, 4>(a, st);
     if (form == 2) return launch_act<1, 4, 2>(a, st);
@@ -1818,13 +1775,12 @@ int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks)
 int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
 {
     if (n_envs <= 0 || !out || cap < 2) return set_error(SHEMS_ERR_ARG, "shems_act_step_kernel: bad arguments");
-    static const int nw = []() { const char *e = getenv("SHEMS_ACT_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
     const int form = act_form(), form4 = act_form4();
     const char *name;
     if (form4 == 2 && ((form < 0 && n_envs > 8192 && !grouped) || form == 12)) name = "shems::k_act2";
     else {
         const int tm = pick_tm(n_envs);
-        if (tm == 4) name = nw == 8 ? "shems::k_act<4, 8, 0>" : form4 == 0 ? "shems::k_act<4, 4, 0>" : "shems::k_act<4, 4, 2>";
+        if (tm == 4) name = form4 == 0 ? "shems::k_act<4, 4, 0>" : "shems::k_act<4, 4, 2>";
         else if (tm == 2) name = form == 0 || form4 == 0 ? "shems::k_act<2, 4, 0>" : "shems::k_act<2, 4, 2>";
         else if (form == 0) name = "shems::k_act<1, 4, 0>";
         else if (form == 2) name = "shems::k_act<1, 4, 2>";
@@ -1883,30 +1839,6 @@ int shems_act_step_dev(const shems_view *v, const shems_act_params *p, float *d_
 
 }  // extern "C"
 
-namespace shems {
-int act_step_sync(const shems_view *v, const shems_act_params *p, float *d_rewards_f32, const shems_replay *ring, const shems_ring_window *window,
-                  const DevSync &sy, int split, int64_t *grid_out, hipStream_t st)
-{
-    if (int rc = check_act(p, "act_step_sync")) return rc;
-    if (int rc = check_view(v, "act_step_sync")) return rc;
-    ActArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.v = *v; a.p = *p; a.obs = v->obs; a.m = v->n_envs;
-    a.rewards_f32 = d_rewards_f32;
-    a.do_step = 1;
-    a.sy = sy; a.force_split = split;
-    if (ring && window && window->count > 0) {
-        if (ring->capacity <= 0 || !ring->s || !ring->a || !ring->r || !ring->s2 || !ring->done)
-            return set_error(SHEMS_ERR_ARG, "act_step_sync: incomplete replay ring");
-        if (window->count > ring->capacity || window->count > v->n_envs || window->pos < 0 || window->offset < 0 || window->offset >= v->n_envs)
-            return set_error(SHEMS_ERR_ARG, "act_step_sync: ring window outside the ring or the batch");
-        a.ring = *ring; a.win = *window; a.use_ring = 1;
-    }
-    const bool splitf = split && (a.m + 31) / 32 <= kSplitMaxTiles;
-    if (grid_out) *grid_out = splitf ? 2 * ((a.m + 31) / 32) : (a.m + 63) / 64;
-    return dispatch_act(a, st);
-}
-}  // namespace shems
 
 extern "C" {
 

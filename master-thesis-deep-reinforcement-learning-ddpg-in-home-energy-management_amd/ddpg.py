@@ -97,8 +97,6 @@ def _declare():
     L.shems_act_step_kernel.restype = C.c_int
     PD = C.POINTER(DdpgArgs)
     L.shems_ddpg_workspace_floats.argtypes = [C.POINTER(i64)]
-    L.shems_ddpg_sync_timeouts.argtypes = [PD, C.POINTER(i64), vp]
-    L.shems_ddpg_sync_timeouts.restype = C.c_int
     dbl = C.c_double
     L.shems_ddpg_update.argtypes = [PD, C.POINTER(_capi.Replay), i64, C.c_uint64, C.c_uint32, i64, i64, dbl, dbl, dbl, dbl, dbl, dbl, vp, vp]
     L.shems_ddpg_update.restype = C.c_int
@@ -653,16 +651,6 @@ class Agent:
         self.bp_actor = [self.bp_actor[0] * 0.9, self.bp_actor[1] * 0.999]
         self.updates += 1
 
-    def sync_timeouts(self):
-        """Device-side waits of the pipelined training loop (shems_train_steps with SHEMS_LOOP_SYNC=device) that gave up on this learner's
-        workspace since the last call: 0 in every supported use (shems_ddpg_sync_timeouts; read and cleared).  Synchronises the stream."""
-        if self.wide:
-            return 0                                   # the wide path has no in-launch wait
-        d = self._ddpg_args()
-        out = C.c_int64(0)
-        _capi.check(self.L.shems_ddpg_sync_timeouts(C.byref(d), C.byref(out), self._stream()))
-        return out.value
-
     def sample_indices(self, tick, ring_len, batch=None):
         batch = self.batch if batch is None else int(batch)
         out = np.empty(batch, np.int64)
@@ -942,8 +930,6 @@ class TrainWorkload:
             if n.value:
                 raise RuntimeError(f"{n.value} waits of the direct gradient exchange gave up: a peer never delivered, the replicas have diverged")
         self.env.check_error()
-        if self.agent.sync_timeouts():
-            raise RuntimeError("a device-side wait of the pipelined loop gave up: the steps since the last check are invalid")
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
             raise RuntimeError("non-finite network parameters after the timed steps")
         # replicas: every rank's learner must hold the same bytes (they started identical and added the same gradients in the same order);

@@ -36,6 +36,8 @@ def _declare_group():
     dbl = C.c_double
     L.shems_ddpg_group_update.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, vp]
     L.shems_ddpg_group_update.restype = C.c_int
+    L.shems_ddpg_group_update_tp.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, C.c_int32, vp]
+    L.shems_ddpg_group_update_tp.restype = C.c_int
     L.shems_ddpg_group_critic_grad.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, vp]
     L.shems_ddpg_group_critic_apply.argtypes = [PD, PG, C.c_double, C.c_double, C.c_double, vp]
     L.shems_ddpg_group_actor_grad.argtypes = [PD, PG, vp]
@@ -56,11 +58,20 @@ class LearnerGroup:
     """`count` independent learners, learner l seeded with (seed + l) for its network initialisation and (rng_seed + l)
     for its minibatch stream; exploration noise is keyed per env, so it differs between learners by construction."""
 
-    def __init__(self, count, envs_per_learner, seed=1231, rng_seed=None, capacity=MEM_SIZE, sigma=NOISE_SIGMA, device=None):
+    # replay() of a group: "throughput" = csrc/shems_gupd.hip (eight launches shaped for hundreds of learners: small tiles, four workgroups
+    # resident per CU, plain back-propagation), "latency" = the single-learner kernels with grid z = learner (five launches, per learner
+    # bit-identical to Agent.replay).  Default: throughput from TP_MIN_LEARNERS learners up.
+    TP_MIN_LEARNERS = 16
+
+    def __init__(self, count, envs_per_learner, seed=1231, rng_seed=None, capacity=MEM_SIZE, sigma=NOISE_SIGMA, device=None, form=None):
         import torch
         self.torch = torch
         self.L = _declare_group()
         self.count, self.envs_per_learner, self.capacity = int(count), int(envs_per_learner), int(capacity)
+        self.form = form if form is not None else ("throughput" if self.count >= self.TP_MIN_LEARNERS else "latency")
+        if self.form not in ("throughput", "latency"):
+            raise ValueError("form must be 'throughput' or 'latency'")
+        self.store_grad = False                    # throughput form: also leave the gradients in grad_actor / grad_critic (tests)
         if self.count < 1 or self.envs_per_learner % 128 != 0:
             raise ValueError("a learner group needs count >= 1 and envs_per_learner a multiple of 128")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -140,13 +151,17 @@ class LearnerGroup:
                 ring.pushed += int(window[1])
 
     def replay(self, tick=None):
-        """replay() (DDPG.jl:121-145) for every learner: 5 launches in total, grid z = learner (fused = False: the split calls,
-        7 launches -- the same bits)."""
+        """replay() (DDPG.jl:121-145) for every learner.  form "throughput": eight launches of csrc/shems_gupd.hip; "latency": 5 launches
+        in total, grid z = learner (fused = False: the split calls, 7 launches -- the same bits)."""
         a0, g, r0 = self.learners[0], self.struct(), self.rings[0].struct()
         d = a0._ddpg_args()
         st = self._stream()
         tick = self.updates if tick is None else tick
-        if getattr(self, "fused", True):
+        if self.form == "throughput":
+            _capi.check(self.L.shems_ddpg_group_update_tp(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed, int(tick) & 0xFFFFFFFF,
+                                                          a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], a0.eta_act, a0.bp_actor[0], a0.bp_actor[1],
+                                                          1 if self.store_grad else 0, st))
+        elif getattr(self, "fused", True):
             _capi.check(self.L.shems_ddpg_group_update(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed, int(tick) & 0xFFFFFFFF,
                                                        a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], a0.eta_act, a0.bp_actor[0], a0.bp_actor[1], st))
         else:

@@ -20,7 +20,7 @@ def _mods():
     return torch, S, D, G
 
 
-def _setup(L=3, E=256, cap=2400, mixed=False):
+def _setup(L=3, E=256, cap=2400, mixed=False, form="latency"):
     torch, S, D, G = _mods()
     if mixed:                                       # the thesis grid: learner l trains on charger profile l mod 10 (ids 1-9, 98; LU1:47-58)
         ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
@@ -32,7 +32,7 @@ def _setup(L=3, E=256, cap=2400, mixed=False):
     else:
         tab = S.tables.synthetic_table("train", 98)
         env = S.ShemsBatch(L * E, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
-    grp = G.LearnerGroup(L, E, seed=21, rng_seed=77, capacity=cap)
+    grp = G.LearnerGroup(L, E, seed=21, rng_seed=77, capacity=cap, form=form)
     grp.populate_memory(env, seed=5)
     grp.min_max_buffer()
     env.reset_(9, episode=1)
@@ -94,6 +94,132 @@ def test_group_step_and_update_match_single_learner_calls_bitwise(L, E, mixed):
             cnt -= 96        # the workspace ends with 96 bookkeeping words (timeout count of the pipelined loop's device-side waits): not results
         assert torch.equal(grp.slab[:, off:off + cnt].contiguous().view(torch.int32), slab_g[:, off:off + cnt].contiguous().view(torch.int32)), name
     env.check_error()
+
+
+def test_default_form_follows_the_group_width():
+    torch, S, D, G = _mods()
+    assert G.LearnerGroup(3, 128, capacity=720).form == "latency"
+    assert G.LearnerGroup(G.LearnerGroup.TP_MIN_LEARNERS, 128, capacity=720).form == "throughput"
+    with pytest.raises(ValueError):
+        G.LearnerGroup(3, 128, capacity=720, form="fast")
+
+
+# The THROUGHPUT form of the grouped update (csrc/shems_gupd.hip: eight launches for the whole group, plain back-propagation on small
+# tiles) sums in another order than the single-learner kernels, so it is held to what those are held to in tests/test_ddpg_gpu.py
+# instead of to their bits: every Flux.params block of every learner's two gradients within BLOCK_TOL of ITS max-abs of the float64
+# evaluation (DDPG.jl:121-145 restated in oracle/ddpg_oracle.py), ADAM / soft update element-wise at 1e-7 from the kernel's own
+# gradient, targets and losses at the latency form's tolerances.  batch 120 (8 pad columns) and 128 (none); two updates in a row
+# (the second with advanced beta powers, non-zero moments and targets that have moved).
+# A relu whose float64 pre-activation lies within fp32 accumulation error of zero is on in one evaluation order and off in another:
+# the gradient then differs by that unit's whole contribution (seen in this very test: unit 496 of an actor at 1.5e-8 for one sample
+# moved gb2[496] by 1.2e-3 of the block's max while every other element agreed to 4e-7).  Such a (learner, update, network) is not
+# compared -- and at most two of them may occur in the whole run.
+TIE = 1e-7                      # ~5 sigma of the fp32 accumulation error of a layer-2 pre-activation (K = 250 terms of ~3e-2)
+
+
+def _relu_margin(p, x, in_dim, out_dim):
+    _, (_, z1, _, z2, _, _) = DO.mlp_forward(p, x, in_dim, out_dim, out_dim == 2, keep=True, dtype=np.float64)
+    return min(float(np.abs(z1).min()), float(np.abs(z2).min()))
+
+
+@pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17)])
+def test_throughput_form_matches_float64_oracle_per_block(L, batch):
+    import test_ddpg_gpu as TD
+    ties = []
+    torch, S, D, G, env, grp = _setup(L=L, E=128, cap=2400, form="throughput")
+    grp.store_grad = True
+    rng = np.random.default_rng(5)
+    host = []
+    for l, ag in enumerate(grp.learners):
+        ag.batch = batch
+        pa, pc = ag.actor.cpu().numpy().copy(), ag.critic.cpu().numpy().copy()
+        pa[128000:129000] *= 30.0                 # lift the 3e-3 heads so every gradient path is exercised (as test_ddpg_gpu._setup)
+        pc[128250:128750] *= 30.0
+        pa[2250:2500] = rng.normal(0, 0.05, 250); pc[2750:3000] = rng.normal(0, 0.05, 250)
+        ag.set_params(actor=pa, critic=pc)
+        ring = grp.rings[l]
+        ring.done.copy_(torch.from_numpy((rng.random(ring.capacity) < 0.05).astype(np.uint8)))   # the formula's (1 - done) term
+        host.append(dict(pa=pa, pc=pc, pat=pa.copy(), pct=pc.copy(), s=ring.s.cpu().numpy(), a=ring.a.cpu().numpy(), r=ring.r.cpu().numpy(),
+                         s2=ring.s2.cpu().numpy(), done=ring.done.cpu().numpy(), s_min=ag.s_min.cpu().numpy(), s_max=ag.s_max.cpu().numpy(),
+                         opt_c=DO.Adam(len(pc), DO.ETA_CRIT), opt_a=DO.Adam(len(pa), DO.ETA_ACT)))
+    worst = {}
+    for tick in (3, 4):
+        grp.replay(tick=tick)
+        torch.cuda.synchronize()
+        for l, (ag, h) in enumerate(zip(grp.learners, host)):
+            idx = DO.sample_indices(grp.rng_seed + l, tick, batch, len(grp.rings[l]))
+            Lr = DO.Learner(h["pa"], h["pc"], h["s_min"], h["s_max"])
+            Lr.actor_t, Lr.critic_t = h["pat"], h["pct"]
+            s, a, r, s2, done = (h[k][idx] for k in ("s", "a", "r", "s2", "done"))
+            y = Lr.targets(r, s2, done.astype(bool))
+            gc64, lc64 = Lr.critic_grad(s, a, y, dtype=np.float64)
+            gc = ag.grad_critic.cpu().numpy()
+            sn = DO.normalize(s, h["s_min"], h["s_max"])
+            e = {}
+            if _relu_margin(h["pc"], np.concatenate([sn, a], 1), 11, 1) < TIE:
+                ties.append(("critic", l, tick))
+            else:
+                e = TD._assert_blocks(gc, gc64, 11, 1, f"critic gradient of learner {l}, tick {tick}: throughput form vs float64")
+            losses = ag.losses.cpu().numpy()
+            assert abs(losses[0] - lc64) < 1e-4 * max(1.0, abs(lc64)), (l, tick)
+            pc1 = h["opt_c"].step(h["pc"], gc)                                  # ADAM + soft update from the kernel's own gradient
+            crit = ag.critic.cpu().numpy()
+            np.testing.assert_allclose(crit, pc1, rtol=0, atol=1e-7)
+            pct1 = DO.soft_update(h["pct"], crit)
+            np.testing.assert_allclose(ag.critic_t.cpu().numpy(), pct1, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(ag.m_critic.cpu().numpy(), h["opt_c"].m, rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(ag.v_critic.cpu().numpy(), h["opt_c"].v, rtol=1e-6, atol=1e-15)
+            Lr.critic = crit                                                    # the actor gradient goes through the UPDATED critic
+            ga64, la64 = Lr.actor_grad(s, dtype=np.float64)
+            ga = ag.grad_actor.cpu().numpy()
+            a_pi = DO.actor_forward(h["pa"], sn, dtype=np.float64)
+            e2 = {}
+            if min(_relu_margin(h["pa"], sn, 9, 2), _relu_margin(crit, np.concatenate([sn, a_pi], 1), 11, 1)) < TIE:
+                ties.append(("actor", l, tick))
+            else:
+                e2 = TD._assert_blocks(ga, ga64, 9, 2, f"actor gradient of learner {l}, tick {tick}: throughput form vs float64")
+            assert abs(losses[1] - la64) < 1e-4 * max(1.0, abs(la64)), (l, tick)
+            pa1 = h["opt_a"].step(h["pa"], ga)
+            act = ag.actor.cpu().numpy()
+            np.testing.assert_allclose(act, pa1, rtol=0, atol=1e-7)
+            pat1 = DO.soft_update(h["pat"], act)
+            np.testing.assert_allclose(ag.actor_t.cpu().numpy(), pat1, rtol=0, atol=1e-7)
+            for k, v in list(e.items()) + [("a_" + k, v) for k, v in e2.items()]:
+                worst[k] = max(worst.get(k, 0.0), v)
+            # carry the DEVICE state forward: the next update starts from exactly these bytes
+            h["pa"], h["pc"], h["pat"], h["pct"] = act, crit, ag.actor_t.cpu().numpy(), ag.critic_t.cpu().numpy()
+            h["opt_c"].m, h["opt_c"].v = ag.m_critic.cpu().numpy().astype(h["opt_c"].m.dtype), ag.v_critic.cpu().numpy().astype(h["opt_c"].v.dtype)
+            h["opt_a"].m, h["opt_a"].v = ag.m_actor.cpu().numpy().astype(h["opt_a"].m.dtype), ag.v_actor.cpu().numpy().astype(h["opt_a"].v.dtype)
+    print("throughput form, worst per-block gradient error (fraction of the block's max-abs):", worst, "relu ties not compared:", ties)
+    assert len(ties) <= 2, ties
+
+
+def test_throughput_and_latency_forms_agree_and_leave_no_gradient_unless_asked():
+    """Same group, same minibatches: after one update the two forms' networks agree to ADAM's step size (the gradients differ in the
+    last bits only, and ADAM normalises them), and the throughput form does not touch the gradient buffers unless store_grad is set."""
+    torch, S, D, G, env, grp = _setup(L=4, E=128, cap=2400, form="throughput")
+    snap = grp.slab.clone()
+    grp.replay(tick=2)
+    torch.cuda.synchronize()
+    tp = grp.slab.clone()
+    for name in ("grad_actor", "grad_critic"):
+        off, cnt = grp.layout[name]
+        assert torch.equal(tp[:, off:off + cnt], snap[:, off:off + cnt]), name
+    grp.slab.copy_(snap)
+    for ag in grp.learners:
+        ag.bp_critic, ag.bp_actor, ag.updates = [0.9, 0.999], [0.9, 0.999], 0
+    grp.updates = 0
+    grp.form = "latency"
+    grp.replay(tick=2)
+    torch.cuda.synchronize()
+    for name, tol in (("critic", 2.1e-3), ("actor", 2.1e-4), ("critic_t", 2.1e-6), ("actor_t", 2.1e-7)):   # eta (1e-3 / 1e-4), x tau for the targets
+        off, cnt = grp.layout[name]
+        d = (tp[:, off:off + cnt] - grp.slab[:, off:off + cnt]).abs()
+        assert float(d.max()) <= tol, (name, float(d.max()))
+        assert float((d > tol * 1e-2).float().mean()) < 0.05, (name, float((d > tol * 1e-2).float().mean()))   # (a first step is +-eta: sign flips of ~0 gradients only)
+    for name in ("losses",):
+        off, cnt = grp.layout[name]
+        assert torch.allclose(tp[:, off:off + cnt], grp.slab[:, off:off + cnt], rtol=1e-4, atol=1e-5)
 
 
 def test_group_exploration_noise_is_keyed_by_the_global_env_index():

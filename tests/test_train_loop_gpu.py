@@ -176,47 +176,9 @@ def test_fused_step_on_more_than_32_streams():
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
-_SYNC_SCRIPT = r"""
-import sys, zlib, importlib
-sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
-import util as U, torch
-S = U.pkg(); D = importlib.import_module(U.PKG_NAME + ".ddpg")
-out = []
-for n, ups in ((4096, 1), (8192, 1), (12000, 2), (20000, 1)):
-    wl = D.TrainWorkload(S, torch, n, seed=31, updates=ups, loop="native", overlap="pipelined")
-    wl.steps(100); wl.steps(117)
-    wl.finish()                                      # raises if a device-side wait gave up
-    a = wl.agent
-    crc = 0
-    for t in (a.actor, a.critic, a.actor_t, a.critic_t, a.m_actor, a.v_critic, wl.ring.s2, wl.ring.a, wl.ring.r):
-        crc = zlib.crc32(t.detach().cpu().numpy().tobytes(), crc)
-    out.append(crc ^ zlib.crc32(wl.env.state.tobytes()))
-print("SYNC", *out)
-"""
-
-
-def test_every_way_of_carrying_the_pipeline_dependencies_gives_the_same_bytes():
-    """The pipelined loop's two dependencies per vector step can be stream memory operations (default), events, or -- up to 16 384 envs --
-    in-kernel waits on counts of finished producer workgroups with NO queue-level dependency at all (SHEMS_LOOP_SYNC=device: the published
-    actor stored write-through, K1 / the step kernel polling flag copies, bounded).  Same launches, same arguments: the same bytes, also
-    with two updates per step and above the device form's size limit (where it falls back to the queue-level form).  Child processes:
-    the knob is read when the loop's sync record is created."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _SYNC_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
-    got = {}
-    for how in ("values", "events", "device"):
-        e = dict(os.environ); e["SHEMS_LOOP_SYNC"] = how
-        r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=400)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got[how] = [ln for ln in r.stdout.splitlines() if ln.startswith("SYNC")][-1]
-    assert len(set(got.values())) == 1, got
-
-
 def test_mode_change_on_a_live_loop_record():
-    """A caller may flip shems_train_loop.mode between calls (the record is caller-owned): the loop's dependency objects of the other form
-    are made afresh behind a drain.  Pipelined with in-kernel waits (SHEMS_LOOP_SYNC=device) -> order-exact (queue-level) -> pipelined;
-    child process: the knob is read when the objects are made."""
+    """A caller may flip shems_train_loop.mode between calls (the record is caller-owned): pipelined -> order-exact -> pipelined on one
+    record (the two signal words carry both modes' dependencies; round 4's event and in-kernel forms were removed in round 5)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = r"""
@@ -234,6 +196,5 @@ wl.finish()
 assert wl.t == 60 and wl.agent.updates == 60 and bool(torch.isfinite(wl.agent.actor).all())
 print("MODES ok")
 """ % (root, os.path.join(root, "tests"))
-    e = dict(os.environ); e["SHEMS_LOOP_SYNC"] = "device"
-    r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "MODES ok" in r.stdout, r.stderr[-2000:]
