@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32-input MFMA
 BYTES_PER_ENV_STEP = 92        # obs 36 + action 8 + idx 4 in; obs' 36 + reward 4 + idx 4 out
 EP_LEN = 72
+# bytes one replay() has to move: 258 003 parameters x (28 B ADAM + 12 B soft update) + one pass over the four networks' weights
+UPDATE_ALGORITHMIC_BYTES = 258003 * 40 + 2 * 4 * (129002 + 129001)
+BATCH_FOR_UPDATE = 120
 
 
 def parse():
@@ -48,6 +51,7 @@ def parse():
                          "measured at the sustained clock and not on a GPU that was idle a moment ago (0 = off)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env", "group"])
+    ap.add_argument("--group-form", default=None, choices=["throughput", "latency"], help="group mode: the form of the grouped replay() (default: throughput from 16 learners up; csrc/shems_gupd.hip / csrc/shems_ddpg.hip)")
     ap.add_argument("--learners", type=int, default=32, help="group mode: independent learners per GPU (the thesis protocol of many seeds x chargers, SURVEY 8(f) rank 4); --envs must be learners x a multiple of 128")
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--overlap", nargs="?", const="pipelined", default=None, choices=["pipelined", "exact"],
@@ -423,7 +427,7 @@ def main():
             raise SystemExit("train mode requested but the DDPG path is not built")
         mode = "train" if train_mod is not None else "env"
     if mode == "group":
-        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank, mixed=args.mixed)
+        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank, mixed=args.mixed, form=args.group_form)
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
@@ -525,6 +529,29 @@ def main():
             roof["kernel_avg_us_is"] = k["avg_us_is"]
         if k.get("back_to_back_us") is not None:
             roof["kernel_back_to_back_us"] = k["back_to_back_us"]      # the same launch timed directly, back to back: the cross-check of the difference
+            roof["frac_back_to_back"] = k["algorithmic"] / (k["back_to_back_us"] * 1e-6) / 1e12 / k["peak"] if k["unit"] == "TFLOP/s" else None
+        for extra in ("hbm_frac_of_8tbs", "algorithmic_gbs", "per_learner_update_us", "launches_per_update", "other_kernel"):
+            if k.get(extra) is not None:
+                roof[extra] = k[extra]
+        # the learner's update next to the fused kernel (train mode): five dependent launches of 5-8 us at B = 120, latency-bound -- its
+        # MFMA fraction is reported all the same (north_star: "MFMA utilisation vs gfx950 peak"), with the counter bytes of the
+        # committed rocprofv3 --pmc passes against the bytes an update has to move (10.3 MB of ADAM + soft-update traffic
+        # + one pass over the four networks' weights)
+        upd_us = getattr(wl, "update_us", None)
+        if mode == "train" and upd_us and args.hidden.lower() == "250x500":
+            mflop = 2.565 * BATCH_FOR_UPDATE                 # 2.565 MFLOP x B
+            ur = {"update_us": upd_us, "launches": 5 if world == 1 else 7, "mflop": mflop, "achieved_tflops": mflop * 1e6 / (upd_us * 1e-6) / 1e12,
+                  "peak_tflops": 157.3, "frac": mflop * 1e6 / (upd_us * 1e-6) / 1e12 / 157.3, "bound": "latency (five dependent launches; MFMA nominally)",
+                  "algorithmic_bytes": UPDATE_ALGORITHMIC_BYTES, "counter_bytes": None, "counter_bytes_fetch_x2": None, "traffic_ratio": None,
+                  "traffic_source": None}
+            if os.path.exists(pmc):
+                urec = json.load(open(pmc)).get("update", {})
+                if urec:
+                    ur["counter_bytes"] = urec.get("bytes_as_read")
+                    ur["counter_bytes_fetch_x2"] = urec.get("bytes_fetch_x2")
+                    ur["traffic_ratio"] = [urec["bytes_as_read"] / UPDATE_ALGORITHMIC_BYTES, urec["bytes_fetch_x2"] / UPDATE_ALGORITHMIC_BYTES] if urec.get("bytes_as_read") else None
+                    ur["traffic_source"] = "profiles/pmc_traffic.json (static: FETCH_SIZE + WRITE_SIZE of k_fwd x2, k_mid, k_grad x2 per update, as read / with the guide's 2x FETCH correction, " + str(urec.get("round")) + ")"
+            roof["update_roofline"] = ur
         if world == 1 and not args.no_cpu_baseline and args.hidden.lower() == "250x500":      # (the CPU port is timed at the headline architecture)
             t_cpu0 = time.perf_counter()
             cpu = cpu_baseline(args.envs, "train" if mode == "group" else mode, args.learners if mode == "group" else args.updates)

@@ -347,12 +347,17 @@ int shems_dp_allreduce_sum(shems_dp *dp, float *d_buf, int64_t n, void *stream);
  * peer's inbox, stamps a per-slice epoch flag, waits (bounded) for the peers' slices and sums them in rank order -- no collective launch
  * ("direct one-shot ... over all 7 links").  world <= 8.  shems_dp_create_direct, then exchange the 128-byte handle
  * blocks by any means and shems_dp_direct_connect every peer on every rank BEFORE the first shems_ddpg_update_dp (a barrier of the
- * caller's).  shems_dp_direct_timeouts: waits that gave up since the last call (0 in every healthy run; read and cleared).  Validated
- * on ONE device only (two processes, tests/test_bench_gpu.py); never run across xGMI. */
+ * caller's).  A wait is bounded (shems_dp_direct_set_wait_ms, default 5 s).  A wait that gives up POISONS the record: that sweep and
+ * every sweep already enqueued behind it apply nothing, and every later shems_ddpg_update_dp / shems_train_steps on the record
+ * returns SHEMS_ERR_STATE -- a late peer makes the replicas fail loudly, it never lets them train on diverged
+ * (shems_dp_direct_poisoned reads the sticky word without synchronising; shems_dp_direct_timeouts counts the waits that gave up).
+ * Validated on ONE device only (two processes, tests/test_bench_gpu.py); never run across xGMI. */
 int shems_dp_create_direct(int rank, int world, shems_dp **out);
 int shems_dp_direct_handles(shems_dp *dp, char *out128);
 int shems_dp_direct_connect(shems_dp *dp, int peer, const char *handles128);
 int shems_dp_direct_timeouts(shems_dp *dp, int64_t *out, void *stream);
+int shems_dp_direct_set_wait_ms(shems_dp *dp, int64_t ms);
+int shems_dp_direct_poisoned(const shems_dp *dp, int32_t *out);
 /* replay() of one replica: shems_ddpg_critic_grad_ex, all-reduce(grad_critic), shems_ddpg_critic_apply(grad_scale = 1 / world),
  * shems_ddpg_actor_grad, all-reduce(grad_actor), shems_ddpg_actor_apply_pub -- everything in `stream`.  dp == NULL: a single replica in
  * the split form (the bytes of shems_ddpg_update). */

@@ -1048,6 +1048,12 @@ __global__ __launch_bounds__(256) void k_adam_xchg(AdamCtx c, XchgArgs x)
 {
     const int tid = threadIdx.x, wg = blockIdx.x, i0 = 4 * (wg * 256 + tid);
     const int par = (int)(x.epoch & 1ull);
+    // a record poisoned by an earlier exchange: this sweep is a no-op (nothing pushed, nothing waited for, nothing applied) -- the host
+    // answers every later call with SHEMS_ERR_STATE, and whatever was already enqueued drains without another bounded wait
+    __shared__ unsigned s_dead;
+    if (tid == 0) s_dead = __hip_atomic_load(x.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (s_dead) return;
     const bool full = i0 + 3 < c.n;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
     if (full) { const float4 v = *reinterpret_cast<const float4 *>(c.g + i0); g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w; }
@@ -1063,13 +1069,20 @@ __global__ __launch_bounds__(256) void k_adam_xchg(AdamCtx c, XchgArgs x)
     // wait: the same workgroup of every peer has pushed this epoch into MY inbox (bounded: a peer that never comes is counted, not waited for)
     if (tid < x.world && tid != x.rank) {
         const unsigned long long *f = x.flags[x.rank] + ((int64_t)par * x.world + tid) * kXchgWgs + wg;
-        unsigned spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x.epoch) {
-            if (++spins > (1u << 20)) { __hip_atomic_fetch_add(x.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(8);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > x.wait_ticks) {
+                // gave up: count it, and poison the record for good (host-visible at once; the replicas can no longer be trusted)
+                __hip_atomic_fetch_add(x.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(x.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s_dead = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
         }
     }
     __syncthreads();
+    if (s_dead) return;                                                // an incomplete sum is never applied
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     // sum in rank order
     float s4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1763,7 +1776,7 @@ int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, do
 {
     if (int rc = check_ddpg(d, "ddpg_apply_xchg")) return rc;
     if (int rc = check_adam(bp1, bp2, "ddpg_apply_xchg")) return rc;
-    if (x.world < 1 || x.world > kXchgMaxWorld || x.rank < 0 || x.rank >= x.world || x.epoch < 1 || !x.timeouts)
+    if (x.world < 1 || x.world > kXchgMaxWorld || x.rank < 0 || x.rank >= x.world || x.epoch < 1 || !x.timeouts || !x.poison || x.wait_ticks < 1)
         return set_error(SHEMS_ERR_ARG, "ddpg_apply_xchg: bad exchange record");
     static_assert(SHEMS_ACTOR_PARAMS <= kXchgNmax && SHEMS_CRITIC_PARAMS <= kXchgNmax, "inbox slot holds either gradient");
     const AdamCtx c = adam_ctx(d, critic, AdamScalars{eta, bp1, bp2, 1.0 / (double)x.world, d_publish});

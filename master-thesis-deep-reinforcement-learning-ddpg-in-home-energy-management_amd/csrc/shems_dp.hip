@@ -72,6 +72,9 @@ struct Direct {
     int connected = 0;                    // peers mapped so far
     unsigned long long epoch = 0;         // exchanges enqueued so far
     unsigned *timeouts = nullptr;         // device word
+    unsigned *poison_host = nullptr;      // pinned host word the kernels can store to: non-zero = a wait gave up (sticky, see shems_ddpg_update_dp)
+    unsigned *poison_dev = nullptr;       // the same word as the device addresses it
+    unsigned long long wait_ticks = 500000000ull;   // bound of one wait in s_memrealtime ticks (100 MHz): 5 s
     size_t inbox_bytes = 0, flags_bytes = 0;
 };
 
@@ -122,6 +125,7 @@ int shems_dp_destroy(shems_dp *dp)
         if (x->inbox[dp->rank]) (void)hipFree(x->inbox[dp->rank]);
         if (x->flags[dp->rank]) (void)hipFree(x->flags[dp->rank]);
         if (x->timeouts) (void)hipFree(x->timeouts);
+        if (x->poison_host) (void)hipHostFree(x->poison_host);
         delete x;
     }
     delete dp;
@@ -146,6 +150,9 @@ int shems_dp_create_direct(int rank, int world, shems_dp **out)
     if (!rc) rc = hip_ok(hipExtMallocWithFlags((void **)&x->inbox[rank], x->inbox_bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(inbox)");
     if (!rc) rc = hip_ok(hipExtMallocWithFlags((void **)&x->flags[rank], x->flags_bytes, hipDeviceMallocFinegrained), "hipExtMallocWithFlags(flags)");
     if (!rc) rc = hip_ok(hipMalloc((void **)&x->timeouts, sizeof(unsigned)), "hipMalloc(timeouts)");
+    // the poison word lives in pinned, coherent host memory: the sweep stores to it at system scope, the host reads it with a plain load
+    if (!rc) rc = hip_ok(hipHostMalloc((void **)&x->poison_host, sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(poison)");
+    if (!rc) { *x->poison_host = 0u; rc = hip_ok(hipHostGetDevicePointer((void **)&x->poison_dev, x->poison_host, 0), "hipHostGetDevicePointer(poison)"); }
     if (!rc) rc = hip_ok(hipMemset(x->inbox[rank], 0, x->inbox_bytes), "hipMemset(inbox)");
     if (!rc) rc = hip_ok(hipMemset(x->flags[rank], 0, x->flags_bytes), "hipMemset(flags)");
     if (!rc) rc = hip_ok(hipMemset(x->timeouts, 0, sizeof(unsigned)), "hipMemset(timeouts)");
@@ -197,6 +204,22 @@ int shems_dp_direct_timeouts(shems_dp *dp, int64_t *out, void *stream)
     return SHEMS_OK;
 }
 
+/* Bound of one exchange wait in milliseconds (default 5 000; 1 .. 600 000).  A wait that reaches it POISONS the record. */
+int shems_dp_direct_set_wait_ms(shems_dp *dp, int64_t ms)
+{
+    if (!dp || !dp->direct || ms < 1 || ms > 600000) return set_error(SHEMS_ERR_ARG, "shems_dp_direct_set_wait_ms: a direct-exchange record and 1..600000 ms");
+    dp->direct->wait_ticks = (unsigned long long)ms * 100000ull;        // s_memrealtime: 100 MHz
+    return SHEMS_OK;
+}
+
+/* 1 if an exchange wait of this record ever gave up (sticky; no synchronisation: the word is host memory the kernels store to). */
+int shems_dp_direct_poisoned(const shems_dp *dp, int32_t *out)
+{
+    if (!dp || !dp->direct || !out) return set_error(SHEMS_ERR_ARG, "shems_dp_direct_poisoned: not a direct-exchange record");
+    *out = *(volatile unsigned *)dp->direct->poison_host ? 1 : 0;
+    return SHEMS_OK;
+}
+
 int shems_dp_info(const shems_dp *dp, int *rank, int *world, char *lib, int32_t cap)
 {
     if (!dp) return set_error(SHEMS_ERR_ARG, "shems_dp_info: NULL");
@@ -220,14 +243,25 @@ int shems_ddpg_update_dp(const shems_ddpg *d, const shems_replay *ring, int64_t 
                          float *d_publish, shems_dp *dp, void *stream)
 {
     if (!d) return set_error(SHEMS_ERR_ARG, "shems_ddpg_update_dp: NULL");
+    // The split form below runs K2 WITH the actor's two E products: a caller's "leave them to shems_ddpg_actor_prepare" flag (the
+    // asynchronous torch.distributed form of replay()) must not reach it -- nobody here would ever issue them.
+    shems_ddpg dl = *d;
+    dl.flags &= ~SHEMS_DDPG_DEFER_ACTOR_E;
+    d = &dl;
     if (dp && dp->direct) {
         // direct exchange: the ADAM sweep of each network pushes / waits / sums in rank order (k_adam_xchg); two launches less than RCCL's form
         Direct *x = dp->direct;
         if (x->connected != dp->world - 1) return set_error(SHEMS_ERR_STATE, "shems_ddpg_update_dp: %d of %d peers connected", x->connected, dp->world - 1);
+        // Sticky: once a wait has given up (a peer never delivered within the bound), this replica has applied -- or skipped -- an
+        // incomplete sum and the replicas have diverged; every later call fails instead of training on.  The sweeps already enqueued
+        // see the same word and turn into no-ops (they neither push, wait nor apply), so the queue drains at once.
+        if (*(volatile unsigned *)x->poison_host)
+            return set_error(SHEMS_ERR_STATE, "shems_ddpg_update_dp: a gradient exchange wait gave up earlier (a peer did not deliver within %.1f s): "
+                             "the replicas have diverged -- this record is poisoned, restart the replicas from a common snapshot", (double)x->wait_ticks * 1e-8);
         XchgArgs a;
         std::memset(&a, 0, sizeof a);
         for (int q = 0; q < dp->world; ++q) { a.inbox[q] = x->inbox[q]; a.flags[q] = x->flags[q]; }
-        a.rank = dp->rank; a.world = dp->world; a.timeouts = x->timeouts;
+        a.rank = dp->rank; a.world = dp->world; a.timeouts = x->timeouts; a.poison = x->poison_dev; a.wait_ticks = x->wait_ticks;
         if (int rc = shems_ddpg_critic_grad_ex(d, ring, ring_len, seed, tick, excl_pos, excl_count, stream)) return rc;
         a.epoch = ++x->epoch;
         if (int rc = ddpg_apply_xchg(d, true, eta_crit, bp1_crit, bp2_crit, nullptr, a, (hipStream_t)stream)) return rc;

@@ -41,7 +41,7 @@ int64_t wide_act_part_offset(int l1, int64_t m);
 // Every rank owns an INBOX [2 parities][world][kXchgNmax] float32 and FLAGS [2][world][kXchgWgs] uint64 in fine-grained device memory that
 // every peer has mapped (hipIpcOpenMemHandle).  The ADAM sweep of an exchange (k_adam_xchg, one workgroup per 1 024 consecutive
 // parameters) PUSHES its range of the local gradient into slot [parity][my rank] of every peer's inbox, releases at system scope, stamps
-// the peers' flag [parity][my rank][workgroup] with the exchange's epoch, WAITS (bounded) for the same workgroup's flag from every peer
+// the peers' flag [parity][my rank][workgroup] with the exchange's epoch, WAITS (bounded: seconds; a wait that gives up POISONS the record, see XchgArgs::poison) for the same workgroup's flag from every peer
 // in its own flags, then sums the slots IN RANK ORDER (its own gradient in its own position: every replica adds the same numbers in the
 // same order, so the replicas stay bit-identical) and applies ADAM with grad_scale 1 / world.  No collective launch, no launch at all
 // beyond the sweep the data-parallel form has anyway.  Epochs count exchanges (critic, actor, critic, ...), parity = epoch & 1: a slot
@@ -56,6 +56,8 @@ struct XchgArgs {
     int rank, world;
     unsigned long long epoch;                         // this exchange (>= 1)
     unsigned *timeouts;                               // device word: waits that gave up
+    unsigned *poison;                                 // pinned host word (device address): set when a wait gives up, never cleared
+    unsigned long long wait_ticks;                    // bound of one wait, s_memrealtime ticks (100 MHz)
 };
 // ADAM + soft update of one network behind a direct exchange of its gradient (grad_scale 1 / world inside).
 int ddpg_apply_xchg(const shems_ddpg *d, bool critic, double eta, double bp1, double bp2, float *d_publish, const XchgArgs &x, hipStream_t st);

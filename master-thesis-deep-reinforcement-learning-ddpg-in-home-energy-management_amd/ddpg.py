@@ -858,6 +858,8 @@ class TrainWorkload:
             L.view = self.env.view()
             L.act = ag._act_params(True, 0)
             L.ddpg = ag._ddpg_args()
+            L.ddpg.flags = 0                     # the native data-parallel step runs both exchanges in program order: K2 keeps the actor's E
+                                                 # products (the DEFER_ACTOR_E form belongs to Agent.replay's asynchronous torch path only)
             L.ring = self.ring.struct()
             L.rewards_f32 = self.rew32.data_ptr()
             if self.overlap:
@@ -922,24 +924,46 @@ class TrainWorkload:
             self.torch.cuda.synchronize()
         if self._native is not None:
             _capi.check(self.agent.L.shems_train_loop_release(C.byref(self._native)))
+        # Every rank-local verdict is collected FIRST and exchanged in ONE collective together with the learner's checksum; only then does
+        # anybody raise -- a rank that sees an exchange timeout (normally only some do) must not leave its peers blocked in a collective.
+        problems = []
         if getattr(self.agent.sync, "direct", False):
             n = C.c_int64(0)
             self.agent.L.shems_dp_direct_timeouts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
             self.agent.L.shems_dp_direct_timeouts.restype = C.c_int
             _capi.check(self.agent.L.shems_dp_direct_timeouts(self.agent.sync.native, C.byref(n), self.agent._stream()))
-            if n.value:
-                raise RuntimeError(f"{n.value} waits of the direct gradient exchange gave up: a peer never delivered, the replicas have diverged")
-        self.env.check_error()
+            if n.value or self.dp_poisoned():
+                problems.append(f"{n.value} waits of the direct gradient exchange gave up: a peer never delivered, the replicas have diverged")
+        try:
+            self.env.check_error()
+        except Exception as e:                      # noqa: BLE001
+            problems.append(f"env error: {e}")
         if not bool(self.torch.isfinite(self.agent.actor).all()) or not bool(self.torch.isfinite(self.agent.critic).all()):
-            raise RuntimeError("non-finite network parameters after the timed steps")
+            problems.append("non-finite network parameters after the timed steps")
         # replicas: every rank's learner must hold the same bytes (they started identical and added the same gradients in the same order);
         # gathered here, where every rank passes, and reported by rank 0 (`replica_crc32_distinct`: 1 = identical)
         self.replica_crcs = None
         sync = self.agent.sync
         if sync.dist is not None:
-            crcs = [None] * sync.dist.get_world_size()
-            sync.dist.all_gather_object(crcs, self._learner_crc())
-            self.replica_crcs = crcs
+            got = [None] * sync.dist.get_world_size()
+            sync.dist.all_gather_object(got, (self._learner_crc(), problems))
+            self.replica_crcs = [g[0] for g in got]
+            for r, g in enumerate(got):
+                if r != sync.rank and g[1]:
+                    problems.append(f"rank {r}: " + "; ".join(g[1]))
+        if problems:
+            raise RuntimeError("; ".join(problems))
+
+    def dp_poisoned(self):
+        """True once a wait of the direct gradient exchange has given up on this rank (sticky; no synchronisation)."""
+        sync = self.agent.sync
+        if not getattr(sync, "direct", False) or sync.native is None:
+            return False
+        out = C.c_int32(0)
+        self.agent.L.shems_dp_direct_poisoned.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self.agent.L.shems_dp_direct_poisoned.restype = C.c_int
+        _capi.check(self.agent.L.shems_dp_direct_poisoned(sync.native, C.byref(out)))
+        return bool(out.value)
 
     def close(self):
         """End of the run: give the native communicator / the direct exchange's mappings back (every rank calls it; idempotent)."""
@@ -1063,7 +1087,7 @@ class TrainWorkload:
                 "replay_mode": "scaled (capacity 72 N, every env inserts)" if self.scaled_replay else "window (MEM_SIZE = 24 000, 333 envs insert per step)",
                 "overlap": {LOOP_ORDERED: False, LOOP_PIPELINED: "pipelined", LOOP_PIPELINED_EXACT: "exact"}[self.overlap_mode],
                 "loop": self.loop,
-                "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1),
+                "learner_crc32": crc, "dp_overlap": bool(self.agent.dp_overlap and self.agent.sync.world > 1 and self.loop != "native"),   # (the native loop exchanges in program order)
                 "dp_exchange": None if self.agent.sync.world == 1 else (
                     "direct exchange through peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg), no collective launch" if getattr(self.agent.sync, "direct", False) else
                     "RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)" if self.agent.sync.native is not None else

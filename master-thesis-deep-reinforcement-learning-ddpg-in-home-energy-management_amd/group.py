@@ -201,7 +201,7 @@ class GroupWorkload:
     dtype = "f32"
     EP_LEN = 72
 
-    def __init__(self, S, torch, n, learners, seed, mixed=False):
+    def __init__(self, S, torch, n, learners, seed, mixed=False, form=None):
         self.S, self.torch, self.n, self.count = S, torch, int(n), int(learners)
         if self.n % self.count or (self.n // self.count) % 128:
             raise ValueError("--envs must be learners x a multiple of 128")
@@ -218,7 +218,7 @@ class GroupWorkload:
             self.env = S.ShemsBatch(self.n, self.EP_LEN, [self.tab], [S.make_config(98, 0, self.tab.shape[0])],
                                     device=torch.cuda.current_device()).use_torch_stream()
         self.env_seed = int(seed)
-        self.group = LearnerGroup(self.count, E, seed=1231, rng_seed=self.env_seed)
+        self.group = LearnerGroup(self.count, E, seed=1231, rng_seed=self.env_seed, form=form)
         self.group.populate_memory(self.env, seed=self.env_seed)
         self.group.min_max_buffer()
         self.win = min(E, MEM_SIZE // self.EP_LEN)
@@ -259,10 +259,28 @@ class GroupWorkload:
         torch.cuda.synchronize()
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
-        return dict(kernel=act_kernel_name(self.n, grouped=True), avg_us=avg_us, median_us=med_us, launches=reps,
-                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
+        act = dict(kernel=act_kernel_name(self.n, grouped=True), avg_us=avg_us, median_us=med_us, launches=reps,
+                   bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
+        if self.update_us <= avg_us:
+            return act
+        # the grouped replay() is the larger share of the step: it is the kernel the roofline object describes.
+        # Work per learner-update: 2.565 MFLOP x B = 307.8 MFLOP, and 12.4 MB that have to move (258 003 parameters x
+        # (28 B ADAM + 12 B soft update) + one pass over the four networks' weights) -- at 400 learners 0.78 ms at the fp32-MFMA peak and
+        # 0.62 ms at 8 TB/s: the matrix pipe is the binding roof, HBM within 25 % of it.
+        upd_bytes = 258003 * 40 + 2 * 4 * (129002 + 129001)
+        tp = g.form == "throughput"
+        name = ("grouped replay(), throughput form: k_tp_prep + k_tp_fwd x3 + k_tp_d1 x2 + k_tp_gw2 x2 (csrc/shems_gupd.hip)" if tp else
+                "grouped replay(), latency form: k_fwd x2 + k_mid + k_grad x2 with grid z = learner (csrc/shems_ddpg.hip)")
+        t_s = self.update_us * 1e-6
+        return dict(kernel=name, avg_us=self.update_us, median_us=self.update_us, launches=nup, bound="mfma",
+                    algorithmic=2.565e6 * BATCH_SIZE * self.count, unit="TFLOP/s", peak=157.3,
+                    algorithmic_bytes=upd_bytes * self.count, algorithmic_gbs=upd_bytes * self.count / t_s / 1e9,
+                    hbm_frac_of_8tbs=upd_bytes * self.count / t_s / 8e12, per_learner_update_us=self.update_us / self.count,
+                    launches_per_update=8 if tp else 5,
+                    other_kernel={"kernel": act["kernel"], "avg_us": avg_us, "frac": flops / (avg_us * 1e-6) / 1e12 / 157.3},
+                    method=f"HIP events around {nup} grouped replay() calls back to back ({8 if tp else 5} launches each, all learners per launch)")
 
     def extra(self):
         return {"learners": self.count, "envs_per_learner": self.n // self.count, "updates_per_step": self.count,
                 "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "replay_window_envs_per_step": self.win,
-                "group_update_us": getattr(self, "update_us", None), "update_mflop": 307.8}
+                "group_update_us": getattr(self, "update_us", None), "update_mflop": 307.8, "update_form": self.group.form}

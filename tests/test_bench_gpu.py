@@ -41,6 +41,14 @@ def test_bench_json_contract_small():
     assert 0.7 * r["kernel_avg_us"] < r["kernel_back_to_back_us"] < 1.5 * r["kernel_avg_us"]      # the direct timing agrees with the difference
     assert d["gpu_section_s"] > 0 and d["roofline_pass_s"] > 0 and d["cpu_baseline_s"] == 0.0
     assert d["overlap"] is False and d["loop"] == "native"
+    # round 5: every dominant kernel group is on the line -- the direct timing's fraction next to the in-loop one, and the learner's
+    # update with its own (latency-bound, tiny) MFMA fraction and bytes: 307.8 MFLOP, 12.4 MB algorithmic, counter bytes where committed
+    assert abs(r["frac_back_to_back"] - r["algorithmic_per_launch"] / (r["kernel_back_to_back_us"] * 1e-6) / 1e12 / 157.3) < 1e-9
+    u = r["update_roofline"]
+    assert abs(u["update_us"] - d["update_us"]) < 1e-9 and u["launches"] == 5 and abs(u["mflop"] - 307.8) < 1e-9
+    assert abs(u["frac"] - 307.8e6 / (u["update_us"] * 1e-6) / 1e12 / 157.3) < 1e-9 and 0.01 < u["frac"] < 0.2
+    assert u["algorithmic_bytes"] == 258003 * 40 + 8 * 258003
+    assert u["counter_bytes"] is None or (u["counter_bytes"] > u["algorithmic_bytes"] and len(u["traffic_ratio"]) == 2)
 
 
 def test_bench_kernel_name_follows_the_dispatcher():
@@ -71,6 +79,20 @@ def test_bench_group_mode_with_charger_grid():
               "--no-cpu-baseline"])
     assert d["config"]["mode"] == "group" and d["learners"] == 16 and d["envs_per_learner"] == 512
     assert d["updates_per_sec"] > 16 * 100 and d["value"] > 1e6
+    # the roofline object describes the DOMINANT kernel of the step: the grouped replay() when it is the larger share
+    assert d["update_form"] == "throughput"
+    r = d["roofline"]
+    if d["group_update_us"] > r.get("other_kernel", {}).get("avg_us", float("inf")):
+        assert r["kernel"].startswith("grouped replay(), throughput form") and r["launches_per_update"] == 8
+        assert abs(r["kernel_avg_us"] - d["group_update_us"]) < 1e-6 and abs(r["per_learner_update_us"] - d["group_update_us"] / 16) < 1e-9
+        assert abs(r["frac"] - 16 * 307.8e6 / (d["group_update_us"] * 1e-6) / 1e12 / 157.3) < 1e-9
+        assert r["algorithmic_bytes"] == 16 * (258003 * 40 + 8 * 258003) and r["hbm_frac_of_8tbs"] > 0
+        assert r["other_kernel"]["kernel"].startswith("shems::k_act")
+    else:
+        assert r["kernel"].startswith("shems::k_act")
+    dl = _run([sys.executable, "bench.py", "--mode", "group", "--learners", "16", "--envs", "8192", "--steps", "12", "--warmup", "2",
+               "--no-cpu-baseline", "--group-form", "latency"])
+    assert dl["update_form"] == "latency"
 
 
 def test_two_rank_data_parallel_rehearsal():
@@ -157,11 +179,45 @@ def test_direct_gradient_exchange_two_ranks_on_one_device():
     assert out["torch"]["dp_exchange"].startswith("torch.distributed") and out["torch"]["loop"] == "host"
     assert out["direct"]["learner_crc32"] == out["torch"]["learner_crc32"], (out["direct"]["learner_crc32"], out["torch"]["learner_crc32"])
     assert out["direct"]["replica_crc32_distinct"] == 1 and out["torch"]["replica_crc32_distinct"] == 1
+    # with SHEMS_DP_OVERLAP=1 Agent._ddpg_args() sets DEFER_ACTOR_E (K2 leaves the actor's E products to
+    # shems_ddpg_actor_prepare).  The native data-parallel step never issues that call: the flag must not reach it (shems_ddpg_update_dp
+    # clears it on its copy, the native loop's record carries flags = 0) -- same bytes as the torch path, and the line says program order.
+    dov = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "48", "--warmup", "6", "--envs", "4096", "--prewarm-s", "0"],
+               env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP": "direct", "SHEMS_DP_OVERLAP": "1"})
+    assert dov["loop"] == "native" and dov["dp_overlap"] is False and dov["learner_crc32"] == out["torch"]["learner_crc32"]
     # four replicas (four rank processes on the one device): the rank-order sum of four gradients is no longer gloo's order, so only the
     # replicas are held to each other -- all four learners bit-identical after 54 exchanged updates, no wait gave up
     d4 = _run([sys.executable, "bench.py", "--gpus", "4", "--steps", "48", "--warmup", "6", "--envs", "2048", "--prewarm-s", "0"],
               env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP": "direct"})
     assert d4["n_gpus"] == 4 and d4["dp_exchange"].startswith("direct exchange") and d4["replica_crc32_distinct"] == 1
+
+
+def test_direct_exchange_late_peer_waits_or_fails_loudly_on_every_rank():
+    """a peer that is late must not produce silently diverged replicas.  tests/dp_direct_late_peer.py: two rank
+    processes on device 0, rank 1 stalls on the host in the middle of the run.  (a) the stall (1 s) is shorter than the wait bound
+    (5 s, the default): rank 0's sweeps wait in the kernel, both ranks finish with the SAME learner bytes.  (b) the stall (2 s) is
+    longer than the bound (set to 300 ms): rank 0's wait gives up and poisons its record -- its enqueued sweeps apply nothing, its next
+    call returns SHEMS_ERR_STATE -- and rank 1, whose next exchange never gets rank 0's slice, ends the same way: BOTH ranks fail.
+    The script exits non-zero for any third outcome (one rank finishing, different checksums)."""
+    script = os.path.join(U.ROOT, "tests", "dp_direct_late_peer.py")
+    a = subprocess.run([sys.executable, script, "5000", "1.0"], cwd=U.ROOT, capture_output=True, text=True, timeout=400)
+    assert a.returncode == 0 and "LATE ok" in a.stdout, (a.stdout[-500:], a.stderr[-1500:])
+    crcs = a.stdout.split("LATE ok")[1].split()
+    assert crcs[0] == crcs[1]
+    b = subprocess.run([sys.executable, script, "300", "2.0"], cwd=U.ROOT, capture_output=True, text=True, timeout=400)
+    assert b.returncode == 0 and "LATE poisoned" in b.stdout, (b.stdout[-500:], b.stderr[-1500:])
+
+
+def test_driver_command_rehearsal_at_the_widest_world_one_box_allows():
+    """The driver's multi-GPU call is `python bench.py --gpus N --steps K --warmup W` (BASELINE config 4: N = 8, --envs 8192).  A one-GPU box
+    admits at most six processes on the card at once (this pytest process is one of them), so the rehearsal inside the suite is N = 4
+    rank processes on device 0 over gloo; the N = 6 run of the same command outside pytest is profiles/r05_dp_world6_rehearsal.json.
+    Every data-parallel field, one census entry per rank, replicas identical."""
+    d = _run([sys.executable, "bench.py", "--gpus", "4", "--envs", "8192", "--steps", "20", "--warmup", "5", "--prewarm-s", "0"],
+             env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 4 and d["config"]["envs_per_gpu"] == 8192 and len(d["rank_census"]) == 4
+    assert abs(d["value"] - 4 * 8192 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-3 * d["value"]      # whole-job aggregate
+    _check_data_parallel_fields(d, 4)
 
 
 def test_rccl_stream_ordering_on_a_one_rank_group():

@@ -59,7 +59,19 @@ def main():
                          "width, so 2x is an upper bound for the read side.",
            "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline",
                         "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline"]}
-    json.dump({"train": rec, "policy": rec}, open(os.path.join(outdir, "pmc_traffic.json"), "w"), indent=1)
+    # the learner's update (train mode, one replica): k_fwd x2 + k_mid + k_grad x2 per replay()
+    def mean(name, ctr):
+        v = [x for (k, c), vals in rows if c == ctr and name in k for x in vals]
+        return sum(v) / len(v) if v else None
+    upd = None
+    f = {n: mean(n, "FETCH_SIZE") for n in ("k_fwd(", "k_mid(", "k_grad(")}
+    w = {n: mean(n, "WRITE_SIZE") for n in ("k_fwd(", "k_mid(", "k_grad(")}
+    if all(v is not None for v in list(f.values()) + list(w.values())):
+        fetch_kb = 2 * f["k_fwd("] + f["k_mid("] + 2 * f["k_grad("]
+        write_kb = 2 * w["k_fwd("] + w["k_mid("] + 2 * w["k_grad("]
+        upd = {"round": tag, "launches": "k_fwd x2 + k_mid + k_grad x2", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+               "bytes_as_read": (fetch_kb + write_kb) * 1024.0, "bytes_fetch_x2": (2.0 * fetch_kb + write_kb) * 1024.0}
+    json.dump({"train": rec, "policy": rec, "update": upd}, open(os.path.join(outdir, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps({"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "dispatches": len(fetch)}))
 
 
