@@ -120,52 +120,62 @@ __device__ __forceinline__ void gshift(shems_replay &r, int64_t off)
     r.s = gsh(r.s, off); r.a = gsh(r.a, off); r.r = gsh(r.r, off); r.s2 = gsh(r.s2, off); r.done = gsh(r.done, off);
 }
 
-__global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A)
+// grid (5, learners): workgroup 0 samples / gathers / normalises and freezes the output layers, workgroups 1..4 pack one network's
+// frozen layer-1 image each (one launch of 2 000 short workgroups instead of 400 long ones: 49 -> ~10 us at 400 learners)
+__device__ __forceinline__ void prep_body(const PrepArgs &A, const int role, const int l)
 {
-    const int l = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int64_t off = (int64_t)l * A.gstride;
     shems_ddpg d = A.d;
     shems_replay ring = A.ring;
     gshift(d, off); gshift(ring, off);
-    const uint64_t seed = A.seed + (uint64_t)l;               // learner l: Philox key seed + l (as the latency form)
     float *ws = d.ws;
+    if (role > 0) {
+        const int net = role - 1;
+        const float *P = net == NET_ACTOR_T ? d.actor_t : net == NET_CRITIC_T ? d.critic_t : net == NET_CRITIC ? d.critic : d.actor;
+        const int in = (net == NET_CRITIC_T || net == NET_CRITIC) ? CIN : SIN;
+        float *img = w1i_of(ws, net);
+        const int k = min(tid, H1N - 1);
+        float v[W1K];
+#pragma unroll
+        for (int j = 0; j < W1K; ++j) v[j] = P[(j == W1K - 1 ? in : min(j, in - 1)) * H1N + k];       // clamped, all twelve loads in flight
+#pragma unroll
+        for (int j = 0; j < W1K; ++j) img[j * W1C + tid] = ((j < in || j == W1K - 1) && tid < H1N) ? v[j] : 0.0f;
+        return;
+    }
+    const uint64_t seed = A.seed + (uint64_t)l;               // learner l: Philox key seed + l (as the latency form)
     if (tid < BP) {
         const int m = tid;
         const u32x4 x = philox4x32_10((uint32_t)(m >> 2), 0u, A.tick, kStreamSample, (uint32_t)seed, (uint32_t)(seed >> 32));
         const uint32_t w = (m & 3) == 0 ? x.x : (m & 3) == 1 ? x.y : (m & 3) == 2 ? x.z : x.w;
         const int64_t j = (int64_t)(w % (uint32_t)A.ring_len);
         const bool live = m < d.batch;
+        float sv[SIN], s2v[SIN], lo[SIN], hi[SIN];
+#pragma unroll
+        for (int k = 0; k < SIN; ++k) { sv[k] = ring.s[j * SIN + k]; s2v[k] = ring.s2[j * SIN + k]; lo[k] = d.s_min[k]; hi[k] = d.s_max[k]; }
+        const float a0 = ring.a[j * 2], a1 = ring.a[j * 2 + 1], rr = ring.r[j];
+        const bool dn = ring.done[j] != 0;
 #pragma unroll
         for (int k = 0; k < SIN; ++k) {
-            const float lo = d.s_min[k], den = (d.s_max[k] - lo) + 1e-8f;                 // MPS:56
-            ws[TP_X + k * BP + m] = live ? (ring.s[j * SIN + k] - lo) / den : 0.0f;
-            ws[TP_X2 + k * BP + m] = live ? (ring.s2[j * SIN + k] - lo) / den : 0.0f;
+            const float den = (hi[k] - lo[k]) + 1e-8f;                                     // MPS:56
+            ws[TP_X + k * BP + m] = live ? (sv[k] - lo[k]) / den : 0.0f;
+            ws[TP_X2 + k * BP + m] = live ? (s2v[k] - lo[k]) / den : 0.0f;
         }
-        ws[TP_X + 9 * BP + m] = live ? ring.a[j * 2] : 0.0f;
-        ws[TP_X + 10 * BP + m] = live ? ring.a[j * 2 + 1] : 0.0f;
+        ws[TP_X + 9 * BP + m] = live ? a0 : 0.0f;
+        ws[TP_X + 10 * BP + m] = live ? a1 : 0.0f;
         ws[TP_X + 11 * BP + m] = 1.0f;
         ws[TP_X2 + 9 * BP + m] = 0.0f; ws[TP_X2 + 10 * BP + m] = 0.0f; ws[TP_X2 + 11 * BP + m] = 1.0f;
-        ws[TP_R + m] = live ? ring.r[j] : 0.0f;
-        ws[TP_DONE + m] = live ? (ring.done[j] ? 1.0f : 0.0f) : 0.0f;
+        ws[TP_R + m] = live ? rr : 0.0f;
+        ws[TP_DONE + m] = live && dn ? 1.0f : 0.0f;
         reinterpret_cast<int32_t *>(ws + TP_IDX)[m] = live ? (int32_t)j : -1;
     }
-    // frozen layer-1 images of the four networks
-#pragma unroll
-    for (int net = 0; net < 4; ++net) {
-        const float *P = net == NET_ACTOR_T ? d.actor_t : net == NET_CRITIC_T ? d.critic_t : net == NET_CRITIC ? d.critic : d.actor;
-        const int in = (net == NET_CRITIC_T || net == NET_CRITIC) ? CIN : SIN;
-        float *img = w1i_of(ws, net);
-        for (int e = tid; e < W1K * W1C; e += 256) {
-            const int j = e >> 8, k = e & 255;
-            const bool used = k < H1N && (j < in || j == W1K - 1);
-            img[e] = used ? P[(j == W1K - 1 ? in : j) * H1N + k] : 0.0f;
-        }
-    }
     // frozen output layers
-    for (int e = tid; e < 1024; e += 256) {
-        const int n = e >> 1, o = e & 1;
-        ws[TP_FW3C + e] = (n < H2N && o == 0) ? d.critic[off_w3(CIN) + n] : 0.0f;
-        ws[TP_FW3A + e] = n < H2N ? d.actor[off_w3(SIN) + e] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = it * 256 + tid, n = e >> 1, o = e & 1;
+        const float wc = d.critic[off_w3(CIN) + min(n, H2N - 1)], wa = d.actor[off_w3(SIN) + min(e, 2 * H2N - 1)];
+        ws[TP_FW3C + e] = (n < H2N && o == 0) ? wc : 0.0f;
+        ws[TP_FW3A + e] = n < H2N ? wa : 0.0f;
     }
     if (tid < 8)
         ws[TP_FB3 + tid] = tid == 0 ? d.critic[off_b3(CIN, 1)] : tid == 1 ? d.critic_t[off_b3(CIN, 1)]
@@ -196,25 +206,27 @@ __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
     J.api = gsh(J.api, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off); J.DAP = gsh(J.DAP, off);
 }
 
-// W2 chunk c of an n-tile: rows k = 32 c .. 32 c + 31, columns n0 .. n0 + 63 (256 B per row), two float4 per thread.  Rows >= 250 are
+// W2 chunk c of an n-tile of NTL MFMA tiles (64 or 128 columns): rows k = 32 c .. 32 c + 31, columns n0 .. (256 / 512 B per row), NTL float4
+// per thread.  Rows >= 250 are
 // copies of row 249 (clamped address): they only meet layer-1 activations that are exactly zero (the image has no columns >= 250)
 // or output rows whose relu mask is off.  Columns >= 500 of the last tile read on into the next row / b2 (inside the parameter
 // block) and only feed outputs that are discarded.
-__device__ __forceinline__ void fwd_chunk_load(const float *__restrict__ W2, int n0, int c, f32x4 (&v)[2])
+template <int NTL>
+__device__ __forceinline__ void fwd_chunk_load(const float *__restrict__ W2, int n0, int c, f32x4 (&v)[NTL])
 {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int e = it * 256 + (int)threadIdx.x, k = min(32 * c + (e >> 4), H1N - 1);
-        v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + n0 + 4 * (e & 15));
+    for (int it = 0; it < NTL; ++it) {
+        const int e = it * 256 + (int)threadIdx.x, k = min(32 * c + e / (8 * NTL), H1N - 1);
+        v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + n0 + 4 * (e % (8 * NTL)));
     }
 }
-template <int S>
-__device__ __forceinline__ void fwd_chunk_store(float *buf, const f32x4 (&v)[2])
+template <int S, int NTL>
+__device__ __forceinline__ void fwd_chunk_store(float *buf, const f32x4 (&v)[NTL])
 {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NTL; ++it) {
         const int e = it * 256 + (int)threadIdx.x;
-        float *p = buf + (e >> 4) * S + 4 * (e & 15);
+        float *p = buf + (e / (8 * NTL)) * S + 4 * (e % (8 * NTL));
         if constexpr (S % 4 == 0) *reinterpret_cast<f32x4 *>(p) = v[it];
         else { p[0] = v[it][0]; p[1] = v[it][1]; p[2] = v[it][2]; p[3] = v[it][3]; }
     }
@@ -234,30 +246,34 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1s, int c, const float (
     return t;
 }
 
+// NTL = MFMA tiles per wave along n: the plain forward passes take 4 (a 128-wide n-tile: layer 1 is recomputed per n-tile -- 6 MFMAs per
+// chunk beside 64 instead of beside 32), the pass with the input gradient 2 (its second sweep holds 16 more accumulators).
 template <bool QG> struct FwdShape {
-    static constexpr int S = QG ? 65 : 64;         // chunk row stride: the backward pass reads the chunk along n (odd stride: conflict free)
-    static constexpr int LDS = (W1K * W1C + 64 * 4 + 2 * 32 * S) * 4;
+    static constexpr int NTL = QG ? 2 : 4;
+    static constexpr int NW = 32 * NTL;            // n-tile width
+    static constexpr int TILES = 512 / NW;         // n-tiles per network
+    static constexpr int S = QG ? NW + 1 : NW;     // chunk row stride: the backward pass reads the chunk along n (odd stride: conflict free)
+    static constexpr int LDS = (W1K * W1C + NW * 4 + 2 * 32 * S) * 4;
 };
 
 template <bool QG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tp_fwd(FwdArgs A)
+__device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const int by, float *smem)
 {
     typedef FwdShape<QG> SH;
-    constexpr int S = SH::S;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int S = SH::S, NTL = SH::NTL, NW = SH::NW;
     float *w1s = smem;                           // [12][256]
-    float *ep = w1s + W1K * W1C;                 // [64][4]: b2, W3[.][0], W3[.][1], valid
-    float *ring = ep + 64 * 4;                   // [2][32][S]
+    float *ep = w1s + W1K * W1C;                 // [NW][4]: b2, W3[.][0], W3[.][1], valid
+    float *ring = ep + NW * 4;                   // [2][32][S]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int job = (int)blockIdx.x / NT, nt = (int)blockIdx.x % NT, n0 = 64 * nt;
+    const int job = bx / SH::TILES, nt = bx % SH::TILES, n0 = NW * nt;
     FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];
-    gshift(J, (int64_t)blockIdx.y * A.gstride);
+    gshift(J, (int64_t)by * A.gstride);
     const float *__restrict__ P = J.P;
     const float *__restrict__ W2 = P + off_w2(J.in);
     const int m = 32 * w + li;
 
-    f32x4 pv[2];
-    fwd_chunk_load(W2, n0, 0, pv);
+    f32x4 pv[NTL];
+    fwd_chunk_load<NTL>(W2, n0, 0, pv);
     // layer-1 image -> LDS
     if (J.w1i) {
         const f32x4 *g4 = reinterpret_cast<const f32x4 *>(J.w1i) + tid;
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < W1K; ++j) w1s[j * W1C + tid] = ((j < J.in || j == W1K - 1) && tid < H1N) ? v[j] : 0.0f;
     }
-    if (tid < 64) {
+    if (tid < NW) {
         const int n = n0 + tid, nc = min(n, H2N - 1);
         const float valid = n < H2N ? 1.0f : 0.0f;
         const float b2 = P[off_b2(J.in) + nc], w30 = P[off_w3(J.in) + nc * J.out], w31 = J.out == 2 ? P[off_w3(J.in) + nc * 2 + 1] : 0.0f;
@@ -290,12 +306,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (lh == 1) xreg[4] = a0; else xreg[5] = a1;          // row 9 = (s 4, lh 1), row 10 = (s 5, lh 0)
         if (J.api && nt == 0) J.api[lh * BP + m] = lh ? a1 : a0;
     }
-    fwd_chunk_store<S>(ring, pv);
+    fwd_chunk_store<S, NTL>(ring, pv);
     __syncthreads();
 
-    f32x16 acc[2];
+    f32x16 acc[NTL];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < NTL; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
     float da0 = 0.0f, da1 = 0.0f;
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int c = it & 7;
             const float *buf = ring + (it & 1) * 32 * S;
             const bool more = wrap || c < 7;
-            if (more) fwd_chunk_load(W2, n0, (it + 1) & 7, pv);
+            if (more) fwd_chunk_load<NTL>(W2, n0, (it + 1) & 7, pv);
             const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
             if constexpr (!BWD) {
                 // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers
@@ -317,8 +333,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float b = fmaxf(t[r], 0.0f);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S], b, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S + 32], b, acc[1], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < NTL; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S + 32 * tt], b, acc[tt], 0, 0, 0);
                 }
             } else {
                 // backward through this n-tile: D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m], rows k = 32 c .. + 31; M = acc (see below)
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int r = 0; r < 16; ++r) g[r] = 0.0f;
                 const float *pa = buf + li * S + 4 * lh;
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < NTL; ++tt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[32 * tt + (r & 3) + 8 * (r >> 2)], acc[tt][r], g, 0, 0, 0);
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     da1 = fmaf(pw[W1C + (r & 3) + 8 * (r >> 2)], v, da1);
                 }
             }
-            if (more) fwd_chunk_store<S>(ring + ((it + 1) & 1) * 32 * S, pv);
+            if (more) fwd_chunk_store<S, NTL>(ring + ((it + 1) & 1) * 32 * S, pv);
             __syncthreads();
         }
     };
@@ -347,24 +364,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // epilogue of the forward pass: bias, relu, store, layer-3 partials; QG: M[n][m] = d3q[m] W3[n] (h2 > 0) replaces acc
     auto epilogue = [&](auto keep) {
         constexpr bool KEEP = decltype(keep)::value;
-        float p0 = 0.0f, p1 = 0.0f;
         const float *epl = ep + 16 * lh;
         float *hp = J.H2 + (n0 + 4 * lh) * BP + m;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int hf = 0; hf < NTL / 2; ++hf) {                                  // one pair of layer-3 partials per 64 columns: the consumers add
+            float p0 = 0.0f, p1 = 0.0f;                                         // NT = 8 of them whatever the tile width
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nb = 32 * tt + (r & 3) + 8 * (r >> 2);              // + 4 lh = the tile row
-                const f32x4 e = *reinterpret_cast<const f32x4 *>(epl + nb * 4);
-                const float h = fmaxf(acc[tt][r] + e[0], 0.0f) * e[3];
-                if constexpr (KEEP) hp[nb * BP] = h;
-                p0 = fmaf(h, e[1], p0);
-                p1 = fmaf(h, e[2], p1);
-                if (QG) acc[tt][r] = h > 0.0f ? e[1] * d3q : 0.0f;
-            }
-        p0 += __shfl_xor(p0, 32, 64);
-        p1 += __shfl_xor(p1, 32, 64);
-        if (lh == 0) { J.P3[(nt * 2 + 0) * BP + m] = p0; J.P3[(nt * 2 + 1) * BP + m] = p1; }
+            for (int th = 0; th < 2; ++th)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tt = 2 * hf + th;
+                    const int nb = 32 * tt + (r & 3) + 8 * (r >> 2);          // + 4 lh = the tile row
+                    const f32x4 e = *reinterpret_cast<const f32x4 *>(epl + nb * 4);
+                    const float h = fmaxf(acc[tt][r] + e[0], 0.0f) * e[3];
+                    if constexpr (KEEP) hp[nb * BP] = h;
+                    p0 = fmaf(h, e[1], p0);
+                    p1 = fmaf(h, e[2], p1);
+                    if (QG) acc[tt][r] = h > 0.0f ? e[1] * d3q : 0.0f;
+                }
+            p0 += __shfl_xor(p0, 32, 64);
+            p1 += __shfl_xor(p1, 32, 64);
+            const int slot = (NTL / 2) * nt + hf;
+            if (lh == 0) { J.P3[(slot * 2 + 0) * BP + m] = p0; J.P3[(slot * 2 + 1) * BP + m] = p1; }
+        }
     };
     if (J.H2) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if constexpr (QG) pass(std::true_type{}, 8, false);
@@ -465,18 +487,17 @@ constexpr int D1_LDS = (2 * 64 * D1_S + 1024 + 2 * BP + 8) * 4;
 static_assert(2 * 64 * D1_S >= 4 * 2 * 8 * 64, "the ring holds the four waves' gW1 partials");
 
 template <int IN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
+__device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const int by, float *smem)
 {
     typedef NetOf<IN> N;
     constexpr int OUT = N::OUT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem;                          // [2][64 k][33]
     float *w3s = ring + 2 * 64 * D1_S;           // [512][2] frozen W3
     float *d3s = w3s + 1024;                     // [2][BP]
     float *red = d3s + 2 * BP;                   // [8]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int kt = blockIdx.x, k0 = 64 * kt;
-    const int64_t off = (int64_t)blockIdx.y * A.gstride;
+    const int kt = bx, k0 = 64 * kt;
+    const int64_t off = (int64_t)by * A.gstride;
     shems_ddpg d = A.d;
     AdamCtx c = A.c;
     gshift(d, off); gshift(c, off);
@@ -593,27 +614,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 }
 
 // ================================================================================================================================
-// P4 / P7: gW2[k][n] = sum_m h1[k][m] D2[n][m] for one 64 x 64 tile, ADAM + soft target update by the lane that holds the element;
-// the k-tile-0 workgroups also finish gb2[n] = sum_m D2[n][m] and gW3[n][o] = sum_m h2[n][m] d3[o][m] of their n-tile.
-// h1' (samples x units) is recomputed on the matrix pipe per 32-sample block -- its D layout is the A operand; D2 goes through LDS.
+// P4 / P7: gW2[k][n] = sum_m h1[k][m] D2[n][m] for one 64 x 64 tile, ADAM + soft target update on it; the k-tile-0 workgroups also
+// finish gb2[n] = sum_m D2[n][m] and gW3[n][o] = sum_m h2[n][m] d3[o][m] of their n-tile.  h1' (samples x units) is recomputed on the
+// matrix pipe per 32-sample block -- its D layout is the A operand; D2 goes through LDS.
+// This phase is the update's HBM stream: 32 B in and out per parameter of W2 (moments, parameter, target) against 64 FLOP.  What it
+// reaches depends on how the four arrays are touched and on how many bytes a CU keeps in flight (measured with the matrix work switched
+// off, 400 learners, 1.65 GB per launch; profiles/r05_gw2_stream_forms.txt): 4-byte accesses in the accumulator's layout (128-byte row
+// pieces) 3.85 TB/s; 16-byte accesses in row-major order of the tile, 256-byte pieces 4.1 TB/s, 1 KB pieces 4.7 TB/s = the rate of a
+// plain elementwise ADAM sweep (a device copy of the same bytes: 5.5 TB/s) -- but only with ~256 KB in flight per CU: a 32 x 256 tile
+// whose state is requested in quarters (to fit the registers beside the product) fell to 1.9 TB/s.  So: the whole tile's state is
+// requested FIRST, 16 bytes per lane in row-major order (thread -> four consecutive columns of one row), the product runs under those
+// loads, and the finished tile changes hands through LDS (accumulator layout -> rows) before ADAM.
 // ================================================================================================================================
 constexpr int GW_S = BP + 1;
+constexpr int GW_TS = 68;          // row stride of the row-major copy of the finished tile [64 k][68] (over the D2 panel)
+constexpr int GW_WGS = 4 * NT;     // k-tiles x n-tiles of 64 per learner
 constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3) * 4;
+static_assert(64 * GW_TS <= 64 * GW_S, "the row-major copy of a tile fits the D2 panel it replaces");
 
 template <int IN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
+__device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const int by, float *smem)
 {
     typedef NetOf<IN> N;
     constexpr int OUT = N::OUT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *d2s = smem;                           // [64 n][129]
+    float *d2s = smem;                           // [64 n][129]; later the tile [64 k][68]
     float *d3s = d2s + 64 * GW_S;                // [2][BP]
     float *w3s = d3s + 2 * BP;                   // [64][2]
     float *rs = w3s + 64 * 2;                    // [64][3] row sums: gb2, gW3[.][0], gW3[.][1]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int nt = (int)blockIdx.x & 7, kt = (int)blockIdx.x >> 3, n0 = 64 * nt, k0 = 64 * kt;
+    const int nt = bx & 7, kt = bx >> 3, n0 = 64 * nt, k0 = 64 * kt;
     const int kw = w >> 1, nw = w & 1;
-    const int64_t off = (int64_t)blockIdx.y * A.gstride;
+    const int64_t off = (int64_t)by * A.gstride;
     shems_ddpg d = A.d;
     AdamCtx c = A.c;
     gshift(d, off); gshift(c, off);
@@ -621,10 +652,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const float *__restrict__ H2 = N::H2(ws);
     const bool store_grad = A.store_grad != 0;
 
-    // this lane's 16 elements of the tile: (k = k0 + 32 kw + drow(r, lh), n = n0 + 32 nw + li); their moments / parameter / target are
-    // requested right before the product (below) and consumed after it
-    const int nn = n0 + 32 * nw + li;
-    const int kb = k0 + 32 * kw + 4 * lh;
+    // this thread's 16 elements of the tile, row-major: float4 it = row 16 it + (tid >> 4), columns 4 (tid & 15) .. + 3
+    int eidx[4];
+    f32x4 am[4], av[4], ap[4], at[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = k0 + 16 * it + (tid >> 4), n = n0 + 4 * (tid & 15);
+        eidx[it] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;          // (500 is a multiple of 4: a float4 is all in or all out)
+        const int e = off_w2(IN) + min(k, H1N - 1) * H2N + min(n, H2N - 4);
+        am[it] = *reinterpret_cast<const f32x4 *>(c.mt + e); av[it] = *reinterpret_cast<const f32x4 *>(c.vt + e);
+        ap[it] = *reinterpret_cast<const f32x4 *>(c.p + e); at[it] = *reinterpret_cast<const f32x4 *>(c.target + e);
+    }
     f32x4 hv[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -658,13 +696,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         }
     }
     __syncthreads();
-    float am[16], av[16], ap[16], at[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = min(kb + (r & 3) + 8 * (r >> 2), H1N - 1);
-        const int e = off_w2(IN) + k * H2N + min(nn, H2N - 1);
-        am[r] = c.mt[e]; av[r] = c.vt[e]; ap[r] = c.p[e]; at[r] = c.target[e];
-    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -684,17 +715,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         for (int r = 0; r < 16; ++r)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), pb[32 * mt + (r & 3) + 8 * (r >> 2)], acc, 0, 0, 0);
     }
-    // ADAM + soft update on this lane's 16 elements
+    // the tile changes hands: accumulator layout -> LDS [64 k][68] (over the D2 panel, which every wave has finished reading) -> rows
+    __syncthreads();
+    float *T = d2s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(32 * kw + drow(r, lh)) * GW_TS + 32 * nw + li] = acc[r];
+    __syncthreads();
     {
         float *gW = const_cast<float *>(c.g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kb + (r & 3) + 8 * (r >> 2);
-            adam_math(c, acc[r], am[r], av[r], ap[r], at[r]);
-            if (k < H1N && nn < H2N) {
-                const int e = off_w2(IN) + k * H2N + nn;
-                c.mt[e] = am[r]; c.vt[e] = av[r]; c.p[e] = ap[r]; c.target[e] = at[r];
-                if (store_grad) gW[e] = acc[r];
+        for (int it = 0; it < 4; ++it) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(T + (16 * it + (tid >> 4)) * GW_TS + 4 * (tid & 15));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m_ = am[it][i], v_ = av[it][i], p_ = ap[it][i], t_ = at[it][i];
+                adam_math(c, g4[i], m_, v_, p_, t_);
+                am[it][i] = m_; av[it][i] = v_; ap[it][i] = p_; at[it][i] = t_;
+            }
+            if (eidx[it] >= 0) {
+                const int e = eidx[it];
+                *reinterpret_cast<f32x4 *>(c.mt + e) = am[it]; *reinterpret_cast<f32x4 *>(c.vt + e) = av[it];
+                *reinterpret_cast<f32x4 *>(c.p + e) = ap[it]; *reinterpret_cast<f32x4 *>(c.target + e) = at[it];
+                if (store_grad) *reinterpret_cast<f32x4 *>(gW + e) = g4;
             }
         }
     }
@@ -703,6 +745,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         if (n < H2N && col - 1 < OUT) adam_at(c, col == 0 ? off_b2(IN) + n : off_w3(IN) + n * OUT + (col - 1), rs[tid], store_grad);
     }
 }
+
+// ---- one launch per phase (the plain form: every learner of the group in the same phase) ---------------------------------------
+__global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A) { prep_body(A, blockIdx.x, blockIdx.y); }
+template <bool QG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tp_fwd(FwdArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fwd_body<QG>(A, blockIdx.x, blockIdx.y, smem);
+}
+template <int IN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    d1_body<IN>(A, blockIdx.x, blockIdx.y, smem);
+}
+template <int IN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gw2_body<IN>(A, blockIdx.x, blockIdx.y, smem);
+}
+
+// (Round 5 also built two ways of running the HBM-bound phases (P4, P7) under the MFMA-bound ones (P1, P2, P5) of OTHER learners: cohorts
+// of learners on separate streams, and a launch that runs different phases for different cohorts with their workgroups interleaved.
+// Both verified, both measured slower than the plain sequence above (2.11-3.27 ms and 2.17-2.34 ms against 2.08-2.11 ms), both removed:
+// profiles/r05_tp_overlap_probe.json.)
 
 static int set_attrs()
 {
@@ -749,22 +817,6 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     const int sg = (flags & SHEMS_TP_STORE_GRAD) ? 1 : 0;
     float *ws = d->ws;
 
-    PrepArgs pa{*d, *ring, ring_len, gs, seed, tick};
-    hipLaunchKernelGGL(k_tp_prep, dim3(L), dim3(256), 0, st, pa);
-
-    FwdArgs f;
-    std::memset(&f, 0, sizeof f);
-    f.gstride = gs; f.batch = d->batch;
-    f.job[0] = FwdJob{d->actor_t, ws + TP_X2, w1i_of(ws, NET_ACTOR_T), nullptr, nullptr, nullptr, nullptr, p3_of(ws, NET_ACTOR_T), nullptr, SIN, 2};
-    f.job[1] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, NET_CRITIC), nullptr, nullptr, nullptr, ws + TP_H2C, p3_of(ws, NET_CRITIC), nullptr, CIN, 1};
-    f.job[2] = FwdJob{d->actor, ws + TP_X, w1i_of(ws, NET_ACTOR), nullptr, nullptr, nullptr, ws + TP_H2A, p3_of(ws, NET_ACTOR), nullptr, SIN, 2};
-    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(3 * NT, L), dim3(256), FwdShape<false>::LDS, st, f);
-    // critic_target on [s'; actor_target(s')]
-    std::memset(&f.job, 0, sizeof f.job);
-    f.job[0] = FwdJob{d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
-                      p3_of(ws, NET_CRITIC_T), nullptr, CIN, 1};
-    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(NT, L), dim3(256), FwdShape<false>::LDS, st, f);
-
     auto adam_ctx = [&](bool critic) {
         const double eta = critic ? eta_crit : eta_act, bp1 = critic ? bp1_crit : bp1_act, bp2 = critic ? bp2_crit : bp2_act;
         return critic ? AdamCtx{d->critic, d->grad_critic, d->m_critic, d->v_critic, d->critic_t, nullptr, SHEMS_CRITIC_PARAMS, (int)CIN,
@@ -772,16 +824,29 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
                       : AdamCtx{d->actor, d->grad_actor, d->m_actor, d->v_actor, d->actor_t, nullptr, SHEMS_ACTOR_PARAMS, (int)SIN,
                                 eta, bp1, bp2, 1.0, eta / (1.0 - bp1), 1.0 / (1.0 - bp2), d->tau};
     };
-    NetArgs nc{*d, adam_ctx(true), gs, 1, sg};
-    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(4, L), dim3(256), D1_LDS, st, nc);
-    hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(4 * NT, L), dim3(256), GW_LDS, st, nc);
-    // updated critic on [s; actor(s)]: forward + input gradient
-    std::memset(&f.job, 0, sizeof f.job);
-    f.job[0] = FwdJob{d->critic, ws + TP_X, nullptr, p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
-                      ws + TP_DAP, CIN, 1};
-    hipLaunchKernelGGL(k_tp_fwd<true>, dim3(NT, L), dim3(256), FwdShape<true>::LDS, st, f);
-    NetArgs na{*d, adam_ctx(false), gs, 2, sg};
-    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(4, L), dim3(256), D1_LDS, st, na);
-    hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(4 * NT, L), dim3(256), GW_LDS, st, na);
+    struct { PrepArgs pa; FwdArgs f1, f2, f5; NetArgs nc, na; } U;
+    std::memset(&U, 0, sizeof U);
+    U.pa = PrepArgs{*d, *ring, ring_len, gs, seed, tick};
+    for (FwdArgs *f : {&U.f1, &U.f2, &U.f5}) { f->gstride = gs; f->batch = d->batch; }
+    // P1: three independent forward passes
+    U.f1.job[0] = FwdJob{d->actor_t, ws + TP_X2, w1i_of(ws, NET_ACTOR_T), nullptr, nullptr, nullptr, nullptr, p3_of(ws, NET_ACTOR_T), nullptr, SIN, 2};
+    U.f1.job[1] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, NET_CRITIC), nullptr, nullptr, nullptr, ws + TP_H2C, p3_of(ws, NET_CRITIC), nullptr, CIN, 1};
+    U.f1.job[2] = FwdJob{d->actor, ws + TP_X, w1i_of(ws, NET_ACTOR), nullptr, nullptr, nullptr, ws + TP_H2A, p3_of(ws, NET_ACTOR), nullptr, SIN, 2};
+    // P2: critic_target on [s'; actor_target(s')]
+    U.f2.job[0] = FwdJob{d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
+                         p3_of(ws, NET_CRITIC_T), nullptr, CIN, 1};
+    // P5: updated critic on [s; actor(s)], forward + input gradient
+    U.f5.job[0] = FwdJob{d->critic, ws + TP_X, nullptr, p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
+                         ws + TP_DAP, CIN, 1};
+    U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg};
+    U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg};
+    hipLaunchKernelGGL(k_tp_prep, dim3(5, L), dim3(256), 0, st, U.pa);
+    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(3 * FwdShape<false>::TILES, L), dim3(256), FwdShape<false>::LDS, st, U.f1);
+    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(FwdShape<false>::TILES, L), dim3(256), FwdShape<false>::LDS, st, U.f2);
+    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(4, L), dim3(256), D1_LDS, st, U.nc);
+    hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
+    hipLaunchKernelGGL(k_tp_fwd<true>, dim3(FwdShape<true>::TILES, L), dim3(256), FwdShape<true>::LDS, st, U.f5);
+    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(4, L), dim3(256), D1_LDS, st, U.na);
+    hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
 }

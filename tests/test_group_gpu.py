@@ -112,8 +112,8 @@ def test_default_form_follows_the_group_width():
 # (the second with advanced beta powers, non-zero moments and targets that have moved).
 # A relu whose float64 pre-activation lies within fp32 accumulation error of zero is on in one evaluation order and off in another:
 # the gradient then differs by that unit's whole contribution (seen in this very test: unit 496 of an actor at 1.5e-8 for one sample
-# moved gb2[496] by 1.2e-3 of the block's max while every other element agreed to 4e-7).  Such a (learner, update, network) is not
-# compared -- and at most two of them may occur in the whole run.
+# moved gb2[496] by 1.2e-3 of the block's max while every other element agreed to 4e-7).  A block comparison that FAILS is forgiven only
+# when the float64 evaluation has such a pre-activation (|z| < TIE) in that network for that minibatch -- and at most twice per run.
 TIE = 1e-7                      # ~5 sigma of the fp32 accumulation error of a layer-2 pre-activation (K = 250 terms of ~3e-2)
 
 
@@ -122,7 +122,7 @@ def _relu_margin(p, x, in_dim, out_dim):
     return min(float(np.abs(z1).min()), float(np.abs(z2).min()))
 
 
-@pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17)])
+@pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17), (11, 120)])
 def test_throughput_form_matches_float64_oracle_per_block(L, batch):
     import test_ddpg_gpu as TD
     ties = []
@@ -156,10 +156,12 @@ def test_throughput_form_matches_float64_oracle_per_block(L, batch):
             gc = ag.grad_critic.cpu().numpy()
             sn = DO.normalize(s, h["s_min"], h["s_max"])
             e = {}
-            if _relu_margin(h["pc"], np.concatenate([sn, a], 1), 11, 1) < TIE:
-                ties.append(("critic", l, tick))
-            else:
+            try:
                 e = TD._assert_blocks(gc, gc64, 11, 1, f"critic gradient of learner {l}, tick {tick}: throughput form vs float64")
+            except AssertionError:
+                if _relu_margin(h["pc"], np.concatenate([sn, a], 1), 11, 1) >= TIE:
+                    raise
+                ties.append(("critic", l, tick))
             losses = ag.losses.cpu().numpy()
             assert abs(losses[0] - lc64) < 1e-4 * max(1.0, abs(lc64)), (l, tick)
             pc1 = h["opt_c"].step(h["pc"], gc)                                  # ADAM + soft update from the kernel's own gradient
@@ -174,10 +176,12 @@ def test_throughput_form_matches_float64_oracle_per_block(L, batch):
             ga = ag.grad_actor.cpu().numpy()
             a_pi = DO.actor_forward(h["pa"], sn, dtype=np.float64)
             e2 = {}
-            if min(_relu_margin(h["pa"], sn, 9, 2), _relu_margin(crit, np.concatenate([sn, a_pi], 1), 11, 1)) < TIE:
-                ties.append(("actor", l, tick))
-            else:
+            try:
                 e2 = TD._assert_blocks(ga, ga64, 9, 2, f"actor gradient of learner {l}, tick {tick}: throughput form vs float64")
+            except AssertionError:
+                if min(_relu_margin(h["pa"], sn, 9, 2), _relu_margin(crit, np.concatenate([sn, a_pi], 1), 11, 1)) >= TIE:
+                    raise
+                ties.append(("actor", l, tick))
             assert abs(losses[1] - la64) < 1e-4 * max(1.0, abs(la64)), (l, tick)
             pa1 = h["opt_a"].step(h["pa"], ga)
             act = ag.actor.cpu().numpy()
