@@ -246,20 +246,22 @@ __device__ __forceinline__ f32x16 l1_tile(const float *w1s, int c, const float (
     return t;
 }
 
-// NTL = MFMA tiles per wave along n: the plain forward passes take 4 (a 128-wide n-tile: layer 1 is recomputed per n-tile -- 6 MFMAs per
-// chunk beside 64 instead of beside 32), the pass with the input gradient 2 (its second sweep holds 16 more accumulators).
-template <bool QG> struct FwdShape {
-    static constexpr int NTL = QG ? 2 : 4;
+// NTL = MFMA tiles per wave along n.  4 = a 128-wide n-tile: layer 1 is recomputed per n-tile, 6 MFMAs per chunk beside 64 instead of
+// beside 32 -- taken where the launch still has several rounds of workgroups (P1: three networks x 4 tiles x learners); 2 = 64-wide
+// n-tiles, twice the workgroups at four per CU: P2 (one network: 1 600 workgroups of the wide form would be 2.1 rounds of 768 slots)
+// and the pass with the input gradient (its second sweep holds 16 more accumulators).
+template <bool QG, int NTL_> struct FwdShape {
+    static constexpr int NTL = NTL_;
     static constexpr int NW = 32 * NTL;            // n-tile width
     static constexpr int TILES = 512 / NW;         // n-tiles per network
     static constexpr int S = QG ? NW + 1 : NW;     // chunk row stride: the backward pass reads the chunk along n (odd stride: conflict free)
     static constexpr int LDS = (W1K * W1C + NW * 4 + 2 * 32 * S) * 4;
 };
 
-template <bool QG>
+template <bool QG, int NTL_>
 __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const int by, float *smem)
 {
-    typedef FwdShape<QG> SH;
+    typedef FwdShape<QG, NTL_> SH;
     constexpr int S = SH::S, NTL = SH::NTL, NW = SH::NW;
     float *w1s = smem;                           // [12][256]
     float *ep = w1s + W1K * W1C;                 // [NW][4]: b2, W3[.][0], W3[.][1], valid
@@ -748,11 +750,11 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
 
 // ---- one launch per phase (the plain form: every learner of the group in the same phase) ---------------------------------------
 __global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A) { prep_body(A, blockIdx.x, blockIdx.y); }
-template <bool QG>
+template <bool QG, int NTL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tp_fwd(FwdArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    fwd_body<QG>(A, blockIdx.x, blockIdx.y, smem);
+    fwd_body<QG, NTL>(A, blockIdx.x, blockIdx.y, smem);
 }
 template <int IN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
@@ -776,8 +778,11 @@ static int set_attrs()
 {
     static std::atomic<uint64_t> m0{0}, m1{0}, m2{0}, m3{0}, m4{0}, m5{0};
     // (all below 64 KB: the opt-in is a no-op kept for the day a tile grows)
-    if (int rc = lds_optin(m0, reinterpret_cast<const void *>(&k_tp_fwd<false>), FwdShape<false>::LDS, "attr k_tp_fwd")) return rc;
-    if (int rc = lds_optin(m1, reinterpret_cast<const void *>(&k_tp_fwd<true>), FwdShape<true>::LDS, "attr k_tp_fwd<QG>")) return rc;
+    static std::atomic<uint64_t> m01{0};
+    constexpr int l4 = FwdShape<false, 4>::LDS, l2 = FwdShape<false, 2>::LDS, lq = FwdShape<true, 2>::LDS;
+    if (int rc = lds_optin(m0, reinterpret_cast<const void *>(&k_tp_fwd<false, 4>), l4, "attr k_tp_fwd")) return rc;
+    if (int rc = lds_optin(m01, reinterpret_cast<const void *>(&k_tp_fwd<false, 2>), l2, "attr k_tp_fwd")) return rc;
+    if (int rc = lds_optin(m1, reinterpret_cast<const void *>(&k_tp_fwd<true, 2>), lq, "attr k_tp_fwd<QG>")) return rc;
     if (int rc = lds_optin(m2, reinterpret_cast<const void *>(&k_tp_d1<CIN>), D1_LDS, "attr k_tp_d1")) return rc;
     if (int rc = lds_optin(m3, reinterpret_cast<const void *>(&k_tp_d1<SIN>), D1_LDS, "attr k_tp_d1")) return rc;
     if (int rc = lds_optin(m4, reinterpret_cast<const void *>(&k_tp_gw2<CIN>), GW_LDS, "attr k_tp_gw2")) return rc;
@@ -841,11 +846,14 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg};
     U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg};
     hipLaunchKernelGGL(k_tp_prep, dim3(5, L), dim3(256), 0, st, U.pa);
-    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(3 * FwdShape<false>::TILES, L), dim3(256), FwdShape<false>::LDS, st, U.f1);
-    hipLaunchKernelGGL(k_tp_fwd<false>, dim3(FwdShape<false>::TILES, L), dim3(256), FwdShape<false>::LDS, st, U.f2);
+    typedef FwdShape<false, 4> SW;           // (typedefs: the launch macro splits its arguments at the commas of a template argument list)
+    typedef FwdShape<false, 2> SN;
+    typedef FwdShape<true, 2> SQ;
+    hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
+    hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
     hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(4, L), dim3(256), D1_LDS, st, U.nc);
     hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
-    hipLaunchKernelGGL(k_tp_fwd<true>, dim3(FwdShape<true>::TILES, L), dim3(256), FwdShape<true>::LDS, st, U.f5);
+    hipLaunchKernelGGL((k_tp_fwd<true, 2>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
     hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(4, L), dim3(256), D1_LDS, st, U.na);
     hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
