@@ -73,9 +73,15 @@ def test_actor_forward_matches_float64_reference(m):
     assert np.abs(outn - out).max() > 0.05         # the noise is really there (its N(0,1) shape: test_ddpg_oracle.py)
 
 
-@pytest.mark.parametrize("n,nsteps", [(20000, 6), (2048 + 5, 3), (65536, 2)])      # 64-, 32- and 128-env tiles (the first two ragged)
-def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps):
+# 64-, 32- and 128-env tiles (the first two ragged) with per-tile reward sums; (8192, .., False) / (4096, .., False): BASELINE config 4's shard
+# and config 2 exactly as the training loop launches them -- NO per-tile sums, hence the two-workgroups-per-tile forms k_actg<1, 4, 2, 2> and
+# k_actg<1, 4, 2, 3> (with sums the dispatcher takes the 8-wave form): the shapes the bench times meet the oracle directly.
+@pytest.mark.parametrize("n,nsteps,sums", [(20000, 6, True), (2048 + 5, 3, True), (65536, 2, True), (8192, 2, False), (4096, 2, False),
+                                           (6005, 2, False)])
+def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps, sums):
     torch, S, D = _mods()
+    if not sums:
+        assert D.act_kernel_name(n) == ("shems::k_actg<1, 4, 2, 3>" if n <= 4096 else "shems::k_actg<1, 4, 2, 2>")
     ReplayRing = importlib.import_module(U.PKG_NAME + ".replay").ReplayRing
     T = S.tables
     tab = T.synthetic_table("train", 98)
@@ -93,7 +99,7 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps):
     a_out = torch.empty((n, 2), dtype=torch.float32, device="cuda")
     rew = torch.empty(n, dtype=torch.float64, device="cuda")
     rew32 = torch.empty(n, dtype=torch.float32, device="cuda")
-    blk = torch.zeros(ag.act_step_blocks(n), dtype=torch.float64, device="cuda")
+    blk = torch.zeros(ag.act_step_blocks(n), dtype=torch.float64, device="cuda") if sums else None
     pos = 0
     for t in range(nsteps):
         pre = env.state
@@ -110,8 +116,8 @@ def test_fused_act_step_equals_act_then_oracle_step_and_fills_ring(n, nsteps):
         r = rew.cpu().numpy()
         assert (U.bits64(r) == U.bits64(r_ref)).all() and (U.bits32(env.state) == U.bits32(o_ref)).all()
         assert (rew32.cpu().numpy() == r_ref.astype(np.float32)).all()
-        bm = n // blk.numel() if n % blk.numel() == 0 else None
-        assert abs(blk.sum().item() - r.sum()) < 1e-9 * max(1.0, abs(r).sum())
+        if sums:
+            assert abs(blk.sum().item() - r.sum()) < 1e-9 * max(1.0, abs(r).sum())
         # (3) the ring window
         rel = (np.arange(n) - (t * 333) % n) % n
         sel = np.where(rel < 333)[0]
