@@ -510,11 +510,19 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # rocprofv3 --pmc passes, see profiles/README.md
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(mode, {})
-            if rec.get("envs_per_gpu") == args.envs and args.hidden.lower() == "250x500":      # counters of the headline kernel only
+            if mode == "group":
+                # counters of the grouped update (all eight launches of one grouped replay()), only for the shape they were collected on
+                if (rec.get("learners") == args.learners and rec.get("envs_per_gpu") == args.envs and k["kernel"].startswith("grouped replay()")
+                        and rec.get("form") == getattr(wl.group, "form", None)):
+                    traffic = rec.get("bytes_as_read")
+                    traffic_src = ("profiles/pmc_traffic.json (static: FETCH_SIZE + WRITE_SIZE as read over the eight launches of one grouped replay(), separate "
+                                   "rocprofv3 --pmc passes of this command, " + str(rec.get("round")) + "; with the guide's 2x FETCH correction: "
+                                   + str(round(rec.get("bytes_fetch_x2", 0) / 1e9, 2)) + " GB)")
+            elif rec.get("envs_per_gpu") == args.envs and args.hidden.lower() == "250x500":      # counters of the headline kernel only
                 traffic = rec.get("hbm_bytes_per_launch")
                 # PMC counters cannot be read from inside this process: the figure is the committed result of separate
                 # `rocprofv3 --pmc` passes over this same command, not a measurement of the run that prints it
-                traffic_src = "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, " + str(rec.get("round", "r01")) + ")"
+                traffic_src = traffic_src or "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, " + str(rec.get("round", "r01")) + ")"
         roof = {"bound": k["bound"], "achieved": achieved, "peak": k["peak"], "unit": k["unit"],
                 "frac": achieved / k["peak"], "traffic": traffic, "traffic_source": traffic_src, "kernel": k["kernel"],
                 "kernel_avg_us": k["avg_us"], "kernel_median_us": k["median_us"], "launches": k["launches"],

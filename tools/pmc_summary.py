@@ -32,8 +32,11 @@ def main():
     tag = "r03"
     outdir = os.path.join(ROOT, "profiles")        # on the GPU box pass --outdir=gpurun_out/...: only gpurun_out/ travels back
     dirs = []
+    group = None                                   # --group=LEARNERS,ENVS: the passes are of bench.py --mode group (tools/profile_group.sh)
     for a in sys.argv[1:]:
-        if a.startswith("--round="):
+        if a.startswith("--group="):
+            group = tuple(int(x) for x in a.split("=", 1)[1].split(","))
+        elif a.startswith("--round="):
             tag = a.split("=", 1)[1]
         elif a.startswith("--outdir="):
             outdir = a.split("=", 1)[1]
@@ -48,6 +51,24 @@ def main():
         for (k, c), v in rows:
             if k.startswith("shems::") or "shems::" in k:
                 w.writerow([k, c, len(v), sum(v) / len(v), min(v), max(v)])
+    path = os.path.join(outdir, "pmc_traffic.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    if not doc and os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")):
+        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))          # records of the other modes are kept
+    if group is not None:
+        def gmean(name, ctr):
+            v = [x for (k, c), vals in rows if c == ctr and name in k for x in vals]
+            return sum(v) / len(v)
+        # launches of one grouped replay(): prep, fwd<false, 4>, fwd<false, 2>, fwd<true, 2>, d1 x2, gw2 x2
+        names = ("k_tp_prep", "k_tp_fwd<false, 4>", "k_tp_fwd<false, 2>", "k_tp_fwd<true, 2>", "k_tp_d1<11>", "k_tp_d1<9>", "k_tp_gw2<11>", "k_tp_gw2<9>")
+        fetch_kb, write_kb = sum(gmean(n, "FETCH_SIZE") for n in names), sum(gmean(n, "WRITE_SIZE") for n in names)
+        doc["group"] = {"round": tag.split("_")[0], "learners": group[0], "envs_per_gpu": group[1], "form": "throughput",
+                        "launches": "k_tp_prep + k_tp_fwd x3 + k_tp_d1 x2 + k_tp_gw2 x2", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+                        "bytes_as_read": (fetch_kb + write_kb) * 1024.0, "bytes_fetch_x2": (2.0 * fetch_kb + write_kb) * 1024.0,
+                        "source": f"profiles/{tag}_pmc_counters_train.csv (two rocprofv3 --pmc passes of bench.py --mode group, tools/profile_group.sh)"}
+        json.dump(doc, open(path, "w"), indent=1)
+        print(json.dumps(doc["group"]))
+        return
     act = {c: v for (k, c), v in rows if "k_act2" in k or "k_act<4" in k}
     # only the train-loop launches at 65 536 envs (populate / smoke launches of other sizes are other template instances)
     fetch, write = act["FETCH_SIZE"], act["WRITE_SIZE"]
@@ -71,7 +92,8 @@ def main():
         write_kb = 2 * w["k_fwd("] + w["k_mid("] + 2 * w["k_grad("]
         upd = {"round": tag, "launches": "k_fwd x2 + k_mid + k_grad x2", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                "bytes_as_read": (fetch_kb + write_kb) * 1024.0, "bytes_fetch_x2": (2.0 * fetch_kb + write_kb) * 1024.0}
-    json.dump({"train": rec, "policy": rec, "update": upd}, open(os.path.join(outdir, "pmc_traffic.json"), "w"), indent=1)
+    doc.update({"train": rec, "policy": rec, "update": upd})
+    json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps({"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "dispatches": len(fetch)}))
 
 

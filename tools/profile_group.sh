@@ -22,7 +22,7 @@ rm -rf $O/pmc
 echo pmc-mfma-done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $B --steps 24 --warmup 4 --prewarm-s 0.2 > $O/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py $B --steps 24 --warmup 4 --prewarm-s 0.2 > $O/pw.log 2>&1
-mkdir -p $O/prof && cd $R && python3 tools/pmc_summary.py --round=${TAG}_group400 --outdir=$O/prof $O/pmc_fetch $O/pmc_write > $O/pmc_summary.log 2>&1 || cat $O/pmc_summary.log
+mkdir -p $O/prof && cd $R && python3 tools/pmc_summary.py --group=400,51200 --round=${TAG}_group400 --outdir=$O/prof $O/pmc_fetch $O/pmc_write > $O/pmc_summary.log 2>&1 || cat $O/pmc_summary.log
 rm -rf $O/pmc_fetch $O/pmc_write
 echo all-done
 ls $O $O/prof
