@@ -331,24 +331,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
             const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
             if constexpr (!BWD) {
                 // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers
-                // (the A operands of k-step r + 1 are requested BEFORE the MFMAs of k-step r: read -> wait -> MFMA in program order left every
-                // MFMA group behind a fresh LDS latency -- matrix pipe 74 % busy in P1)
                 const float *pa = buf + 4 * lh * S + li;
-                float an[2][NTL];
-#pragma unroll
-                for (int tt = 0; tt < NTL; ++tt) an[0][tt] = pa[32 * tt];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (r < 15) {
-#pragma unroll
-                        for (int tt = 0; tt < NTL; ++tt) an[(r + 1) & 1][tt] = pa[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * S + 32 * tt];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                        // (pinned: the scheduler otherwise sinks the reads back to their use)
                     const float b = fmaxf(t[r], 0.0f);
 #pragma unroll
                     for (int tt = 0; tt < NTL; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[r & 1][tt], b, acc[tt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S + 32 * tt], b, acc[tt], 0, 0, 0);
                 }
             } else {
                 // backward through this n-tile: D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m], rows k = 32 c .. + 31; M = acc (see below)
@@ -356,20 +345,11 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g[r] = 0.0f;
                 const float *pa = buf + li * S + 4 * lh;
-                float aq[4];                                                  // four k-steps' operands ahead of the MFMAs that use them
-#pragma unroll
-                for (int u = 0; u < 4; ++u) aq[u] = pa[u];
 #pragma unroll
                 for (int tt = 0; tt < NTL; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float a = aq[r & 3];
-                        const int nx = 16 * tt + r + 4;                       // the step whose operand replaces this one
-                        if (nx < 16 * NTL) aq[r & 3] = pa[32 * (nx >> 4) + (nx & 3) + 8 * ((nx & 15) >> 2)];
-                        __builtin_amdgcn_sched_barrier(0);
-                        g = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[tt][r], g, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int r = 0; r < 16; ++r)
+                        g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[32 * tt + (r & 3) + 8 * (r >> 2)], acc[tt][r], g, 0, 0, 0);
                 const float *pw = w1s + 9 * W1C + 32 * c + 4 * lh;             // W1[9 + o][k]: the action rows (columns >= 250 zero)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -574,25 +554,13 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
         const float *buf = ring + (q & 1) * 64 * D1_S;
         if (q < 15) { a_load(q + 1, pv); h_load(q + 1, hn); }
         const float *pb = buf + li * D1_S + lh;
-        const float *pw = w3s + 2 * (32 * q + lh);
-        // (operands of k-step s + 1 requested before the MFMAs of k-step s, as in the forward kernel)
-        float2 w3n[2];
-        float bn[2][2];
-        w3n[0] = *reinterpret_cast<const float2 *>(pw);
-        bn[0][0] = pb[0]; bn[0][1] = pb[32 * D1_S];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            if (s < 15) {
-                w3n[(s + 1) & 1] = *reinterpret_cast<const float2 *>(pw + 4 * (s + 1));
-                bn[(s + 1) & 1][0] = pb[2 * (s + 1)]; bn[(s + 1) & 1][1] = pb[32 * D1_S + 2 * (s + 1)];
-            }
-            __builtin_amdgcn_sched_barrier(0);                                // (pinned: the scheduler otherwise sinks the reads back to their use)
-            const float2 w3 = w3n[s & 1];
+            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * (32 * q + 2 * s + lh));
             const float gsum = OUT == 2 ? fmaf(w3.y, d31, w3.x * d30) : w3.x * d30;
             const float d2 = hc[s] > 0.0f ? gsum : 0.0f;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, bn[s & 1][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, bn[s & 1][1], acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[2 * s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[32 * D1_S + 2 * s], acc[1], 0, 0, 0);
         }
         if (q < 15) a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
         __syncthreads();
@@ -745,17 +713,9 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
         for (int r = 0; r < 16; ++r) t[r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 6; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wb[s], t, 0, 0, 0);       // h1'[m][k] pre-activations
-        float bq[4];                                                          // four k-steps' operands ahead of the MFMAs that use them
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bq[u] = pb[32 * mt + u];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float b = bq[r & 3];
-            if (r + 4 < 16) bq[r & 3] = pb[32 * mt + ((r + 4) & 3) + 8 * ((r + 4) >> 2)];
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), b, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int r = 0; r < 16; ++r)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), pb[32 * mt + (r & 3) + 8 * (r >> 2)], acc, 0, 0, 0);
     }
     // the tile changes hands: accumulator layout -> LDS [64 k][68] (over the D2 panel, which every wave has finished reading) -> rows
     __syncthreads();
