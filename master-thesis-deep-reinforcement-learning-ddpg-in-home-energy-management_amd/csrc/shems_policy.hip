@@ -111,7 +111,6 @@ struct ActArgs {
     int gcount;
     int64_t gstride;
     int64_t genvs;
-    int stagger2;              // TEMP (experiment)
 };
 
 template <class T>
@@ -1304,273 +1303,6 @@ __global__ __launch_bounds__(64 * NW) void k_actg(ActArgs A, ActSplit X)
 }
 
 // =====================================================================================================================
-// k_actg16<RD>: the column-group form on 16-ENV tiles (round 5) -- v_mfma_f32_16x16x4_f32, two workgroups per env tile (four column
-// groups each, as k_actg's NS = 2), 72 KB of LDS per workgroup: a launch of 4 096 envs is 512 workgroups, TWO resident per CU, so that
-// one's latency-bound phases (stage 0, layer 1, layer 3, the exchange, the env tail: ~10 of the 16.5 us of a 32-env workgroup that has
-// its CU to itself) run under the other's MFMAs; at 8 192 envs four per CU in two rounds.  The matrix work per CU is unchanged.
-//   * a wave owns one column group = four 16 x 16 accumulators; lane (q = lane >> 4, e = lane & 15) holds, for env e, the sixteen columns
-//     of ONE of the canonical order's four layer-3 chains of the group: chain (a, lh) = (q & 1, q >> 1), element r = 4 t + r' in
-//     accumulator t, register r' = column 64 g + 16 t + 2 r' + 8 lh + a = act_col(64 g, a, drow(r, lh)).  Each lane runs its chain in r
-//     order, the chains meet as (c00 + c10) + (c01 + c11) by two lane exchanges: the additions of the 32 x 32 forms, the same bytes.
-//   * A operand of k-step K (W2 rows 4 K + kk, kk = lane >> 4): row of the wave's ring, columns 16 t + perm(e) for t < 4,
-//     perm(e) = 2 (e & 3) + 8 (e >> 3) + ((e >> 2) & 1) (the column of accumulator row e); B operand: relu(layer 1)[4 K + kk][e].
-//     Both MFMA forms accumulate their k terms as one FMA chain in ascending k, so 4-row steps give the bits of 2-row steps.
-//   * the W2 ring, its LDS-DMA pieces (one per k-step: a 16-row chunk is four k-steps) and the counted vmcnt waits are k_actg's;
-//     the wait for chunk c + 1 sits in front of k-step 2, whose operand prefetch (two k-steps ahead) opens that chunk: ring depth 3.
-//   * layer 1: sixteen 16-unit blocks over the four waves, K = 12 = three k-steps (input rows 10, 11 zero).
-template <int RD>
-constexpr size_t actg16_lds_bytes()
-{
-    return sizeof(float) * (4 * RD * kGChunkFloats + 16 + 256 * 16 + 12 * 16 + (kTailFloats + 2) + 8 * 16 * kOut + 16 * kIn + 16 * kPreDw + 4);
-}
-template <int RD>
-constexpr int g16_keep(int c)                    // pieces younger than chunk c + 1's that may be in flight when the wave waits for it after two
-{                                                // k-steps of chunk c: chunks c + 2 .. c + RD - 2 whole, two pieces of chunk c + RD - 1
-    int n = 0;
-    for (int j = c + 2; j <= c + RD - 2; ++j) n += g_pieces(j);
-    const int last = g_pieces(c + RD - 1);
-    return n + (last < 2 ? last : 2);
-}
-
-template <int RD>
-__global__ __launch_bounds__(256, 2) void k_actg16(ActArgs A, ActSplit X)
-{
-    static_assert(RD >= 3 && RD <= 4, "the operand prefetch of k-step 2 opens chunk c + 1 while chunk c + RD - 1 is still being requested");
-    constexpr int NW = 4, NT_ = 256, BM = 16, HR = 256, XK = 12;
-    typedef float f32x4m __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *Wc = reinterpret_cast<float *>(smem);             // [4 waves][RD][16][64] private W2 rings
-    float *Hc = Wc + NW * RD * kGChunkFloats + 16;           // [256][16] relu(layer 1) (rows 250..255: exactly zero)
-    float *xT = Hc + HR * BM;                                // [12][16] normalised obs (rows 0..8), row 9 = 1 (bias), rows 10, 11 = 0
-    float *tl = xT + XK * BM;                                // b2 [512], W3 [512][2], b3 [2]
-    float *red = tl + (kTailFloats + 2);                     // [8 groups][16][2] layer-3 group sums
-    float *xR = red + 8 * BM * kOut;                         // [16][9] raw observations
-    float *xP = xR + BM * kIn;                               // [16][kPreDw] TailPre blocks
-
-    // Stagger (for speed only; nothing depends on it): under the round-robin dispatch workgroups b and b + 256 land on one CU.  Started
-    // together they would run phase by phase in lockstep -- both in stage 0, both on the matrix pipe, both in the env tail -- and hide
-    // nothing of each other; the second one waits one matrix phase (~8 k cycles) so that its latency-bound phases fall under the
-    // first one's MFMAs and the other way round.
-    if (A.stagger2 == 1 ? ((blockIdx.x >> 3) & 1) : A.stagger2 == 2 ? ((blockIdx.x >> 4) & 1) : A.stagger2 == 3 ? (blockIdx.x & 1) : 0) __builtin_amdgcn_s_sleep(127);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int le = lane & 15, lq = lane >> 4;
-    // workgroup -> (env tile, column half): ids b and b + 8 (same XCD under the round-robin dispatch) are the two halves of a tile
-    int64_t tile;
-    int half;
-    {
-        const unsigned b = blockIdx.x, T = gridDim.x >> 1, full = (T >> 3) << 4;
-        if (b < full) { tile = (int64_t)(b >> 4) * 8 + (b & 7); half = (b >> 3) & 1; }
-        else { tile = (int64_t)(T >> 3) * 8 + ((b - full) >> 1); half = (b - full) & 1; }
-    }
-    const int64_t env0 = A.m0 + tile * BM;
-    const int64_t learner = A.gcount > 1 ? env0 / A.genvs : 0;
-    const int64_t goff = learner * A.gstride;
-    const float *__restrict__ P = gsh(A.p.actor, goff);
-    const float *__restrict__ s_min = gsh(A.p.s_min, goff), *__restrict__ s_max = gsh(A.p.s_max, goff);
-    const int g = half * NW + wave;                          // this wave's column group
-    const int nbase = 64 * g;
-
-    // ---- stage 0: every global load issued before the first use, addresses clamped, never predicated (as k_actg) --------------------
-    const char *W2g = reinterpret_cast<const char *>(P + kOffW2);
-    float *Wg = Wc + wave * (RD * kGChunkFloats);
-    const uint32_t ring_lds = lds_addr(Wg) + 2 * 1024;       // piece 2 of ring buffer 0
-    const char *gsbase = W2g + g * 256;
-    uint32_t gvoff[kGPieces];
-#pragma unroll
-    for (int q = 0; q < kGPieces; ++q) gvoff[q] = (uint32_t)((4 * q + (lane >> 4)) * (kH2 * 4) + (lane & 15) * 16 - (q - 2) * 1024);
-#define G16_PIECE(chunk, q)                                                                       \
-    g_piece(gsbase + (size_t)(chunk) * (kKC * kH2 * 4), gvoff[q], ring_lds + ((chunk) % RD) * (kGChunkFloats * 4), (q))
-    TailPre tp;
-    const bool view = A.do_step != 0, multi = view && A.v.n_cfg > 1;
-    {
-        const int64_t pe = min(env0 + (tid & (BM - 1)), A.m - 1);
-        const int32_t *pidx = view ? A.v.idx : reinterpret_cast<const int32_t *>(P), *pstep = view ? A.v.step : reinterpret_cast<const int32_t *>(P);
-        const uint16_t *pci = multi ? A.v.cfg_of_env : reinterpret_cast<const uint16_t *>(P);
-        tp.idx = pidx[view ? pe : 0];
-        tp.ci = multi ? (int)pci[pe] : 0;
-        tp.step = pstep[view ? pe : 0];
-    }
-    float sv, lo, hi, tv[6];
-    const int64_t last = A.m * kIn - 1;
-    {
-        const int e = min(tid, BM * kIn - 1), k = e % kIn;
-        sv = A.obs[min(env0 * kIn + e, last)];
-        lo = s_min[k];
-        hi = s_max[k];
-    }
-    // layer-1 A operands: W1[j = 4 s + lq][k = 16 blk + le] for the wave's four 16-unit blocks blk = wave + 4 u; input row 9 = b1
-    float wa_[4][3];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int k = 16 * (wave + NW * u) + le;
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) {
-            const int j = 4 * s2 + lq;                        // 0..11; rows 10, 11 do not exist: zero
-            const float v = P[min(j, kW1K - 1) * kH1 + min(k, kH1 - 1)];
-            wa_[u][s2] = (j < kW1K && k < kH1) ? v : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 6; ++it) tv[it] = P[kOffB2 + min(it * 256 + (tid & 255), kH2 + kH2 * kOut + kOut - 1)];
-    tp.nz = noise_draw(A.p, env0 + (tid & (BM - 1)));       // Philox + Box-Muller under the loads
-    f32x4 ra, rb;
-    {
-        const int32_t *pc = view ? reinterpret_cast<const int32_t *>(A.v.cfgs + tp.ci) : reinterpret_cast<const int32_t *>(P);
-        constexpr int o_row0 = offsetof(shems_config, table_row0) / 4, o_nrow = offsetof(shems_config, nrow) / 4;
-        const int32_t row0 = pc[o_row0], nrow = pc[o_nrow];
-        const float *tp_tables = view ? A.v.tables : P;
-        const int64_t tp_row = view ? (int64_t)row0 + max(min(tp.idx + 1, nrow), 2) - 1 : 1;
-        const f32x4 *rp = reinterpret_cast<const f32x4 *>(tp_tables + tp_row * SHEMS_NCOL);
-        ra = rp[0]; rb = rp[1];                                                // row idx + 1
-        tp.h_cur = tp_tables[(tp_row - 1) * SHEMS_NCOL];                       // h_countdown of row idx
-    }
-    {
-        const int e = tid, m = e / kIn, k = e - m * kIn;
-        const float x = (sv - lo) / ((hi - lo) + 1e-8f);                        // MPS:56
-        if (e < BM * kIn) { xT[k * BM + m] = env0 * kIn + e <= last ? x : 0.0f; xR[e] = sv; }
-    }
-    if (tid < BM) xT[kIn * BM + tid] = 1.0f;                                     // row 9 = 1: the bias input
-    if (tid < 2 * BM) xT[(kIn + 1) * BM + tid] = 0.0f;                           // rows 10, 11
-    {
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int e = it * 256 + tid;                     // source index: [0,500) b2, [500,1500) W3, [1500,1502) b3
-            if (e < kH2) tl[e] = tv[it];
-            else if (e < kH2 + kH2 * kOut) tl[kH2P + (e - kH2)] = tv[it];
-            else if (e < kH2 + kH2 * kOut + kOut) tl[kH2P + kH2P * kOut + (e - kH2 - kH2 * kOut)] = tv[it];
-        }
-        if (tid < kH2P - kH2) tl[kH2 + tid] = 0.0f;                                   // pad rows of b2
-        if (tid < (kH2P - kH2) * kOut) tl[kH2P + kH2 * kOut + tid] = 0.0f;            // pad rows of W3
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // xT visible (LDS stores only; the row loads keep flying)
-    {
-        // the ring's first chunks go out only now (as k_actg)
-#pragma unroll
-        for (int ch = 0; ch < RD - 1; ++ch)
-#pragma unroll
-            for (int q = 0; q < kGPieces; ++q) G16_PIECE(ch, q);
-        // layer 1 on the matrix pipe: D[i = unit 4 lq + r'][j = env le] of block blk = sum_j W1[j][unit] x[j][env], K = 12 = 3 steps;
-        // the four blocks' chains interleaved
-        float xb[3];
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) xb[s2] = xT[(4 * s2 + lq) * BM + le];
-        f32x4m t1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) t1[u] = f32x4m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_[u][s2], xb[s2], t1[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Hc[(16 * (wave + NW * u) + 4 * lq + r) * BM + le] = fmaxf(t1[u][r], 0.0f);
-        tp.nx = Row{ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]};
-        tailpre_store(xP + (tid & (BM - 1)) * kPreDw, tp);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // h1 complete; every wave waits for its own ring below
-
-    // ---- layer 2: this wave's group = four 16 x 16 tiles over 63 k-steps of four rows, no barrier -----------------------------------
-    const int qa = lq & 1, qlh = lq >> 1;                    // this lane's layer-3 chain
-    f32x4m acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = tl[nbase + 16 * t + 2 * r + 8 * qlh + qa];          // bias
-    constexpr int kG16Ksteps = (kChunks - 1) * 4 + 3;        // rows 0..251 (250, 251: W2 in bounds, relu(layer 1) zero)
-    const int perm = 2 * (le & 3) + 8 * (le >> 3) + ((le >> 2) & 1);
-    const float *pa0 = Wg + lq * 64 + perm, *pb0 = Hc + lq * BM + le;
-    float af_[3][4], bf_[3];
-#define G16_LOAD(K2_)                                                                                            \
-    do {                                                                                                        \
-        const int c2_ = (K2_) >> 2, kr_ = 4 * ((K2_) & 3);                                                      \
-        const float *pa_ = pa0 + (c2_ % RD) * kGChunkFloats + kr_ * 64;                                         \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) af_[(K2_) % 3][t] = pa_[16 * t];                          \
-        bf_[(K2_) % 3] = pb0[(4 * (K2_)) * BM];                                                                 \
-    } while (0)
-#define G16_KSTEP(c, ks)                                                                                        \
-    do {                                                                                                        \
-        const int K_ = 4 * (c) + (ks), K2_ = K_ + 2;                                                            \
-        if (K2_ < kG16Ksteps) G16_LOAD(K2_);                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                           \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af_[K_ % 3][t], bf_[K_ % 3], acc[t], 0, 0, 0);        \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if ((ks) < g_pieces((c) + RD - 1)) { G16_PIECE((c) + RD - 1, (ks)); __builtin_amdgcn_sched_barrier(0); } \
-    } while (0)
-#define G16_CHUNK(c, NKS)                                                                                       \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int ks = 0; ks < ((NKS) < 2 ? (NKS) : 2); ++ks) G16_KSTEP(c, ks);                \
-        if ((c) + 1 < kChunks) {                                                                                \
-            constexpr int keep_ = g16_keep<RD>(c);                                                              \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep_) : "memory");      /* this wave's chunk c + 1 has landed */ \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-        }                                                                                                       \
-        _Pragma("unroll") for (int ks = 2; ks < (NKS); ++ks) G16_KSTEP(c, ks);                                  \
-    } while (0)
-    {
-        constexpr int keep0_ = g_keep<RD>(-1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(keep0_) : "memory");          // this wave's chunk 0 has landed
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    G16_LOAD(0);
-    G16_LOAD(1);
-    __builtin_amdgcn_sched_barrier(0);
-    G16_CHUNK(0, 4);  G16_CHUNK(1, 4);  G16_CHUNK(2, 4);  G16_CHUNK(3, 4);
-    G16_CHUNK(4, 4);  G16_CHUNK(5, 4);  G16_CHUNK(6, 4);  G16_CHUNK(7, 4);
-    G16_CHUNK(8, 4);  G16_CHUNK(9, 4);  G16_CHUNK(10, 4); G16_CHUNK(11, 4);
-    G16_CHUNK(12, 4); G16_CHUNK(13, 4); G16_CHUNK(14, 4);
-    G16_CHUNK(15, 3);                                                          // rows 240..251
-
-    // ---- layer 3 of this group: this lane's chain (a, lh) in r order, then (c00 + c10) + (c01 + c11): the canonical order ------------
-    {
-        const float *w3s = tl + kH2P;
-        float o0 = 0.0f, o1 = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = nbase + 16 * t + 2 * r + 8 * qlh + qa;
-                const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * n);
-                const float h = fmaxf(acc[t][r], 0.0f);
-                o0 = fmaf(h, w3.x, o0);
-                o1 = fmaf(h, w3.y, o1);
-            }
-        const float u0 = o0 + __shfl_xor(o0, 16, 64), u1 = o1 + __shfl_xor(o1, 16, 64);             // tile a = 0 + tile a = 1
-        const float g0 = u0 + __shfl_xor(u0, 32, 64), g1 = u1 + __shfl_xor(u1, 32, 64);             // + the other lane half
-        if (lq == 0) *reinterpret_cast<float2 *>(red + (g * BM + le) * 2) = make_float2(g0, g1);
-    }
-    __syncthreads();
-
-    // ---- one thread per env: b3 + (H0 + H1), tanh, noise, clamp, scale_action, step!, remember (k_actg's NS = 2 tail) ----------------
-    const int64_t i = env0 + tid;
-    bool fin = tid < BM && i < A.m;
-    float p0 = 0.0f, p1 = 0.0f;
-    if (fin) {
-        auto half_sum = [&](int hf, int j) {
-            return ((red[((4 * hf) * BM + tid) * 2 + j] + red[((4 * hf + 1) * BM + tid) * 2 + j]) + red[((4 * hf + 2) * BM + tid) * 2 + j]) +
-                   red[((4 * hf + 3) * BM + tid) * 2 + j];
-        };
-        float m0 = half_sum(half, 0), m1 = half_sum(half, 1);
-        unsigned long long mine = ((unsigned long long)__float_as_uint(m1) << 32) | __float_as_uint(m0);
-        if (mine == kSplitEmpty) { mine = 0x7FC000007FC00000ull; m0 = m1 = __uint_as_float(0x7FC00000u); }   // a NaN pair never takes the empty pattern
-        unsigned long long *slot = X.slot + tile * BM + tid;
-        const unsigned long long got = __hip_atomic_exchange(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (got == kSplitEmpty) fin = false;
-        else __hip_atomic_store(slot, kSplitEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float x0 = __uint_as_float((uint32_t)got), x1 = __uint_as_float((uint32_t)(got >> 32));
-        const float h00 = half == 0 ? m0 : x0, h01 = half == 0 ? m1 : x1, h10 = half == 0 ? x0 : m0, h11 = half == 0 ? x1 : m1;
-        p0 = tl[kH2P + kH2P * kOut + 0] + (h00 + h10);                              // b3 + (H0 + H1)
-        p1 = tl[kH2P + kH2P * kOut + 1] + (h01 + h11);
-    }
-    if (fin) act_env_tail(A, i, p0, p1, learner, goff, A.obs == A.v.obs ? xR + tid * kIn : nullptr, xP + tid * kPreDw);
-}
-#undef G16_PIECE
-#undef G16_LOAD
-#undef G16_KSTEP
-#undef G16_CHUNK
-
-// =====================================================================================================================
 // k_act2: the fused step for large batches with TWO workgroups resident per CU.
 //
 // k_act's 128-env tile fills a CU's LDS (161 KB), so a CU holds one workgroup at a time and everything outside the MFMA loop -- stage
@@ -1954,24 +1686,6 @@ static int launch_actg(const ActArgs &a, hipStream_t st)
     return hip_ok(hipGetLastError(), "k_actg launch");
 }
 
-template <int RD>
-static int launch_actg16(const ActArgs &a, hipStream_t st)
-{
-    constexpr int BM = 16;
-    constexpr size_t lds = actg16_lds_bytes<RD>();
-    static_assert(lds <= 80 * 1024, "k_actg16: two workgroups per CU");
-    static std::atomic<uint64_t> optin{0};
-    if (int rc = lds_optin(optin, reinterpret_cast<const void *>(&k_actg16<RD>), (int)lds, "hipFuncSetAttribute(k_actg16)")) return rc;
-    const int64_t tiles = (a.m - a.m0 + BM - 1) / BM;
-    ActSplit x = {nullptr};
-    if (tiles * BM > (int64_t)kSplitMaxTiles * 64) return set_error(SHEMS_ERR_ARG, "k_actg16: %lld env tiles exceed the split form's scratch", (long long)tiles);
-    if (split_scratch(st, &x) != SHEMS_OK) return launch_actg<1, 8, 1, 3>(a, st);       // (see launch_actg)
-    ActArgs a2 = a;
-    { const char *e = getenv("SHEMS_TMP_STAGGER"); a2.stagger2 = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((k_actg16<RD>), dim3((unsigned)(tiles * 2)), dim3(256), lds, st, a2, x);
-    return hip_ok(hipGetLastError(), "k_actg16 launch");
-}
-
 // Which form runs a launch of m envs (the knobs exist for the all-forms test and for A/B runs):
 //   m > 8 192            k_act2           64-env tiles, two workgroups resident per CU            (SHEMS_ACT_FORM4 = 1 / 0: k_act, below)
 //   4 096 < m <= 8 192   k_actg<1, 4, 2, 2>  32-env tiles, two workgroups per tile, ring of 2 chunks: both resident on one CU
@@ -2011,7 +1725,6 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     // are two independent workgroups resident on one CU (8 waves, two per SIMD, as the 8-wave form) without that form's coupling (its early
     // waves wait at the barrier for the late ones): 23.1 against 23.8 us at 8 192 envs.  At <= 4 096 envs (one workgroup per CU) the
     // shallower ring costs more than it wins (17.7 against 16.2 us): ring of three there.  Per-tile reward sums need ONE workgroup per tile.
-    if (form == 16 && !want_sum && cnt <= (int64_t)kSplitMaxTiles * 64) return launch_actg16<3>(a, st);      // round 5: 16-env tiles (A/B; see below)
     if ((form == 10 || (form < 0 && cnt > 128 * 32)) && !want_sum && (cnt + 31) / 32 <= kSplitMaxTiles) return launch_actg<1, 4, 2, 2>(a, st);
     if (form == 8 || (form != 9 && (cnt > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
     return launch_actg<1, 4, 2, 3>(a, st);

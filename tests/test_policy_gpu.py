@@ -269,8 +269,7 @@ def test_every_form_of_the_act_kernel_writes_the_same_bytes():
     # default: k_act2 (two workgroups per CU) above 8 192 envs, the column-group forms below
     forms = {"default": {}, "shared": {"SHEMS_ACT_FORM": "0", "SHEMS_ACT_FORM4": "0"}, "free": {"SHEMS_ACT_FORM": "2", "SHEMS_ACT_FORM4": "1"},
              "ring3": {"SHEMS_ACT_FORM": "3", "SHEMS_ACT_FORM4": "1"}, "group8": {"SHEMS_ACT_FORM": "8"}, "split": {"SHEMS_ACT_FORM": "9"},
-             "two_per_cu_everywhere": {"SHEMS_ACT_FORM": "12"}, "split_ring2": {"SHEMS_ACT_FORM": "10"},
-             "tiles16": {"SHEMS_ACT_FORM": "16"}}       # round 5: 16-env tiles on v_mfma_f32_16x16x4_f32 (k_actg16), two workgroups per CU
+             "two_per_cu_everywhere": {"SHEMS_ACT_FORM": "12"}, "split_ring2": {"SHEMS_ACT_FORM": "10"}}
     for name, env in forms.items():
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
@@ -317,7 +316,7 @@ def test_split_tiles_give_the_same_bytes_whichever_half_arrives_second():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _LOAD_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     got = []
-    for form in ("9", "9", "9", "8", "16", "16"):
+    for form in ("9", "9", "9", "8"):
         e = dict(os.environ); e["SHEMS_ACT_FORM"] = form
         r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
