@@ -309,6 +309,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
         if (J.api && nt == 0) J.api[lh * BP + m] = lh ? a1 : a0;
     }
     fwd_chunk_store<S, NTL>(ring, pv);
+    // The operands above are consumed inside the chunk loop only.  Loads retire in order, so without this the compiler's wait in front of
+    // their first use (counted for the loop's entry edge) also waits, on every later iteration, for the chunk prefetch issued just before it.
+#pragma unroll
+    for (int s = 0; s < 6; ++s) asm volatile("" : "+v"(xreg[s]));
     __syncthreads();
 
     f32x16 acc[NTL];
@@ -328,8 +332,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
             const float *buf = ring + (it & 1) * 32 * S;
             const bool more = wrap || c < 7;
             if (more) fwd_chunk_load<NTL>(W2, n0, (it + 1) & 7, pv);
-            const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
+            __builtin_amdgcn_sched_barrier(0);          // (where the request is unconditional the scheduler otherwise sinks it to the end of the iteration)
             if constexpr (!BWD) {
+                const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
                 // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers
                 const float *pa = buf + 4 * lh * S + li;
 #pragma unroll
@@ -350,6 +355,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[32 * tt + (r & 3) + 8 * (r >> 2)], acc[tt][r], g, 0, 0, 0);
+                // layer-1 pre-activations for the mask only now: 16 fewer live registers under the product (with them the 128-register
+                // budget of four waves per SIMD spilled two of M's values, and a scratch reload waits for the chunk prefetch as well)
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
                 const float *pw = w1s + 9 * W1C + 32 * c + 4 * lh;             // W1[9 + o][k]: the action rows (columns >= 250 zero)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -549,23 +558,31 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-#pragma unroll 1
-    for (int q = 0; q < 16; ++q) {
+    // One n-chunk: the next chunk's weights and error-signal source are requested first and are not touched before the following step
+    // (two register sets taken in turn: a copy `hc = hn` at the end of the step is moved up by the scheduler into the product, where its
+    // wait for the just-issued loads -- loads retire in order -- stalls the matrix pipe every chunk).
+    auto step = [&](int q, const float (&hcur)[16], float (&hnext)[16]) {
         const float *buf = ring + (q & 1) * 64 * D1_S;
-        if (q < 15) { a_load(q + 1, pv); h_load(q + 1, hn); }
+        // (unconditional -- the last step requests chunk 15 again: behind a branch the compiler's wait in front of hcur is the one of the
+        // path WITHOUT new requests, which on the other path waits for them)
+        a_load(min(q + 1, 15), pv); h_load(min(q + 1, 15), hnext);
+        __builtin_amdgcn_sched_barrier(0);
         const float *pb = buf + li * D1_S + lh;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * (32 * q + 2 * s + lh));
             const float gsum = OUT == 2 ? fmaf(w3.y, d31, w3.x * d30) : w3.x * d30;
-            const float d2 = hc[s] > 0.0f ? gsum : 0.0f;
+            const float d2 = hcur[s] > 0.0f ? gsum : 0.0f;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[2 * s], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[32 * D1_S + 2 * s], acc[1], 0, 0, 0);
         }
-        if (q < 15) a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
+        a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16; ++s) hc[s] = hn[s];
+    };
+#pragma unroll 1
+    for (int q = 0; q < 16; q += 2) {
+        step(q, hc, hn);
+        step(q + 1, hn, hc);
     }
     // ---- layer-1 relu mask: pre-activations transposed, rows = samples of this wave's column tile, columns = the k-tile's units ----
     const float *w1i = N::w1i(ws);
@@ -631,7 +648,7 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 constexpr int GW_S = BP + 1;
 constexpr int GW_TS = 68;          // row stride of the row-major copy of the finished tile [64 k][68] (over the D2 panel)
 constexpr int GW_WGS = 4 * NT;     // k-tiles x n-tiles of 64 per learner
-constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3) * 4;
+constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3 + W1K * BP) * 4;
 static_assert(64 * GW_TS <= 64 * GW_S, "the row-major copy of a tile fits the D2 panel it replaces");
 
 template <int IN>
@@ -643,6 +660,7 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
     float *d3s = d2s + 64 * GW_S;                // [2][BP]
     float *w3s = d3s + 2 * BP;                   // [64][2]
     float *rs = w3s + 64 * 2;                    // [64][3] row sums: gb2, gW3[.][0], gW3[.][1]
+    float *xs = rs + 64 * 3;                     // [12][BP] the input block
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int nt = bx & 7, kt = bx >> 3, n0 = 64 * nt, k0 = 64 * kt;
     const int kw = w >> 1, nw = w & 1;
@@ -654,6 +672,26 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
     const float *__restrict__ H2 = N::H2(ws);
     const bool store_grad = A.store_grad != 0;
 
+    // Requests, in the order the workgroup needs them: loads retire in order, so a wait for any operand also waits for everything requested
+    // before it.  The small operands of the panel and of the product come first; the tile's state -- 16 float4, the kernel's HBM stream --
+    // is requested LAST and is still arriving while the panel is built and the product runs (nothing later in the kernel issues a load).
+    f32x4 hv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 256 + tid;
+        hv[it] = *reinterpret_cast<const f32x4 *>(H2 + (int64_t)(n0 + (e >> 5)) * BP + 4 * (e & 31));
+    }
+    const float d3v = N::d3(ws)[tid];
+    const float w3v = N::w3f(ws)[2 * n0 + (tid & 127)];
+    const float *w1i = N::w1i(ws);
+    float wb[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) wb[s] = w1i[(2 * s + lh) * W1C + k0 + 32 * kw + li];
+    const float *X = N::X(ws);
+    float xv[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) xv[s] = X[s * 256 + tid];
+    __builtin_amdgcn_sched_barrier(0);
     // this thread's 16 elements of the tile, row-major: float4 it = row 16 it + (tid >> 4), columns 4 (tid & 15) .. + 3
     int eidx[4];
     f32x4 am[4], av[4], ap[4], at[4];
@@ -665,18 +703,11 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
         am[it] = *reinterpret_cast<const f32x4 *>(c.mt + e); av[it] = *reinterpret_cast<const f32x4 *>(c.vt + e);
         ap[it] = *reinterpret_cast<const f32x4 *>(c.p + e); at[it] = *reinterpret_cast<const f32x4 *>(c.target + e);
     }
-    f32x4 hv[8];
+    __builtin_amdgcn_sched_barrier(0);
+    d3s[tid] = d3v;
+    if (tid < 128) w3s[tid] = w3v;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int e = it * 256 + tid;
-        hv[it] = *reinterpret_cast<const f32x4 *>(H2 + (int64_t)(n0 + (e >> 5)) * BP + 4 * (e & 31));
-    }
-    d3s[tid] = N::d3(ws)[tid];
-    if (tid < 128) w3s[tid] = N::w3f(ws)[2 * n0 + tid];
-    const float *w1i = N::w1i(ws);
-    float wb[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) wb[s] = w1i[(2 * s + lh) * W1C + k0 + 32 * kw + li];
+    for (int s = 0; s < 6; ++s) xs[s * 256 + tid] = xv[s];
     __syncthreads();
     // D2 panel + row sums
 #pragma unroll
@@ -701,13 +732,12 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const float *X = N::X(ws);
     const float *pb = d2s + (32 * nw + li) * GW_S + 4 * lh;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float xa[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) xa[s] = X[(2 * s + lh) * BP + 32 * mt + li];
+        for (int s = 0; s < 6; ++s) xa[s] = xs[(2 * s + lh) * BP + 32 * mt + li];
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = 0.0f;
