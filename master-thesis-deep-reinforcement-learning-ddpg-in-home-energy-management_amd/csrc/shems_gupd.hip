@@ -62,8 +62,8 @@ constexpr int64_t TP_X2 = TP_X + W1K * BP;             // [12][BP]  rows 0..8 no
 constexpr int64_t TP_R = TP_X2 + W1K * BP;             // [BP]
 constexpr int64_t TP_DONE = TP_R + BP;                 // [BP]
 constexpr int64_t TP_IDX = TP_DONE + BP;               // [BP] int32 sampled ring slots (-1 in the pad columns)
-constexpr int64_t TP_W1I = TP_IDX + BP;                // [4 nets][12][256] frozen layer-1 images
-constexpr int64_t TP_FW3C = TP_W1I + 4 * W1K * W1C;    // [512][2] frozen critic W3 ([.][1] and rows >= 500 zero)
+constexpr int64_t TP_W1I = TP_IDX + BP;                // [5][12][256] frozen layer-1 images of the four networks + the critic's AFTER its update
+constexpr int64_t TP_FW3C = TP_W1I + 5 * W1K * W1C;    // [512][2] frozen critic W3 ([.][1] and rows >= 500 zero)
 constexpr int64_t TP_FW3A = TP_FW3C + 1024;            // [512][2] frozen actor W3
 constexpr int64_t TP_FB3 = TP_FW3A + 1024;             // [8] frozen b3: critic, critic_target, actor[0], actor[1], actor_target[0], [1]
 constexpr int64_t TP_P3 = TP_FB3 + 8;                  // [5 passes][NT][2][BP] layer-3 partial sums per n-tile
@@ -77,6 +77,7 @@ constexpr int64_t TP_FLOATS = TP_H2A + 512 * BP;
 static_assert(TP_FLOATS <= kTpWsFloats, "the throughput form's carve fits the workspace every caller allocates");
 static_assert(TP_W1I % 4 == 0 && TP_H2C % 4 == 0 && TP_P3 % 4 == 0, "16-byte aligned blocks");
 enum { NET_ACTOR_T = 0, NET_CRITIC_T = 1, NET_CRITIC = 2, NET_ACTOR = 3, PASS_CRITIC2 = 4 };
+constexpr int IMG_CRITIC_NEW = 4;      // image slot P3 fills with the critic's updated layer 1 (P5 reads it; P3 / P4 keep reading the frozen one)
 __host__ __device__ inline float *p3_of(float *ws, int pass) { return ws + TP_P3 + (int64_t)pass * NT * 2 * BP; }
 __host__ __device__ inline float *w1i_of(float *ws, int net) { return ws + TP_W1I + (int64_t)net * W1K * W1C; }
 
@@ -141,6 +142,11 @@ __device__ __forceinline__ void prep_body(const PrepArgs &A, const int role, con
         for (int j = 0; j < W1K; ++j) v[j] = P[(j == W1K - 1 ? in : min(j, in - 1)) * H1N + k];       // clamped, all twelve loads in flight
 #pragma unroll
         for (int j = 0; j < W1K; ++j) img[j * W1C + tid] = ((j < in || j == W1K - 1) && tid < H1N) ? v[j] : 0.0f;
+        if (net == NET_CRITIC) {                 // the zeros of the slot P3 writes the updated elements into
+            float *img2 = w1i_of(ws, IMG_CRITIC_NEW);
+#pragma unroll
+            for (int j = 0; j < W1K; ++j) img2[j * W1C + tid] = 0.0f;
+        }
         return;
     }
     const uint64_t seed = A.seed + (uint64_t)l;               // learner l: Philox key seed + l (as the latency form)
@@ -190,7 +196,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs &A, const int role, con
 struct FwdJob {
     const float *P;        // parameter block of the network
     const float *X;        // [12][BP] input block (workspace)
-    const float *w1i;      // frozen layer-1 image (workspace), or null: pack it from P (a network updated earlier in this update)
+    const float *w1i;      // layer-1 image (workspace): frozen by P0, or written by P3 (the critic after its update)
     const float *ap3;      // rows 9, 10 = tanh(ab3 + sum of these [NT][2][BP] partials) of an actor pass, or null (rows as stored in X)
     const float *ab3;      // [2]
     float *api;            // n-tile 0 publishes the computed action here ([2][BP]), or null
@@ -274,36 +280,44 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
     const float *__restrict__ W2 = P + off_w2(J.in);
     const int m = 32 * w + li;
 
+    // Every request of the prologue is issued before the first wait: the workgroups of a CU start together (at the launch and, staying
+    // in step, after each generation), so their prologues are not covered by anybody's matrix work -- one exposed round trip, not four.
     f32x4 pv[NTL];
     fwd_chunk_load<NTL>(W2, n0, 0, pv);
-    // layer-1 image -> LDS
-    if (J.w1i) {
+    f32x4 wi[3];
+    {
         const f32x4 *g4 = reinterpret_cast<const f32x4 *>(J.w1i) + tid;
-        f32x4 *l4 = reinterpret_cast<f32x4 *>(w1s) + tid;
-        const f32x4 a = g4[0], b = g4[256], c = g4[512];
-        l4[0] = a; l4[256] = b; l4[512] = c;
-    } else {
-        const int k = min(tid, H1N - 1);
-        float v[W1K];
-#pragma unroll
-        for (int j = 0; j < W1K; ++j) v[j] = P[(j == W1K - 1 ? J.in : min(j, J.in - 1)) * H1N + k];
-#pragma unroll
-        for (int j = 0; j < W1K; ++j) w1s[j * W1C + tid] = ((j < J.in || j == W1K - 1) && tid < H1N) ? v[j] : 0.0f;
+        wi[0] = g4[0]; wi[1] = g4[256]; wi[2] = g4[512];
     }
+    float eb2 = 0.0f, ew30 = 0.0f, ew31 = 0.0f;
     if (tid < NW) {
-        const int n = n0 + tid, nc = min(n, H2N - 1);
-        const float valid = n < H2N ? 1.0f : 0.0f;
-        const float b2 = P[off_b2(J.in) + nc], w30 = P[off_w3(J.in) + nc * J.out], w31 = J.out == 2 ? P[off_w3(J.in) + nc * 2 + 1] : 0.0f;
-        ep[tid * 4 + 0] = b2; ep[tid * 4 + 1] = w30 * valid; ep[tid * 4 + 2] = w31 * valid; ep[tid * 4 + 3] = valid;
+        const int nc = min(n0 + tid, H2N - 1);
+        eb2 = P[off_b2(J.in) + nc]; ew30 = P[off_w3(J.in) + nc * J.out];
+        if (J.out == 2) ew31 = P[off_w3(J.in) + nc * 2 + 1];
     }
     // this lane's B operands of layer 1: x[2 s + lh][m]
     float xreg[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) xreg[s] = J.X[(2 * s + lh) * BP + m];
-    if (J.ap3) {                                 // rows 9, 10 from an actor pass: a[o][m] = tanh(b3[o] + partials)
-        float a0 = J.ab3[0], a1 = J.ab3[1];
+    float a0 = 0.0f, a1 = 0.0f, pa3[2 * NT];
+    if (J.ap3) {
+        a0 = J.ab3[0]; a1 = J.ab3[1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { a0 += J.ap3[(t * 2 + 0) * BP + m]; a1 += J.ap3[(t * 2 + 1) * BP + m]; }
+        for (int t = 0; t < NT; ++t) { pa3[2 * t] = J.ap3[(t * 2 + 0) * BP + m]; pa3[2 * t + 1] = J.ap3[(t * 2 + 1) * BP + m]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // layer-1 image -> LDS
+    {
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(w1s) + tid;
+        l4[0] = wi[0]; l4[256] = wi[1]; l4[512] = wi[2];
+    }
+    if (tid < NW) {
+        const float valid = n0 + tid < H2N ? 1.0f : 0.0f;
+        ep[tid * 4 + 0] = eb2; ep[tid * 4 + 1] = ew30 * valid; ep[tid * 4 + 2] = ew31 * valid; ep[tid * 4 + 3] = valid;
+    }
+    if (J.ap3) {                                 // rows 9, 10 from an actor pass: a[o][m] = tanh(b3[o] + partials)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { a0 += pa3[2 * t]; a1 += pa3[2 * t + 1]; }
         a0 = tanhf(a0); a1 = tanhf(a1);          // Dense(500, 2, tanh)
         if (lh == 1) xreg[4] = a0; else xreg[5] = a1;          // row 9 = (s 4, lh 1), row 10 = (s 5, lh 0)
         if (J.api && nt == 0) J.api[lh * BP + m] = lh ? a1 : a0;
@@ -321,6 +335,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
     float da0 = 0.0f, da1 = 0.0f;
+    unsigned mbits = 0u;                         // QG: bit 16 tt + r = (h2 > 0) of this lane's element (tt, r)
     const float d3q = m < A.batch ? -1.0f / (float)A.batch : 0.0f;          // d(-mean q)/dq
     // One pass over the n-tile's eight weight chunks; chunk it + 1 is requested before chunk it is consumed and lands in the other half
     // of the ring.  BWD = false: layer 2 forward; BWD = true (QG only): the input gradient through this n-tile.
@@ -334,27 +349,52 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
             if (more) fwd_chunk_load<NTL>(W2, n0, (it + 1) & 7, pv);
             __builtin_amdgcn_sched_barrier(0);          // (where the request is unconditional the scheduler otherwise sinks it to the end of the iteration)
             if constexpr (!BWD) {
-                const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
-                // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers
+                // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers.
+                // The A operands of step r + 1 are read from LDS before the products of step r are issued (read -> wait -> two products, as
+                // the compiler lays the plain loop out, leaves the LDS latency uncovered behind every pair: ~3/4 of the pipe for one wave).
                 const float *pa = buf + 4 * lh * S + li;
+                float a0[NTL], a1[NTL];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float b = fmaxf(t[r], 0.0f);
+                for (int tt = 0; tt < NTL; ++tt) a0[tt] = pa[32 * tt];
+                const f32x16 t = l1_tile(w1s, c, xreg, li, lh);
 #pragma unroll
-                    for (int tt = 0; tt < NTL; ++tt)
-                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[((r & 3) + 8 * (r >> 2)) * S + 32 * tt], b, acc[tt], 0, 0, 0);
+                for (int r = 0; r < 16; r += 2) {
+#pragma unroll
+                    for (int tt = 0; tt < NTL; ++tt) a1[tt] = pa[(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * S + 32 * tt];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float b0 = fmaxf(t[r], 0.0f);
+#pragma unroll
+                    for (int tt = 0; tt < NTL; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[tt], b0, acc[tt], 0, 0, 0);
+                    if (r < 14) {
+#pragma unroll
+                        for (int tt = 0; tt < NTL; ++tt) a0[tt] = pa[(((r + 2) & 3) + 8 * ((r + 2) >> 2)) * S + 32 * tt];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float b1 = fmaxf(t[r + 1], 0.0f);
+#pragma unroll
+                    for (int tt = 0; tt < NTL; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[tt], b1, acc[tt], 0, 0, 0);
                 }
             } else {
-                // backward through this n-tile: D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m], rows k = 32 c .. + 31; M = acc (see below)
+                // backward through this n-tile: D1part[k][m] = sum_{n in tile} W2[k][n] M[n][m], rows k = 32 c .. + 31; M[n][m] = d3q[m] W3[n]
+                // (h2[n][m] > 0) is rebuilt per k-step from one mask bit and the epilogue block in LDS (32 registers less than keeping it:
+                // with those the four-waves budget spilled, and a scratch reload in this loop waits for the chunk prefetch as well)
                 f32x16 g;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g[r] = 0.0f;
                 const float *pa = buf + li * S + 4 * lh;
+                const float *pe = ep + 16 * lh + 1;
+                // (operands of step i + 1 read before the product of step i is issued, as in the forward pass)
+                auto nbof = [](int i) { return 32 * (i >> 4) + (i & 3) + 8 * ((i & 15) >> 2); };
+                float aA = pa[0], wA = pe[0], aB, wB;
 #pragma unroll
-                for (int tt = 0; tt < NTL; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        g = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[32 * tt + (r & 3) + 8 * (r >> 2)], acc[tt][r], g, 0, 0, 0);
+                for (int i = 0; i < 16 * NTL; i += 2) {
+                    aB = pa[nbof(i + 1)]; wB = pe[nbof(i + 1) * 4];
+                    __builtin_amdgcn_sched_barrier(0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, (mbits >> i) & 1u ? wA * d3q : 0.0f, g, 0, 0, 0);
+                    if (i + 2 < 16 * NTL) { aA = pa[nbof(i + 2)]; wA = pe[nbof(i + 2) * 4]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, (mbits >> (i + 1)) & 1u ? wB * d3q : 0.0f, g, 0, 0, 0);
+                }
                 // layer-1 pre-activations for the mask only now: 16 fewer live registers under the product (with them the 128-register
                 // budget of four waves per SIMD spilled two of M's values, and a scratch reload waits for the chunk prefetch as well)
                 __builtin_amdgcn_sched_barrier(0);
@@ -372,7 +412,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
         }
     };
     pass(std::false_type{}, 0, QG);
-    // epilogue of the forward pass: bias, relu, store, layer-3 partials; QG: M[n][m] = d3q[m] W3[n] (h2 > 0) replaces acc
+    // epilogue of the forward pass: bias, relu, store, layer-3 partials; QG: the relu mask of the tile is kept, one bit per element
     auto epilogue = [&](auto keep) {
         constexpr bool KEEP = decltype(keep)::value;
         const float *epl = ep + 16 * lh;
@@ -391,7 +431,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
                     if constexpr (KEEP) hp[nb * BP] = h;
                     p0 = fmaf(h, e[1], p0);
                     p1 = fmaf(h, e[2], p1);
-                    if (QG) acc[tt][r] = h > 0.0f ? e[1] * d3q : 0.0f;
+                    if (QG && h > 0.0f) mbits |= 1u << (16 * tt + r);
                 }
             p0 += __shfl_xor(p0, 32, 64);
             p1 += __shfl_xor(p1, 32, 64);
@@ -494,7 +534,7 @@ __device__ __forceinline__ void head_actor(const NetArgs &A, const shems_ddpg &d
 // any LDS round trip (the bias gradient is the row of ones of the input block).  ADAM + soft update for the k-tile's layer-1 columns.
 // ================================================================================================================================
 constexpr int D1_S = 33;
-constexpr int D1_LDS = (2 * 64 * D1_S + 1024 + 2 * BP + 8) * 4;
+constexpr int D1_LDS = (2 * 64 * D1_S + 1024 + 2 * BP + 8 + W1K * BP + W1K * 64) * 4;
 static_assert(2 * 64 * D1_S >= 4 * 2 * 8 * 64, "the ring holds the four waves' gW1 partials");
 
 template <int IN>
@@ -506,6 +546,8 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     float *w3s = ring + 2 * 64 * D1_S;           // [512][2] frozen W3
     float *d3s = w3s + 1024;                     // [2][BP]
     float *red = d3s + 2 * BP;                   // [8]
+    float *xs = red + 8;                         // [12][BP] the input block        } operands of what follows the chunk loop: staged by the
+    float *wls = xs + W1K * BP;                  // [12][64] layer-1 image, k-tile  } prologue's requests, no round trip after the loop
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int kt = bx, k0 = 64 * kt;
     const int64_t off = (int64_t)by * A.gstride;
@@ -544,11 +586,20 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     float hc[16], hn[16];
     a_load(0, pv);
     h_load(0, hc);
-    {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(N::w3f(ws))[tid];
-        reinterpret_cast<f32x4 *>(w3s)[tid] = v;
-    }
+    const f32x4 w3v = reinterpret_cast<const f32x4 *>(N::w3f(ws))[tid];
+    const float *w1i = N::w1i(ws);
+    const float *X = N::X(ws);
+    float xv[6], wlv[3];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) xv[s] = X[s * 256 + tid];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wlv[s] = w1i[(4 * s + (tid >> 6)) * W1C + k0 + (tid & 63)];
     if (A.head == 1) head_critic(A, d, c, d3s, red, kt == 0); else head_actor(A, d, c, d3s, red, kt == 0);
+    reinterpret_cast<f32x4 *>(w3s)[tid] = w3v;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) xs[s * 256 + tid] = xv[s];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) wls[(4 * s + (tid >> 6)) * 64 + (tid & 63)] = wlv[s];
     a_store(ring, pv);
     __syncthreads();
     const float d30 = d3s[m], d31 = d3s[BP + m];
@@ -561,40 +612,65 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     // One n-chunk: the next chunk's weights and error-signal source are requested first and are not touched before the following step
     // (two register sets taken in turn: a copy `hc = hn` at the end of the step is moved up by the scheduler into the product, where its
     // wait for the just-issued loads -- loads retire in order -- stalls the matrix pipe every chunk).
-    auto step = [&](int q, const float (&hcur)[16], float (&hnext)[16]) {
+    auto step = [&](auto prefetch, int q, const float (&hcur)[16], float (&hnext)[16]) {
+        constexpr bool PF = decltype(prefetch)::value;
         const float *buf = ring + (q & 1) * 64 * D1_S;
-        // (unconditional -- the last step requests chunk 15 again: behind a branch the compiler's wait in front of hcur is the one of the
-        // path WITHOUT new requests, which on the other path waits for them)
-        a_load(min(q + 1, 15), pv); h_load(min(q + 1, 15), hnext);
+        // (never behind a run-time branch: the compiler's wait in front of hcur would be the one of the path WITHOUT new requests, which
+        // on the other path waits for them; the last step is a separate instance instead)
+        if constexpr (PF) { a_load(q + 1, pv); h_load(q + 1, hnext); }
         __builtin_amdgcn_sched_barrier(0);
         const float *pb = buf + li * D1_S + lh;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float2 w3 = *reinterpret_cast<const float2 *>(w3s + 2 * (32 * q + 2 * s + lh));
+        const float *pw = w3s + 2 * (32 * q + lh);
+        // (the LDS operands of k-step s + 1 are read before the products of step s are issued: read -> wait -> products leaves the LDS
+        // latency uncovered behind every pair)
+        float2 wA = *reinterpret_cast<const float2 *>(pw), wB;
+        float bA0 = pb[0], bA1 = pb[32 * D1_S], bB0, bB1;
+        auto prod = [&](int s, const float2 w3, float b0, float b1) {
             const float gsum = OUT == 2 ? fmaf(w3.y, d31, w3.x * d30) : w3.x * d30;
             const float d2 = hcur[s] > 0.0f ? gsum : 0.0f;
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[2 * s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, pb[32 * D1_S + 2 * s], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, b1, acc[1], 0, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            wB = *reinterpret_cast<const float2 *>(pw + 4 * (s + 1)); bB0 = pb[2 * (s + 1)]; bB1 = pb[32 * D1_S + 2 * (s + 1)];
+            __builtin_amdgcn_sched_barrier(0);
+            prod(s, wA, bA0, bA1);
+            if (s < 14) { wA = *reinterpret_cast<const float2 *>(pw + 4 * (s + 2)); bA0 = pb[2 * (s + 2)]; bA1 = pb[32 * D1_S + 2 * (s + 2)]; }
+            __builtin_amdgcn_sched_barrier(0);
+            prod(s + 1, wB, bB0, bB1);
         }
-        a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
+        if constexpr (PF) a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
         __syncthreads();
     };
 #pragma unroll 1
-    for (int q = 0; q < 16; q += 2) {
-        step(q, hc, hn);
-        step(q + 1, hn, hc);
+    for (int q = 0; q < 14; q += 2) {
+        step(std::true_type{}, q, hc, hn);
+        step(std::true_type{}, q + 1, hn, hc);
     }
+    step(std::true_type{}, 14, hc, hn);
+    step(std::false_type{}, 15, hn, hc);
+    // ---- this thread's four layer-1 elements: their ADAM state is requested now and arrives under the products below ----
+    int ei[4];
+    float em[4], ev[4], epp[4], et[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int sidx = u * 256 + tid, ln = sidx & 63, rr = (sidx >> 6) & 7, tt = sidx >> 9;
+        const int j = drow(rr, ln >> 5), k = k0 + 32 * tt + (ln & 31);
+        ei[u] = (k < H1N && (j < IN || j == W1K - 1)) ? (j == W1K - 1 ? off_b1(IN) + k : j * H1N + k) : -1;
+        const int e = max(ei[u], 0);
+        em[u] = c.mt[e]; ev[u] = c.vt[e]; epp[u] = c.p[e]; et[u] = c.target[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- layer-1 relu mask: pre-activations transposed, rows = samples of this wave's column tile, columns = the k-tile's units ----
-    const float *w1i = N::w1i(ws);
-    const float *X = N::X(ws);
     float xa[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) xa[s] = X[(2 * s + lh) * BP + m];
+    for (int s = 0; s < 6; ++s) xa[s] = xs[(2 * s + lh) * BP + m];
     // A operands of the layer-1 gradient: x[j = li][32 w + drow(r, lh)] (rows >= 12 zero)
     f32x4 xq[4];
     {
         const float keep = li < W1K ? 1.0f : 0.0f;
-        const float *px = X + min(li, W1K - 1) * BP + 32 * w + 4 * lh;
+        const float *px = xs + min(li, W1K - 1) * BP + 32 * w + 4 * lh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const f32x4 *>(px + 8 * q) * keep;
     }
@@ -603,7 +679,7 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     for (int tt = 0; tt < 2; ++tt) {
         float wb[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) wb[s] = w1i[(2 * s + lh) * W1C + k0 + 32 * tt + li];
+        for (int s = 0; s < 6; ++s) wb[s] = wls[(2 * s + lh) * 64 + 32 * tt + li];
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = 0.0f;
@@ -622,13 +698,25 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
         for (int r = 0; r < 8; ++r) redp[((w * 2 + tt) * 8 + r) * 64 + lane] = g[r];
     }
     __syncthreads();
+    // (consumed unconditionally: left to itself the compiler moves the requests above behind the `ei >= 0` that guards the stores)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(em[u]), "+v"(ev[u]), "+v"(epp[u]), "+v"(et[u]));
+    float *gP = const_cast<float *>(c.g);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int sidx = u * 256 + tid, ln = sidx & 63, rr = (sidx >> 6) & 7, tt = sidx >> 9;
         const float *pr = redp + (tt * 8 + rr) * 64 + ln;
         const float gsum = ((pr[0] + pr[2 * 8 * 64]) + pr[2 * 2 * 8 * 64]) + pr[3 * 2 * 8 * 64];
-        const int j = drow(rr, ln >> 5), k = k0 + 32 * tt + (ln & 31);
-        if (k < H1N && (j < IN || j == W1K - 1)) adam_at(c, j == W1K - 1 ? off_b1(IN) + k : j * H1N + k, gsum, A.store_grad != 0);
+        adam_math(c, gsum, em[u], ev[u], epp[u], et[u]);
+        if (ei[u] >= 0) {
+            const int e = ei[u];
+            c.mt[e] = em[u]; c.vt[e] = ev[u]; c.p[e] = epp[u]; c.target[e] = et[u];
+            if (A.store_grad != 0) gP[e] = gsum;
+            if constexpr (N::critic) {           // P5 runs the UPDATED critic: its layer-1 image, element by element (zeros from P0)
+                const int j = drow(rr, ln >> 5), k = k0 + 32 * tt + (ln & 31);
+                w1i_of(ws, IMG_CRITIC_NEW)[j * W1C + k] = epp[u];
+            }
+        }
     }
 }
 
@@ -743,9 +831,17 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
         for (int r = 0; r < 16; ++r) t[r] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 6; ++s) t = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wb[s], t, 0, 0, 0);       // h1'[m][k] pre-activations
+        // (B operand of k-step r + 1 read from LDS before the product of step r is issued)
+        float bA = pb[32 * mt], bB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), pb[32 * mt + (r & 3) + 8 * (r >> 2)], acc, 0, 0, 0);
+        for (int r = 0; r < 16; r += 2) {
+            bB = pb[32 * mt + ((r + 1) & 3) + 8 * ((r + 1) >> 2)];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r], 0.0f), bA, acc, 0, 0, 0);
+            if (r < 14) bA = pb[32 * mt + ((r + 2) & 3) + 8 * ((r + 2) >> 2)];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(t[r + 1], 0.0f), bB, acc, 0, 0, 0);
+        }
     }
     // the tile changes hands: accumulator layout -> LDS [64 k][68] (over the D2 panel, which every wave has finished reading) -> rows
     __syncthreads();
@@ -781,7 +877,7 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
 // ---- one launch per phase (the plain form: every learner of the group in the same phase) ---------------------------------------
 __global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A) { prep_body(A, blockIdx.x, blockIdx.y); }
 template <bool QG, int NTL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_tp_fwd(FwdArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTL == 4 ? 3 : 4, 4))) void k_tp_fwd(FwdArgs A)      // (the wide form's LDS allows three workgroups per CU)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     fwd_body<QG, NTL>(A, blockIdx.x, blockIdx.y, smem);
@@ -871,7 +967,7 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     U.f2.job[0] = FwdJob{d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
                          p3_of(ws, NET_CRITIC_T), nullptr, CIN, 1};
     // P5: updated critic on [s; actor(s)], forward + input gradient
-    U.f5.job[0] = FwdJob{d->critic, ws + TP_X, nullptr, p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
+    U.f5.job[0] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, IMG_CRITIC_NEW), p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
                          ws + TP_DAP, CIN, 1};
     U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg};
     U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg};
