@@ -1,5 +1,5 @@
 # A/B of builds of the library inside ONE gpurun call (box-to-box spread is ~2.5 %, more than most single changes):
-#   gpurun -- 'bash tools/ab_lib.sh abl/lib_A.so abl/lib_B.so'
+#   gpurun -- 'bash tools/ab_libs_group.sh abl/lib_A.so abl/lib_B.so'
 # runs `bench.py --mode group` (400 learners x 128 envs) alternately on each library (SHEMS_HIP_LIB), three rounds, and prints ms per step.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for round in 1 2 3; do
