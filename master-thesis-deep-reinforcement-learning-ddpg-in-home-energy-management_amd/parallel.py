@@ -24,7 +24,8 @@ def native_comm(dist, timeout_s=120.0, log=None):
     None when it cannot be had -- then the caller keeps torch.distributed's all_reduce.  Collective: every rank calls it.
 
     Rank 0 draws the 128-byte id and torch.distributed broadcasts it; ncclCommInitRank runs in a helper thread so that a rendezvous that
-    never completes cannot hang the job (the thread is abandoned after `timeout_s`); the ranks then agree (MIN over a flag) whether ALL of
+    never completes cannot hang the job (after `timeout_s` the attempt is marked dead: a thread that completes later destroys its own
+    communicator); the ranks then agree (MIN over a flag) whether ALL of
     them have a communicator and a tiny all-reduce through it gave the right sum -- one rank without it and everybody falls back.
     SHEMS_DP=torch skips the attempt."""
     import ctypes as C
@@ -55,7 +56,10 @@ def native_comm(dist, timeout_s=120.0, log=None):
     flag = torch.tensor([ok], device=dev)
     dist.broadcast(flag, src=0)
     handle = C.c_void_p()
-    state = {"rc": None}
+    # The helper thread works on its OWN handle and hands it over under the lock; an attempt given up on is marked dead, and a rendezvous
+    # that completes after that destroys its communicator itself instead of leaving a live one nobody owns.
+    state = {"rc": None, "dead": False, "handle": None}
+    lock = threading.Lock()
     mine = 0.0
     try:                                            # whatever goes wrong on this rank, it still reaches the vote below
         if float(flag.item()) > 0.5:
@@ -64,10 +68,22 @@ def native_comm(dist, timeout_s=120.0, log=None):
 
             def init():
                 torch.cuda.set_device(cur)          # HIP's current device is per thread
-                state["rc"] = L.shems_dp_create(idb, rank, world, C.byref(handle))
+                h = C.c_void_p()
+                rc = L.shems_dp_create(idb, rank, world, C.byref(h))
+                with lock:
+                    if state["dead"]:
+                        if rc == 0 and h.value:
+                            L.shems_dp_destroy(h)
+                    else:
+                        state["rc"], state["handle"] = rc, h
             th = threading.Thread(target=init, daemon=True)
             th.start()
             th.join(timeout_s)
+            with lock:
+                if state["handle"] is None:
+                    state["dead"] = True            # timed out (or still running): whatever it produces later is its own to destroy
+                else:
+                    handle = state["handle"]
         mine = 1.0 if state["rc"] == 0 and handle.value else 0.0
         if mine:
             # self-test: sum of (rank + 1) over the replicas through the new communicator, in this thread's current stream

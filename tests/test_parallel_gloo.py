@@ -101,3 +101,62 @@ def test_shard_envs_partition():
     assert P.shard_envs(65536, 3, 8) == (3 * 8192, 8192)
     g = P.GradSync(None)
     assert g.world == 1 and g.grad_scale == 1.0 and g.mean_scalar(3.5) == 3.5
+
+
+def test_native_comm_gives_up_a_late_rendezvous_and_the_late_thread_destroys_its_own_communicator(monkeypatch):
+    """the helper thread of native_comm used to write into the caller's handle after it had been abandoned -- a
+    rendezvous completing late left a live communicator nobody destroyed.  With a stand-in library whose create() takes longer than the
+    timeout: the call returns None (vote), and the late thread destroys what it created, exactly once."""
+    import importlib
+    import threading
+    import time
+    import types
+    import torch
+    import torch.distributed as dist
+    P = importlib.import_module(U.PKG_NAME + ".parallel")
+    capi = importlib.import_module(U.PKG_NAME + "._capi")
+    destroyed, created = [], threading.Event()
+
+    def unique_id(buf):
+        return 0
+
+    def create(idb, rank, world, href):
+        time.sleep(0.6)
+        href._obj.value = 0x1234
+        created.set()
+        return 0
+
+    def destroy(h):
+        destroyed.append(h.value)
+        return 0
+
+    def allreduce(*a):
+        raise AssertionError("the self-test must not run on an attempt that was given up")
+
+    def last_error():
+        return b"stand-in"
+    fake = types.SimpleNamespace(shems_dp_unique_id=unique_id, shems_dp_create=create, shems_dp_destroy=destroy,
+                                 shems_dp_allreduce_sum=allreduce, shems_last_error=last_error)
+    monkeypatch.setattr(capi, "lib", lambda: fake)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        msgs = []
+        assert P.native_comm(dist, timeout_s=0.1, log=msgs.append) is None and msgs
+        assert destroyed == []                          # nothing existed yet when the attempt was given up
+        assert created.wait(5.0)
+        for _ in range(50):
+            if destroyed:
+                break
+            time.sleep(0.02)
+        assert destroyed == [0x1234]
+        # and an attempt that completes in time hands its handle over (self-test fails on the stand-in -> dropped and destroyed by the caller)
+        destroyed.clear()
+        fake.shems_dp_allreduce_sum = lambda *a: 1
+        assert P.native_comm(dist, timeout_s=5.0, log=msgs.append) is None
+        assert destroyed == [0x1234]
+    finally:
+        dist.destroy_process_group()
