@@ -10,8 +10,11 @@
 //   * plain back-propagation (no E slabs): per learner ten products, every one a stream of 32-deep weight chunks through a small
 //     LDS ring against operands that live in REGISTERS in the MFMA layout (layer 1 is recomputed per chunk on the matrix pipe --
 //     K = 12 -- and its D layout IS the next product's B operand; error signals are loaded from HBM straight into operand layout);
-//   * 17-34 KB of LDS and <= 128 VGPRs per workgroup: 4 workgroups (16 waves) resident per CU, so one workgroup's barrier / global
-//     latency is covered by the others' MFMAs without any hand scheduling;
+//   * 30-47 KB of LDS and 94-143 VGPRs per workgroup: 3-4 workgroups (12-16 waves) resident per CU, so one workgroup's barrier / global
+//     latency is covered by the others' MFMAs;
+//   * loads retire in order (s_waitcnt vmcnt counts from the oldest): every kernel issues LAST what it will wait for last -- the next
+//     weight chunk is never waited for inside the chunk that requested it, the W2 tile's ADAM state is requested after every small operand
+//     and arrives under the product (what this cost before it was looked for in the ISA: profiles/NOTES.md, round-5 log);
 //   * activations that must cross a launch (relu(layer 2) of the two differentiated networks, 256 KB each) are written once and
 //     read from L2 / Infinity Cache; layer-1 activations are never stored; gradients are never stored (ADAM + the soft target
 //     update are applied by the lane that holds the finished element; SHEMS_TP_STORE_GRAD keeps the gradient for the tests).
@@ -21,7 +24,7 @@
 //                  four networks and frozen output layers (the in-place updates below must not be read half-way)
 //   P1 k_tp_fwd    actor_target(s') | critic(s, a) | actor(s)                                      (DDPG.jl:131, 114-119)
 //   P2 k_tp_fwd    critic_target(s', a')                                                           (DDPG.jl:132)
-//   P3 k_tp_d1     y, dq = d mse / dq; D1 = mask1 .* (W2 D2); layer-1 gradient + ADAM; b3 gradient + ADAM   (DDPG.jl:133-137)
+//   P3 k_tp_d1     y, dq = d mse / dq; D1 = mask1 .* (W2 D2); layer-1 gradient + ADAM (+ the updated layer-1 image P5 reads); b3   (DDPG.jl:133-137)
 //   P4 k_tp_gw2    gW2 = h1 D2' + ADAM + soft update per tile; gb2, gW3 + ADAM
 //   P5 k_tp_fwd<QG> updated critic on [s; actor(s)], forward and input gradient per n-tile          (DDPG.jl:117-119, 140)
 //   P6 k_tp_d1     actor: through tanh, D1, layer-1 gradient + ADAM
