@@ -7,9 +7,12 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// shader cycles (s_memtime) per 100-MHz tick (s_memrealtime) seen by workgroup 0's first wave over the whole loop: the clock under this load
+__device__ unsigned long long g_clk[2];
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, float b)
 {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
@@ -28,6 +31,7 @@ __global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
 static int g_lds = 0;       // dynamic LDS per workgroup: caps the workgroups a CU can hold (160 KB / g_lds) without touching the kernel
@@ -49,10 +53,13 @@ static void run(int wgs_per_cu, int iters, float *out, int rounds = 1)
         float ms; hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best; sum += ms;
     }
+    unsigned long long clk[2];
+    (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk);
+    const double ghz = (double)clk[0] / ((double)clk[1] * 10e-9) * 1e-9;
     const double flop = (double)grid * 4.0 * iters * 4.0 * NACC * 4096.0;
-    printf("lds %6d rounds %d accs/wave %d  waves/SIMD %d  iters %6d  avg %.1f us  best %.1f us  %.1f TFLOP/s avg (%.3f of 157.3)  %.1f best (%.3f)\n", g_lds, rounds, NACC, wgs_per_cu, iters,
+    printf("lds %6d rounds %d accs/wave %d  waves/SIMD %d  iters %6d  avg %.1f us  best %.1f us  %.1f TFLOP/s avg (%.3f of 157.3)  %.1f best (%.3f)  shader clock %.2f GHz\n", g_lds, rounds, NACC, wgs_per_cu, iters,
            sum / reps * 1e3, best * 1e3, flop / (sum / reps * 1e-3) * 1e-12, flop / (sum / reps * 1e-3) * 1e-12 / 157.3, flop / (best * 1e-3) * 1e-12,
-           flop / (best * 1e-3) * 1e-12 / 157.3);
+           flop / (best * 1e-3) * 1e-12 / 157.3, ghz);
 }
 
 int main()
