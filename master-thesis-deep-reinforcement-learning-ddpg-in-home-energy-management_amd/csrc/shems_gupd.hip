@@ -460,6 +460,7 @@ struct NetArgs {
     int64_t gstride;
     int head;              // 1 = critic loss head, 2 = actor head
     int store_grad;
+    int learners;
 };
 template <int IN> struct NetOf {
     static constexpr bool critic = IN == CIN;
@@ -889,7 +890,12 @@ template <int IN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    d1_body<IN>(A, blockIdx.x, blockIdx.y, smem);
+    // A learner's four k-tile workgroups read the same 256 KB of relu(layer 2): they are placed on ONE XCD (workgroup id mod 8 picks the
+    // XCD and its L2), consecutive in its dispatch order -- learner = 8 (q / 4) + xcd, k-tile = q mod 4 with q = id / 8.
+    const unsigned id = blockIdx.x, xcd = id & 7u, q = id >> 3;
+    const unsigned learner = 8u * (q >> 2) + xcd;
+    if (learner >= (unsigned)A.learners) return;
+    d1_body<IN>(A, (int)(q & 3u), (int)learner, smem);
 }
 template <int IN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
@@ -972,18 +978,18 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     // P5: updated critic on [s; actor(s)], forward + input gradient
     U.f5.job[0] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, IMG_CRITIC_NEW), p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
                          ws + TP_DAP, CIN, 1};
-    U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg};
-    U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg};
+    U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg, (int)L};
+    U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg, (int)L};
     hipLaunchKernelGGL(k_tp_prep, dim3(5, L), dim3(256), 0, st, U.pa);
     typedef FwdShape<false, 4> SW;           // (typedefs: the launch macro splits its arguments at the commas of a template argument list)
     typedef FwdShape<false, 2> SN;
     typedef FwdShape<true, 2> SQ;
     hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
     hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
-    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(4, L), dim3(256), D1_LDS, st, U.nc);
+    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(32 * ((L + 7) / 8)), dim3(256), D1_LDS, st, U.nc);
     hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
     hipLaunchKernelGGL((k_tp_fwd<true, 2>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
-    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(4, L), dim3(256), D1_LDS, st, U.na);
+    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(32 * ((L + 7) / 8)), dim3(256), D1_LDS, st, U.na);
     hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
 }
