@@ -10,8 +10,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // shader cycles (s_memtime) per 100-MHz tick (s_memrealtime) seen by workgroup 0's first wave over the whole loop: the clock under this load
 __device__ unsigned long long g_clk[2];
 template <int NACC>
-__global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, float b)
+__global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, float b, int stagger = 0)
 {
+    if (stagger) for (int i = 0; i < (int)((blockIdx.x >> 8) & 3) * stagger; ++i) __builtin_amdgcn_s_sleep(16);
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[NACC];
 #pragma unroll
@@ -34,20 +35,20 @@ __global__ __launch_bounds__(256) void k_mfma(float *out, int iters, float a, fl
     if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-static int g_lds = 0;       // dynamic LDS per workgroup: caps the workgroups a CU can hold (160 KB / g_lds) without touching the kernel
+static int g_lds = 0, g_stagger = 0;       // dynamic LDS per workgroup: caps the workgroups a CU can hold (160 KB / g_lds) without touching the kernel
 template <int NACC>
 static void run(int wgs_per_cu, int iters, float *out, int rounds = 1)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = 256 * wgs_per_cu * rounds;
-    hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), g_lds, 0, out, iters, 1.0f, 0.5f);
+    hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), g_lds, 0, out, iters, 1.0f, 0.5f, g_stagger);
     hipDeviceSynchronize();
     float best = 1e30f, sum = 0.0f;
     const int reps = 20;
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), g_lds, 0, out, iters, 1.0f, 0.5f);
+        hipLaunchKernelGGL(k_mfma<NACC>, dim3(grid), dim3(256), g_lds, 0, out, iters, 1.0f, 0.5f, g_stagger);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -65,12 +66,20 @@ static void run(int wgs_per_cu, int iters, float *out, int rounds = 1)
 int main()
 {
     float *out; hipMalloc(&out, 256 * 64 * 256 * sizeof(float));
-    // (1) does the 4 x 4 case lose to uneven placement?  LDS sized so that a CU cannot hold more than 4 (then 3) workgroups
-    for (int lds : {0, 33 * 1024, 41 * 1024, 54 * 1024}) {
-        g_lds = lds;
-        run<4>(4, 400, out); run<4>(3, 400, out); run<2>(4, 800, out); run<4>(4, 100, out, 6); run<4>(3, 100, out, 6); run<2>(4, 200, out, 6);
+    // one exact generation of workgroups: 16 accumulator tiles per SIMD in flight however they are split over waves?
+    for (int st : {0, 1, 7}) {
+        g_stagger = st;
+        printf("stagger %d (workgroup generation b / 256 sleeps b * %d * 1024 cycles first)\n", st, st);
+        g_lds = 33792; run<4>(4, 400, out); run<2>(4, 800, out); run<4>(3, 400, out);
+        g_lds = 70000; run<8>(2, 200, out); run<4>(2, 400, out); run<8>(2, 50, out, 4);
+        g_lds = 150000; run<8>(1, 400, out); 
     }
+    g_stagger = 0;
     g_lds = 0;
     for (int iters : {100, 1600}) { run<4>(1, iters, out); run<4>(2, iters, out); run<2>(4, iters, out); run<1>(4, iters, out); }
+    for (int r = 0; r < 500; ++r) hipLaunchKernelGGL(k_mfma<4>, dim3(1024), dim3(256), 0, 0, out, 3200, 1.0f, 0.5f, 0);
+    hipDeviceSynchronize();
+    printf("after ~2 s of continuous matrix work:\n");
+    run<2>(4, 6400, out);
     return 0;
 }
