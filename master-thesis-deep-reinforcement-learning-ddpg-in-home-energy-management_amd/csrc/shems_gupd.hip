@@ -538,22 +538,26 @@ __device__ __forceinline__ void head_actor(const NetArgs &A, const shems_ddpg &d
 // any LDS round trip (the bias gradient is the row of ones of the input block).  ADAM + soft update for the k-tile's layer-1 columns.
 // ================================================================================================================================
 constexpr int D1_S = 33;
-constexpr int D1_LDS = (2 * 64 * D1_S + 1024 + 2 * BP + 8 + W1K * BP + W1K * 64) * 4;
-static_assert(2 * 64 * D1_S >= 4 * 2 * 8 * 64, "the ring holds the four waves' gW1 partials");
+constexpr unsigned kNarrowBelow = 48;
+// KT = 32-wide sub-tiles per workgroup: 2 = a 64-wide k-tile (four workgroups per learner -- the form for wide groups, fewest reads of
+// relu(layer 2)); 1 = a 32-wide one (eight per learner: with few learners four do not fill the chip -- 128 workgroups at 32 learners)
+constexpr int d1_ring(int KT) { return 2 * 32 * KT * D1_S > 4 * KT * 8 * 64 ? 2 * 32 * KT * D1_S : 4 * KT * 8 * 64; }      // floats: the ring, later the four waves' gW1 partials
+constexpr int d1_lds(int KT) { return (d1_ring(KT) + 1024 + 2 * BP + 8 + W1K * BP + W1K * 32 * KT) * 4; }
 
-template <int IN>
+template <int IN, int KT>
 __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const int by, float *smem)
 {
     typedef NetOf<IN> N;
     constexpr int OUT = N::OUT;
-    float *ring = smem;                          // [2][64 k][33]
-    float *w3s = ring + 2 * 64 * D1_S;           // [512][2] frozen W3
+    constexpr int KW = 32 * KT;                  // k-tile width
+    float *ring = smem;                          // [2][KW k][33]
+    float *w3s = ring + d1_ring(KT);             // [512][2] frozen W3
     float *d3s = w3s + 1024;                     // [2][BP]
     float *red = d3s + 2 * BP;                   // [8]
     float *xs = red + 8;                         // [12][BP] the input block        } operands of what follows the chunk loop: staged by the
-    float *wls = xs + W1K * BP;                  // [12][64] layer-1 image, k-tile  } prologue's requests, no round trip after the loop
+    float *wls = xs + W1K * BP;                  // [12][KW] layer-1 image, k-tile  } prologue's requests, no round trip after the loop
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-    const int kt = bx, k0 = 64 * kt;
+    const int kt = bx, k0 = KW * kt;
     const int64_t off = (int64_t)by * A.gstride;
     shems_ddpg d = A.d;
     AdamCtx c = A.c;
@@ -566,16 +570,16 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 
     // A chunk q: W2[k0 .. k0 + 63][32 q .. 32 q + 31] (128 B per row), two float4 per thread; rows >= 250 clamped (their outputs are
     // never stored), columns >= 500 of the last chunk meet D2 rows that are exactly zero
-    auto a_load = [&](int q, f32x4 (&v)[2]) {
+    auto a_load = [&](int q, f32x4 (&v)[KT]) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < KT; ++it) {
             const int e = it * 256 + tid, k = min(k0 + (e >> 3), H1N - 1);
             v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + 32 * q + 4 * (e & 7));
         }
     };
-    auto a_store = [&](float *buf, const f32x4 (&v)[2]) {
+    auto a_store = [&](float *buf, const f32x4 (&v)[KT]) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < KT; ++it) {
             const int e = it * 256 + tid;
             float *p = buf + (e >> 3) * D1_S + 4 * (e & 7);
             p[0] = v[it][0]; p[1] = v[it][1]; p[2] = v[it][2]; p[3] = v[it][3];
@@ -586,31 +590,32 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 #pragma unroll
         for (int s = 0; s < 16; ++s) h[s] = H2[(int64_t)(32 * q + 2 * s + lh) * BP + m];
     };
-    f32x4 pv[2];
+    f32x4 pv[KT];
     float hc[16], hn[16];
     a_load(0, pv);
     h_load(0, hc);
     const f32x4 w3v = reinterpret_cast<const f32x4 *>(N::w3f(ws))[tid];
     const float *w1i = N::w1i(ws);
     const float *X = N::X(ws);
-    float xv[6], wlv[3];
+    constexpr int WLN = (W1K * KW + 255) / 256;          // 3 (KT = 2) / 2 (KT = 1: 384 floats)
+    float xv[6], wlv[WLN];
 #pragma unroll
     for (int s = 0; s < 6; ++s) xv[s] = X[s * 256 + tid];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) wlv[s] = w1i[(4 * s + (tid >> 6)) * W1C + k0 + (tid & 63)];
+    for (int s = 0; s < WLN; ++s) { const int e = min(s * 256 + tid, W1K * KW - 1); wlv[s] = w1i[(e / KW) * W1C + k0 + e % KW]; }
     if (A.head == 1) head_critic(A, d, c, d3s, red, kt == 0); else head_actor(A, d, c, d3s, red, kt == 0);
     reinterpret_cast<f32x4 *>(w3s)[tid] = w3v;
 #pragma unroll
     for (int s = 0; s < 6; ++s) xs[s * 256 + tid] = xv[s];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) wls[(4 * s + (tid >> 6)) * 64 + (tid & 63)] = wlv[s];
+    for (int s = 0; s < WLN; ++s) if (s * 256 + tid < W1K * KW) wls[s * 256 + tid] = wlv[s];
     a_store(ring, pv);
     __syncthreads();
     const float d30 = d3s[m], d31 = d3s[BP + m];
 
-    f32x16 acc[2];
+    f32x16 acc[KT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < KT; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
     // One n-chunk: the next chunk's weights and error-signal source are requested first and are not touched before the following step
@@ -618,7 +623,7 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     // wait for the just-issued loads -- loads retire in order -- stalls the matrix pipe every chunk).
     auto step = [&](auto prefetch, int q, const float (&hcur)[16], float (&hnext)[16]) {
         constexpr bool PF = decltype(prefetch)::value;
-        const float *buf = ring + (q & 1) * 64 * D1_S;
+        const float *buf = ring + (q & 1) * KW * D1_S;
         // (never behind a run-time branch: the compiler's wait in front of hcur would be the one of the path WITHOUT new requests, which
         // on the other path waits for them; the last step is a separate instance instead)
         if constexpr (PF) { a_load(q + 1, pv); h_load(q + 1, hnext); }
@@ -628,23 +633,24 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
         // (the LDS operands of k-step s + 1 are read before the products of step s are issued: read -> wait -> products leaves the LDS
         // latency uncovered behind every pair)
         float2 wA = *reinterpret_cast<const float2 *>(pw), wB;
-        float bA0 = pb[0], bA1 = pb[32 * D1_S], bB0, bB1;
+        constexpr int T1 = KT == 2 ? 32 * D1_S : 0;          // second sub-tile's rows (KT = 1: the same operand, unused)
+        float bA0 = pb[0], bA1 = pb[T1], bB0, bB1;
         auto prod = [&](int s, const float2 w3, float b0, float b1) {
             const float gsum = OUT == 2 ? fmaf(w3.y, d31, w3.x * d30) : w3.x * d30;
             const float d2 = hcur[s] > 0.0f ? gsum : 0.0f;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, b1, acc[1], 0, 0, 0);
+            if constexpr (KT == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2, b1, acc[1], 0, 0, 0);
         };
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
-            wB = *reinterpret_cast<const float2 *>(pw + 4 * (s + 1)); bB0 = pb[2 * (s + 1)]; bB1 = pb[32 * D1_S + 2 * (s + 1)];
+            wB = *reinterpret_cast<const float2 *>(pw + 4 * (s + 1)); bB0 = pb[2 * (s + 1)]; bB1 = pb[T1 + 2 * (s + 1)];
             __builtin_amdgcn_sched_barrier(0);
             prod(s, wA, bA0, bA1);
-            if (s < 14) { wA = *reinterpret_cast<const float2 *>(pw + 4 * (s + 2)); bA0 = pb[2 * (s + 2)]; bA1 = pb[32 * D1_S + 2 * (s + 2)]; }
+            if (s < 14) { wA = *reinterpret_cast<const float2 *>(pw + 4 * (s + 2)); bA0 = pb[2 * (s + 2)]; bA1 = pb[T1 + 2 * (s + 2)]; }
             __builtin_amdgcn_sched_barrier(0);
             prod(s + 1, wB, bB0, bB1);
         }
-        if constexpr (PF) a_store(ring + ((q + 1) & 1) * 64 * D1_S, pv);
+        if constexpr (PF) a_store(ring + ((q + 1) & 1) * KW * D1_S, pv);
         __syncthreads();
     };
 #pragma unroll 1
@@ -655,10 +661,11 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
     step(std::true_type{}, 14, hc, hn);
     step(std::false_type{}, 15, hn, hc);
     // ---- this thread's four layer-1 elements: their ADAM state is requested now and arrives under the products below ----
-    int ei[4];
-    float em[4], ev[4], epp[4], et[4];
+    constexpr int NE = 2 * KT;                   // elements per thread: [KT tt][8 r][64 lanes] over 256 threads
+    int ei[NE];
+    float em[NE], ev[NE], epp[NE], et[NE];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NE; ++u) {
         const int sidx = u * 256 + tid, ln = sidx & 63, rr = (sidx >> 6) & 7, tt = sidx >> 9;
         const int j = drow(rr, ln >> 5), k = k0 + 32 * tt + (ln & 31);
         ei[u] = (k < H1N && (j < IN || j == W1K - 1)) ? (j == W1K - 1 ? off_b1(IN) + k : j * H1N + k) : -1;
@@ -678,12 +685,12 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 #pragma unroll
         for (int q = 0; q < 4; ++q) xq[q] = *reinterpret_cast<const f32x4 *>(px + 8 * q) * keep;
     }
-    float *redp = ring;                          // [4 waves][2 tt][8 r][64 lanes]  (the ring is free: the loop ended with a barrier)
+    float *redp = ring;                          // [4 waves][KT tt][8 r][64 lanes]  (the ring is free: the loop ended with a barrier)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < KT; ++tt) {
         float wb[6];
 #pragma unroll
-        for (int s = 0; s < 6; ++s) wb[s] = wls[(2 * s + lh) * 64 + 32 * tt + li];
+        for (int s = 0; s < 6; ++s) wb[s] = wls[(2 * s + lh) * KW + 32 * tt + li];
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = 0.0f;
@@ -699,18 +706,18 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
         }
         // rows j = drow(r, lh) < 12: r = 0..3 (both halves), r = 4..7 (lh = 0)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) redp[((w * 2 + tt) * 8 + r) * 64 + lane] = g[r];
+        for (int r = 0; r < 8; ++r) redp[((w * KT + tt) * 8 + r) * 64 + lane] = g[r];
     }
     __syncthreads();
     // (consumed unconditionally: left to itself the compiler moves the requests above behind the `ei >= 0` that guards the stores)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(em[u]), "+v"(ev[u]), "+v"(epp[u]), "+v"(et[u]));
+    for (int u = 0; u < NE; ++u) asm volatile("" : "+v"(em[u]), "+v"(ev[u]), "+v"(epp[u]), "+v"(et[u]));
     float *gP = const_cast<float *>(c.g);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NE; ++u) {
         const int sidx = u * 256 + tid, ln = sidx & 63, rr = (sidx >> 6) & 7, tt = sidx >> 9;
         const float *pr = redp + (tt * 8 + rr) * 64 + ln;
-        const float gsum = ((pr[0] + pr[2 * 8 * 64]) + pr[2 * 2 * 8 * 64]) + pr[3 * 2 * 8 * 64];
+        const float gsum = ((pr[0] + pr[KT * 8 * 64]) + pr[2 * KT * 8 * 64]) + pr[3 * KT * 8 * 64];
         adam_math(c, gsum, em[u], ev[u], epp[u], et[u]);
         if (ei[u] >= 0) {
             const int e = ei[u];
@@ -886,16 +893,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTL == 4 ? 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     fwd_body<QG, NTL>(A, blockIdx.x, blockIdx.y, smem);
 }
-template <int IN>
+template <int IN, int KT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // A learner's four k-tile workgroups read the same 256 KB of relu(layer 2): they are placed on ONE XCD (workgroup id mod 8 picks the
-    // XCD and its L2), consecutive in its dispatch order -- learner = 8 (q / 4) + xcd, k-tile = q mod 4 with q = id / 8.
+    // A learner's k-tile workgroups (T = 8 / KT of them) read the same 256 KB of relu(layer 2): they are placed on ONE XCD (workgroup id
+    // mod 8 picks the XCD and its L2), consecutive in its dispatch order -- learner = 8 (q / T) + xcd, k-tile = q mod T with q = id / 8.
+    constexpr unsigned T = 8 / KT;
     const unsigned id = blockIdx.x, xcd = id & 7u, q = id >> 3;
-    const unsigned learner = 8u * (q >> 2) + xcd;
+    const unsigned learner = 8u * (q / T) + xcd;
     if (learner >= (unsigned)A.learners) return;
-    d1_body<IN>(A, (int)(q & 3u), (int)learner, smem);
+    d1_body<IN, KT>(A, (int)(q % T), (int)learner, smem);
 }
 template <int IN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
@@ -918,8 +926,8 @@ static int set_attrs()
     if (int rc = lds_optin(m0, reinterpret_cast<const void *>(&k_tp_fwd<false, 4>), l4, "attr k_tp_fwd")) return rc;
     if (int rc = lds_optin(m01, reinterpret_cast<const void *>(&k_tp_fwd<false, 2>), l2, "attr k_tp_fwd")) return rc;
     if (int rc = lds_optin(m1, reinterpret_cast<const void *>(&k_tp_fwd<true, 2>), lq, "attr k_tp_fwd<QG>")) return rc;
-    if (int rc = lds_optin(m2, reinterpret_cast<const void *>(&k_tp_d1<CIN>), D1_LDS, "attr k_tp_d1")) return rc;
-    if (int rc = lds_optin(m3, reinterpret_cast<const void *>(&k_tp_d1<SIN>), D1_LDS, "attr k_tp_d1")) return rc;
+    if (int rc = lds_optin(m2, reinterpret_cast<const void *>(&k_tp_d1<CIN, 2>), d1_lds(2), "attr k_tp_d1")) return rc;
+    if (int rc = lds_optin(m3, reinterpret_cast<const void *>(&k_tp_d1<SIN, 2>), d1_lds(2), "attr k_tp_d1")) return rc;
     if (int rc = lds_optin(m4, reinterpret_cast<const void *>(&k_tp_gw2<CIN>), GW_LDS, "attr k_tp_gw2")) return rc;
     if (int rc = lds_optin(m5, reinterpret_cast<const void *>(&k_tp_gw2<SIN>), GW_LDS, "attr k_tp_gw2")) return rc;
     return SHEMS_OK;
@@ -984,12 +992,20 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     typedef FwdShape<false, 4> SW;           // (typedefs: the launch macro splits its arguments at the commas of a template argument list)
     typedef FwdShape<false, 2> SN;
     typedef FwdShape<true, 2> SQ;
-    hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
+    // Few learners: the shapes with twice the workgroups (P1 on 64-wide n-tiles, P3 / P6 on 32-wide k-tiles).  Below kNarrowBelow learners
+    // the wide shapes leave CUs without work (P3 at 32 learners: 128 workgroups); measured per grouped update, wide / narrow: 32 learners
+    // 247 / 226 us, 48 learners 322 / 320, 64 learners 362 / 372, 128 learners 669 / 695 (profiles/NOTES.md, round-5 log).
+    const bool narrow1 = L < kNarrowBelow, narrow = narrow1;
+    if (narrow1) hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(3 * SN::TILES, L), dim3(256), SN::LDS, st, U.f1);
+    else hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
     hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
-    hipLaunchKernelGGL(k_tp_d1<CIN>, dim3(32 * ((L + 7) / 8)), dim3(256), D1_LDS, st, U.nc);
+    const unsigned g8 = 8 * ((L + 7) / 8);
+    if (narrow) hipLaunchKernelGGL((k_tp_d1<CIN, 1>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.nc);
+    else hipLaunchKernelGGL((k_tp_d1<CIN, 2>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.nc);
     hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
     hipLaunchKernelGGL((k_tp_fwd<true, 2>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
-    hipLaunchKernelGGL(k_tp_d1<SIN>, dim3(32 * ((L + 7) / 8)), dim3(256), D1_LDS, st, U.na);
+    if (narrow) hipLaunchKernelGGL((k_tp_d1<SIN, 1>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.na);
+    else hipLaunchKernelGGL((k_tp_d1<SIN, 2>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.na);
     hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
 }

@@ -122,7 +122,7 @@ def _relu_margin(p, x, in_dim, out_dim):
     return min(float(np.abs(z1).min()), float(np.abs(z2).min()))
 
 
-@pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17), (11, 120)])
+@pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17), (11, 120), (48, 120)])      # < 48 learners: the narrow launch shapes; 48: the wide ones
 def test_throughput_form_matches_float64_oracle_per_block(L, batch):
     import test_ddpg_gpu as TD
     ties = []
