@@ -995,8 +995,8 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     // Few learners: the shapes with twice the workgroups (P1 on 64-wide n-tiles, P3 / P6 on 32-wide k-tiles).  Below kNarrowBelow learners
     // the wide shapes leave CUs without work (P3 at 32 learners: 128 workgroups); measured per grouped update, wide / narrow: 32 learners
     // 247 / 226 us, 48 learners 322 / 320, 64 learners 362 / 372, 128 learners 669 / 695 (profiles/NOTES.md, round-5 log).
-    const bool narrow1 = L < kNarrowBelow, narrow = narrow1;
-    if (narrow1) hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(3 * SN::TILES, L), dim3(256), SN::LDS, st, U.f1);
+    const bool narrow = L < kNarrowBelow;
+    if (narrow) hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(3 * SN::TILES, L), dim3(256), SN::LDS, st, U.f1);
     else hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
     hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
     const unsigned g8 = 8 * ((L + 7) / 8);
