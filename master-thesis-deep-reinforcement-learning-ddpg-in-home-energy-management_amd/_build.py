@@ -50,18 +50,22 @@ def _deps(src):
 
 
 def build(force=False, verbose=False, defines=(), tag=""):
-    """defines / tag: a diagnostic variant (e.g. defines=("SHEMS_STAMP",), tag="_stamp" -> libshems_hip_stamp.so with in-kernel
-    phase stamps, tools/stamp_update.py); the product library is the default call."""
+    """defines / tag: a diagnostic variant (e.g. defines=("SHEMS_STAMP",), tag="_stamp" -> build/libshems_hip_stamp.so with in-kernel
+    phase stamps, tools/stamp_update.py); the product library is the default call.  Variants are built on demand under <repo>/build/
+    (objects and library), never in the package directory: only the product library ships with the package."""
     hipcc = _hipcc()
     objs = []
     rebuilt = False
-    lib = os.path.join(HERE, f"libshems_hip{tag}.so")
+    outdir = HERE if not tag else os.path.join(ROOT, "build")
+    objdir = CSRC if not tag else outdir
+    os.makedirs(outdir, exist_ok=True)
+    lib = os.path.join(outdir, f"libshems_hip{tag}.so")
     for name, extra in UNITS:
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             continue
         extra = list(extra) + ["-D" + d for d in defines]
-        obj = os.path.join(CSRC, name.rsplit(".", 1)[0] + tag + ".o")
+        obj = os.path.join(objdir, name.rsplit(".", 1)[0] + tag + ".o")
         stale = force or not os.path.exists(obj) or any(os.path.getmtime(p) > os.path.getmtime(obj) for p in _deps(src))
         if stale:
             cmd = [hipcc, *COMMON, *extra, "-c", src, "-o", obj]

@@ -1,7 +1,7 @@
 """In-kernel phase stamps of one DDPG update (diagnostic build, never the product library).
 
     python <package>/_build.py --stamp                      # libshems_hip_stamp.so (-DSHEMS_STAMP)
-    SHEMS_HIP_LIB=<package>/libshems_hip_stamp.so python tools/stamp_update.py [out.json]
+    SHEMS_HIP_LIB=build/libshems_hip_stamp.so python tools/stamp_update.py [out.json]
 
 Thread 0 of every workgroup of the five launches records (s_memtime, s_memrealtime) at its phase boundaries.  The table printed
 below is, per launch and workgroup role, the median over workgroups of each phase in shader cycles, and the launch's span on the
