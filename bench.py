@@ -63,8 +63,101 @@ def parse():
     ap.add_argument("--mixed", action="store_true", help="train mode: BASELINE config 5 (10 charger profiles x discomfort-weight sweep, per-env configs)")
     ap.add_argument("--scaled-replay", action="store_true", help="train mode: SURVEY 8(d)'s optional replay mode: ring capacity 72 x envs, every env's transition inserted each step (177 B per env-step) instead of MEM_SIZE = 24 000 with a rotating window of 333 envs")
     ap.add_argument("--hidden", default="250x500", help="train mode: Dense widths L1xL2 of actor and critic; the headline is the tuned 250x500, 300x600 is the reference grids' wider point (layer-by-layer path, csrc/shems_wide.hip), smaller ones run zero-padded")
+    ap.add_argument("--group-window", type=int, default=None, help="group mode: transitions each learner remembers per vector step.  Default: the rotating window of "
+                    "min(envs per learner, MEM_SIZE / 72) households; 1 = the reference's ratio, ONE remembered transition per replay() (DDPG.jl:229-233), household 0 of "
+                    "the learner's block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="auto", choices=["auto", "on", "off"], help="after the headline run, time the other configurations BASELINE.json names and the "
+                    "learner-group shapes on the same box and report them as compact sub-records under \"also\" (auto: only for the default headline workload -- "
+                    "train mode, 65 536 envs, one GPU)")
+    ap.add_argument("--also-which", default=None, help="comma-separated subset of the sub-record names (tests)")
     return ap.parse_args()
+
+
+# The other workloads this repo quotes numbers for, timed by the default run so that every claimed figure stands under the driver's clock
+# (VERDICT round 5, item 1): BASELINE configs[1] (4 096 envs), the configs[3] shard (8 192 envs per GPU), configs[4] on one GPU (65 536
+# envs x 10 charger profiles x discomfort-weight sweep), and the learner groups of SURVEY 8(f) rank 4 at the thesis protocol's width
+# (40 seeds x 10 chargers, RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87) and at 32 learners x 2 048 households.
+ALSO = [
+    ("config2_4096_envs", dict(kind="train", envs=4096, steps=720, warmup=72)),
+    ("config4_shard_8192_envs", dict(kind="train", envs=8192, steps=720, warmup=72)),
+    ("config5_mixed_65536_envs", dict(kind="train", envs=65536, mixed=True, steps=360, warmup=72)),
+    ("group_400x128", dict(kind="group", learners=400, envs=51200, mixed=True, steps=72, warmup=8)),
+    ("group_32x2048", dict(kind="group", learners=32, envs=65536, mixed=True, steps=144, warmup=16)),
+]
+
+
+def run_also(S, torch, which=None, prewarm_s=0.7, log=None):
+    """Each entry of ALSO as a compact record: the same order as the headline (build -> untimed pre-warm -> W warm-up steps -> synchronize ->
+    exactly K steps -> synchronize -> roofline pass), one after the other on this process's GPU, every workload freed before the next is built.
+    A workload that fails leaves {"error": ...} in its place and the others still run."""
+    out = {}
+    for name, spec in ALSO:
+        if which is not None and name not in which:
+            continue
+        t_build = time.perf_counter()
+        wl = None
+        try:
+            if spec["kind"] == "train":
+                wl = importlib.import_module(PKG + ".ddpg").TrainWorkload(S, torch, spec["envs"], seed=1231, updates=1, mixed=spec.get("mixed", False))
+                upd_per_step = 1
+            else:
+                wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, spec["envs"], spec["learners"], seed=1231, mixed=spec.get("mixed", False),
+                                                                           window=spec.get("window"))
+                upd_per_step = spec["learners"]
+            many = getattr(wl, "steps", None)
+            run = many if many is not None else (lambda k: [wl.step() for _ in range(k)])
+            torch.cuda.synchronize()
+            setup_s = time.perf_counter() - t_build
+            tp, pre = time.perf_counter(), 0
+            while time.perf_counter() - tp < prewarm_s:
+                run(24)
+                pre += 24
+                torch.cuda.synchronize()
+            run(spec["warmup"])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(spec["steps"])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            wl.finish()
+            k = wl.kernel_pass(64)
+            ach = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
+            rec = {"workload": (f"{spec['learners']} learners x {spec['envs'] // spec['learners']} households" if spec["kind"] == "group" else f"{spec['envs']} envs")
+                               + (", 10 charger profiles" if spec.get("mixed") else ", Charger98") + f", mode={spec['kind']}",
+                   "value": spec["envs"] * spec["steps"] / dt, "unit": "env-steps/s", "ms_per_step": dt / spec["steps"] * 1e3, "steps": spec["steps"],
+                   "warmup": spec["warmup"], "prewarm_steps": pre, "updates_per_sec": upd_per_step * spec["steps"] / dt,
+                   "roofline": {"kernel": k["kernel"], "kernel_avg_us": k["avg_us"], "bound": k["bound"], "achieved": ach, "peak": k["peak"], "unit": k["unit"],
+                                "frac": ach / k["peak"]},
+                   "setup_s": setup_s, "wall_s": time.perf_counter() - t_build}
+            if k.get("other_kernel") is not None:
+                rec["roofline"]["other_kernel"] = k["other_kernel"]
+            if k.get("back_to_back_us") is not None:
+                rec["roofline"]["kernel_back_to_back_us"] = k["back_to_back_us"]
+            upd_us = getattr(wl, "update_us", None)
+            if upd_us:
+                rec["update_us"] = upd_us
+            if spec["kind"] == "group":
+                rec["update_form"] = wl.group.form
+                rec["replay_window_envs_per_step"] = wl.win
+            out[name] = rec
+        except Exception as e:                      # noqa: BLE001 -- the headline line must still be printed
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:400], "wall_s": time.perf_counter() - t_build}
+        finally:
+            if wl is not None:
+                try:
+                    if hasattr(wl, "close"):
+                        wl.close()
+                    wl.env.close()
+                except Exception:                   # noqa: BLE001
+                    pass
+            wl = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        if log:
+            log(f"also: {name}: {json.dumps(out[name])[:300]}")
+    return out
 
 
 class EnvWorkload:
@@ -427,7 +520,7 @@ def main():
             raise SystemExit("train mode requested but the DDPG path is not built")
         mode = "train" if train_mod is not None else "env"
     if mode == "group":
-        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank, mixed=args.mixed, form=args.group_form)
+        wl = importlib.import_module(PKG + ".group").GroupWorkload(S, torch, args.envs, args.learners, seed=1231 + 1000 * rank, mixed=args.mixed, form=args.group_form, window=args.group_window)
     elif mode == "policy":
         wl = PolicyWorkload(S, torch, args.envs, seed=123 + rank)
     elif mode == "train":
@@ -504,6 +597,16 @@ def main():
         k = wl.kernel_pass(max(200, min(args.steps, 500)))
     t_pass = time.perf_counter() - t_pass0
     t_cpu = 0.0
+    also, t_also = None, 0.0
+    headline_default = (mode == "train" and world == 1 and args.envs == 65536 and args.updates == 1 and not args.mixed and not args.scaled_replay
+                        and not args.overlap and args.hidden.lower() == "250x500")
+    if args.also == "on" or (args.also == "auto" and headline_default):
+        if world != 1:
+            raise SystemExit("--also on: the sub-records are one-GPU workloads")
+        # the headline workload's buffers are kept (its learner checksum is read below); the sub-records fit beside them (< 8 GB)
+        t_also0 = time.perf_counter()
+        also = run_also(S, torch, which=None if args.also_which is None else set(args.also_which.split(",")), log=lambda m: print(m, file=sys.stderr, flush=True))
+        t_also = time.perf_counter() - t_also0
     if rank == 0:
         achieved = k["algorithmic"] / (k["avg_us"] * 1e-6) / (1e9 if k["unit"] == "GB/s" else 1e12)
         traffic, traffic_src = None, None
@@ -592,7 +695,10 @@ def main():
             "gpu_section_s": t_gpu_section_end - t_gpu_section_start,
             "roofline_pass_s": t_pass,
             "cpu_baseline_s": t_cpu,
+            "also_s": t_also,
         }
+        if also is not None:
+            out["also"] = also
         out.update(wl.extra())
         if census is not None:
             out["rccl_ranks"] = census["rccl_ranks"]

@@ -176,17 +176,30 @@ class LearnerGroup:
             ag.updates += 1
         self.updates += 1
 
+    def ring_window(self, num_steps=72, window_count=None):
+        """(count, offset) of the transitions each learner stores at the CURRENT tick.
+        window_count None: the vectorised default (SURVEY 8(d) replay-capacity note): a rotating window of min(E, capacity / num_steps)
+        of the learner's E households per step, so the ring spans about one episode of each.
+        window_count 1: the reference's ratio -- episode! remembers ONE transition per replay() (DDPG.jl:229-233, push order
+        [s, a, r, s', done] MPS:46-47): always household 0 of the learner's block, so that consecutive ring entries are one household's
+        trajectory (s' of entry t = s of entry t + 1 inside an episode), as the reference's single env fills its CircularBuffer.
+        Any other count: a rotating window of that many households."""
+        E = self.envs_per_learner
+        wc = min(E, max(1, self.capacity // int(num_steps))) if window_count is None else int(window_count)
+        if not 1 <= wc <= E:
+            raise ValueError("window_count must be in 1 .. envs_per_learner")
+        return wc, (0 if wc == 1 else (self.tick * wc) % E)
+
     def episode_(self, env, train=True, num_steps=None, rng_ep=0, episode=0, window_count=None):
-        """episode! for all learners at once (cf. Agent.episode_).  Returns the per-env episode returns [count * E]."""
+        """episode! for all learners at once (cf. Agent.episode_).  Returns the per-env episode returns [count * E].
+        window_count: see ring_window (1 = one remembered transition per update, the thesis protocol's update-to-data ratio)."""
         t = self.torch
         num_steps = env.maxsteps if num_steps is None else int(num_steps)
         env.reset_(rng_ep, episode=episode) if rng_ep != -1 else env.reset_(-1)
         returns = t.zeros(env.n, dtype=t.float64, device=self.device)
-        E = self.envs_per_learner
-        wc = min(E, max(1, self.capacity // num_steps)) if window_count is None else int(window_count)
         for step in range(num_steps):
             tick = (int(episode) * 4096 + step) & 0xFFFFFFFF
-            win = (self.rings[0].pos, wc, (self.tick * wc) % E) if train else None
+            win = (self.rings[0].pos, *self.ring_window(num_steps, window_count)) if train else None
             self.act_step(env, train=train, tick=tick, returns_acc=returns, window=win)
             if train:
                 self.replay()
@@ -201,7 +214,9 @@ class GroupWorkload:
     dtype = "f32"
     EP_LEN = 72
 
-    def __init__(self, S, torch, n, learners, seed, mixed=False, form=None):
+    def __init__(self, S, torch, n, learners, seed, mixed=False, form=None, window=None):
+        """window: transitions each learner remembers per vector step (None: min(E, MEM_SIZE / 72), the rotating window; 1: the reference's
+        one transition per replay(), LearnerGroup.ring_window)."""
         self.S, self.torch, self.n, self.count = S, torch, int(n), int(learners)
         if self.n % self.count or (self.n // self.count) % 128:
             raise ValueError("--envs must be learners x a multiple of 128")
@@ -221,7 +236,8 @@ class GroupWorkload:
         self.group = LearnerGroup(self.count, E, seed=1231, rng_seed=self.env_seed, form=form)
         self.group.populate_memory(self.env, seed=self.env_seed)
         self.group.min_max_buffer()
-        self.win = min(E, MEM_SIZE // self.EP_LEN)
+        self.window = None if window is None else int(window)
+        self.win = self.group.ring_window(self.EP_LEN, self.window)[0]
         self.t, self.episode = 0, 1
         self.env.reset_(self.env_seed, episode=self.episode)
 
@@ -231,7 +247,8 @@ class GroupWorkload:
             v = self.env.view()
             _capi.check(_capi.lib().shems_reset_seeded_dev(C.byref(v), self.env_seed, self.episode, self.env._stream()))
         g = self.group
-        g.act_step(self.env, train=True, tick=self.t, window=(g.rings[0].pos, self.win, (self.t * self.win) % g.envs_per_learner))
+        g.tick = self.t
+        g.act_step(self.env, train=True, tick=self.t, window=(g.rings[0].pos, *g.ring_window(self.EP_LEN, self.window)))
         g.replay()
         self.t += 1
 
@@ -248,7 +265,9 @@ class GroupWorkload:
         from .timing import time_launches
         g = self.group
         reset = lambda k, i: self.env.reset_(self.env_seed, episode=100000 + i) if k % 8 == 0 else None
-        act = lambda i: g.act_step(self.env, train=True, tick=i, window=(g.rings[0].pos, self.win, (i * self.win) % g.envs_per_learner))
+        def act(i):
+            g.tick = i
+            g.act_step(self.env, train=True, tick=i, window=(g.rings[0].pos, *g.ring_window(self.EP_LEN, self.window)))
         avg_us, med_us, reps = time_launches(torch, act, min(reps, 96), before_group=reset)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         nup = 20

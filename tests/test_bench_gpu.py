@@ -51,6 +51,37 @@ def test_bench_json_contract_small():
     assert u["counter_bytes"] is None or (u["counter_bytes"] > u["algorithmic_bytes"] and len(u["traffic_ratio"]) == 2)
 
 
+def test_bench_also_records():
+    """The default run's "also" object (here switched on for a small headline and two of its five entries): compact sub-records of the other
+    configurations and of the learner groups, each with value, ms_per_step, steps, updates_per_sec and roofline{kernel, kernel_avg_us, frac}."""
+    d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline", "--prewarm-s", "0.2",
+              "--also", "on", "--also-which", "config2_4096_envs,group_32x2048"])
+    assert d["config"]["envs_per_gpu"] == 8192 and d["value"] > 1e6                      # the headline is untouched
+    also = d["also"]
+    assert sorted(also) == ["config2_4096_envs", "group_32x2048"] and d["also_s"] > 0
+    for name, rec in also.items():
+        assert "error" not in rec, rec
+        for k in ("workload", "value", "unit", "ms_per_step", "steps", "warmup", "updates_per_sec", "roofline", "setup_s", "wall_s"):
+            assert k in rec, (name, k)
+        r = rec["roofline"]
+        assert r["kernel"] and r["kernel_avg_us"] > 0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert abs(rec["value"] - (4096 if name.startswith("config2") else 65536) * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-3 * rec["value"]
+    c2, g = also["config2_4096_envs"], also["group_32x2048"]
+    assert c2["roofline"]["kernel"] == "shems::k_actg<1, 4, 2, 3>" and abs(c2["updates_per_sec"] - c2["steps"] / (c2["ms_per_step"] * 1e-3 * c2["steps"])) < 1e-3 * c2["updates_per_sec"]
+    assert g["update_form"] == "throughput" and abs(g["updates_per_sec"] - 32 * 1e3 / g["ms_per_step"]) < 1e-3 * g["updates_per_sec"]
+    assert g["roofline"]["kernel"].startswith("grouped replay(), throughput form") and g["roofline"]["other_kernel"]["kernel"].startswith("shems::k_act")
+    # without the switch a non-default headline carries no sub-records
+    d0 = _run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--envs", "4096", "--no-cpu-baseline", "--prewarm-s", "0.1"])
+    assert "also" not in d0 and d0["also_s"] == 0.0
+
+
+def test_bench_group_window_one():
+    """--group-window 1: one remembered transition per learner per update (the reference's ratio, DDPG.jl:229-233)."""
+    d = _run([sys.executable, "bench.py", "--mode", "group", "--learners", "16", "--envs", "2048", "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
+              "--prewarm-s", "0.1", "--group-window", "1"])
+    assert d["replay_window_envs_per_step"] == 1 and d["learners"] == 16 and d["updates_per_sec"] > 1600
+
+
 def test_bench_kernel_name_follows_the_dispatcher():
     import importlib
     D = importlib.import_module(U.PKG_NAME + ".ddpg")

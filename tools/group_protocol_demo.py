@@ -22,6 +22,7 @@ G = importlib.import_module(PKG + ".group")
 out_path = sys.argv[1] if len(sys.argv) > 1 else "group_protocol.json"
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 form = sys.argv[3] if len(sys.argv) > 3 else "throughput"
+window = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] not in ("", "default") else None
 SEEDS, E = 40, 128
 ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
 L = SEEDS * len(ids)
@@ -36,7 +37,7 @@ grp.min_max_buffer()
 t0 = time.perf_counter()
 first = last = None
 for ep in range(1, episodes + 1):
-    ret = grp.episode_(env, train=True, rng_ep=7, episode=ep).view(L, E).mean(1).cpu().numpy()
+    ret = grp.episode_(env, train=True, rng_ep=7, episode=ep, window_count=window).view(L, E).mean(1).cpu().numpy()
     first = ret if ep == 1 else first
     last = ret
 torch.cuda.synchronize()
@@ -57,7 +58,12 @@ for k, cid in enumerate(ids):
     sc = scores[k::len(ids)]
     per_charger[str(cid)] = {"rule_based": rule[cid], "learners": SEEDS, "score_mean": float(sc.mean()), "score_best": float(sc.max()),
                              "score_worst": float(sc.min()), "beat_rule_based": int((sc > rule[cid]).sum())}
+wc = grp.ring_window(72, window)[0]
 doc = {"protocol": "40 seeds x 10 chargers = 400 learners x 128 households, grouped launches", "form": grp.form, "episodes": episodes,
+       "remembered_transitions_per_learner_update": wc,
+       "update_to_data": ("1 update per remembered transition: the reference's ratio (DDPG.jl:229-233)" if wc == 1 else
+                          f"1 update per {wc} remembered transitions ({wc} x the reference's data per update)"),
+       "transitions_remembered_per_learner": episodes * 72 * wc,
        "updates_per_learner": grp.updates, "learner_updates_total": grp.updates * L, "env_steps": episodes * 72 * L * E, "wall_s": wall,
        "learner_updates_per_s": grp.updates * L / wall, "state_finite": finite,
        "train_return_first_mean": float(first.mean()), "train_return_last_mean": float(last.mean()), "per_charger": per_charger}
