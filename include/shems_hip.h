@@ -451,6 +451,32 @@ enum { SHEMS_TP_STORE_GRAD = 1 };
 int shems_ddpg_group_update_tp(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, int64_t ring_len,
                                uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit,
                                double eta_act, double bp1_act, double bp2_act, int32_t flags, void *stream);
+/* The throughput form on a TILED working layout of the layer-2 state (round 6).  The W2-gradient launches of the form above are its
+ * HBM stream -- 32 B in and out per W2 parameter: ADAM moments (Flux.Optimise.ADAM state, DDPG.jl:105-108), parameter and target
+ * (soft_update!, DDPG.jl:99-103) -- and in Flux order ([in][out] rows of 500 floats) a 64 x 64 tile of it is 4 x 64 pieces of 256
+ * bytes: 3.85 TB/s where one contiguous 64 KB piece per tile reaches 4.78 TB/s (tools/micro/adam_stream.hip).  A tiled region holds,
+ * per network, W2 / m / v / target as [4 k-tiles][8 n-tiles][m | v | p | target][64][64] floats (rows / columns padded to 256 / 512
+ * with zeros), SHEMS_W2T_FLOATS per learner, at learner 0's pointer + l * stride_bytes like every other block.  While a group
+ * trains through these entry points the tiled regions hold the CURRENT layer-2 state and the W2 ranges of the Flux-order blocks
+ * (shems_ddpg.actor / critic / actor_t / critic_t / m_* / v_*) are stale; everything else (layer 1, b2, W3, b3) stays in the
+ * Flux-order blocks.  shems_group_w2_to_tiled / _to_flux copy the W2 ranges one way or the other (checkpoints, set / get of
+ * parameters, the single-learner entry points and the latency form all speak Flux order).  Same arithmetic and summation order as
+ * shems_ddpg_group_update_tp: the two leave the same values (tests/test_group_gpu.py holds both to the float64 oracle and to each
+ * other bit for bit). */
+enum { SHEMS_W2T_FLOATS = 32 * 4 * 64 * 64 };
+typedef struct shems_group_w2t {
+    float *actor;              /* dev [SHEMS_W2T_FLOATS] of learner 0: actor W2, its moments and actor_target W2  */
+    float *critic;             /* dev [SHEMS_W2T_FLOATS] of learner 0: critic ...                                   */
+} shems_group_w2t;
+int shems_group_w2_to_tiled(const shems_ddpg *d0, const shems_group *g, const shems_group_w2t *t, void *stream);
+int shems_group_w2_to_flux(const shems_ddpg *d0, const shems_group *g, const shems_group_w2t *t, void *stream);
+int shems_ddpg_group_update_tiled(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g, const shems_group_w2t *t,
+                                  int64_t ring_len, uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit,
+                                  double bp2_crit, double eta_act, double bp1_act, double bp2_act, int32_t flags, void *stream);
+/* shems_act_step_group_dev with every learner's actor W2 read from its tiled region (t->actor; t->critic is not used). */
+int shems_act_step_group_tiled_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, const shems_group_w2t *t,
+                                   float *d_a, double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window,
+                                   void *stream);
 int shems_ddpg_group_critic_grad(const shems_ddpg *d0, const shems_replay *ring0, const shems_group *g,
                                  int64_t ring_len, uint64_t seed, uint32_t tick, void *stream);
 int shems_ddpg_group_critic_apply(const shems_ddpg *d0, const shems_group *g, double eta, double bp1, double bp2,

@@ -59,6 +59,19 @@ __host__ __device__ constexpr int off_b2(int in) { return off_w2(in) + H1N * H2N
 __host__ __device__ constexpr int off_w3(int in) { return off_b2(in) + H2N; }
 __host__ __device__ constexpr int off_b3(int in, int out) { return off_w3(in) + H2N * out; }
 
+// ---- TILED working layout of a network's layer-2 state (shems_group_w2t; round 6) ----------------------------------------------
+// W2 [250][500], its two ADAM moments and its target as 4 x 8 tiles of 64 x 64 (rows / columns padded to 256 / 512 with zeros), the four
+// arrays of a tile ADJACENT: region [kt][nt][m | v | p | target][64 rows][64 columns], 64 KB per tile, 2 MB per network.  P4 / P7 read and
+// write one tile's 64 KB as ONE contiguous piece (tools/micro/adam_stream.hip: 4.78 TB/s against 3.85 TB/s for the 256-byte row pieces
+// of the Flux order and 4.56 TB/s for a device copy of the same bytes); the forward / D1 launches find a 32-row chunk of a 64-wide n-tile
+// as one contiguous 8 KB piece.  The Flux-order blocks keep every other parameter (layer 1, b2, W3, b3) and are the API's view of W2:
+// shems_group_w2_to_tiled / _to_flux convert (csrc below), group.py keeps track of which copy is current.
+constexpr int TL_TILE = 64 * 64;                   // floats of one array of one tile
+constexpr int TL_BLOCK = 4 * TL_TILE;              // one tile: m | v | p | target
+enum { TL_M = 0, TL_V = 1, TL_P = 2, TL_T = 3 };
+static_assert(SHEMS_W2T_FLOATS == 32 * TL_BLOCK, "shems_hip.h and the kernels agree on the tiled region's size");
+__host__ __device__ constexpr int64_t tl_tile(int kt, int nt) { return (int64_t)(kt * 8 + nt) * TL_BLOCK; }
+
 // ---- workspace carve (floats, inside shems_ddpg.ws; see kTpWsFloats) -----------------------------------------------------------
 constexpr int64_t TP_X = 0;                            // [12][BP]  rows 0..8 normalize(s), 9..10 stored action, 11 = 1
 constexpr int64_t TP_X2 = TP_X + W1K * BP;             // [12][BP]  rows 0..8 normalize(s'), 9..10 zero, 11 = 1
@@ -197,6 +210,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs &A, const int role, con
 // QG (P5): the same workgroup then back-propagates the constant upstream gradient of -mean(q) through its own 64 hidden units.
 // ================================================================================================================================
 struct FwdJob {
+    const float *w2t;      // tiled layout: the network's region + TL_P / TL_T array offset (its W2 is read from there); null: Flux order, from P
     const float *P;        // parameter block of the network
     const float *X;        // [12][BP] input block (workspace)
     const float *w1i;      // layer-1 image (workspace): frozen by P0, or written by P3 (the critic after its update)
@@ -211,7 +225,7 @@ struct FwdJob {
 struct FwdArgs { FwdJob job[3]; int64_t gstride; int batch; };
 __device__ __forceinline__ void gshift(FwdJob &J, int64_t off)
 {
-    J.P = gsh(J.P, off); J.X = gsh(J.X, off); J.w1i = gsh(J.w1i, off); J.ap3 = gsh(J.ap3, off); J.ab3 = gsh(J.ab3, off);
+    J.w2t = gsh(J.w2t, off); J.P = gsh(J.P, off); J.X = gsh(J.X, off); J.w1i = gsh(J.w1i, off); J.ap3 = gsh(J.ap3, off); J.ab3 = gsh(J.ab3, off);
     J.api = gsh(J.api, off); J.H2 = gsh(J.H2, off); J.P3 = gsh(J.P3, off); J.DAP = gsh(J.DAP, off);
 }
 
@@ -227,6 +241,29 @@ __device__ __forceinline__ void fwd_chunk_load(const float *__restrict__ W2, int
     for (int it = 0; it < NTL; ++it) {
         const int e = it * 256 + (int)threadIdx.x, k = min(32 * c + e / (8 * NTL), H1N - 1);
         v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + n0 + 4 * (e % (8 * NTL)));
+    }
+}
+// The same chunk from the tiled layout: per 64 columns the 32 rows are ONE contiguous 8 KB piece (512 float4) of the tile (kt = c / 2,
+// rows 32 (c & 1) ..); pad rows / columns hold zeros.  fwd_chunk_store_t puts float4 r of piece j at LDS row r / 16, column 64 j + 4 (r % 16).
+template <int NTL>
+__device__ __forceinline__ void fwd_chunk_load_t(const float *__restrict__ Wt, int n0, int c, f32x4 (&v)[NTL])
+{
+    const float *base = Wt + tl_tile(c >> 1, n0 >> 6) + (c & 1) * (32 * 64);
+#pragma unroll
+    for (int it = 0; it < NTL; ++it) {
+        const int e = it * 256 + (int)threadIdx.x;
+        v[it] = *reinterpret_cast<const f32x4 *>(base + (int64_t)(e >> 9) * TL_BLOCK + 4 * (e & 511));
+    }
+}
+template <int S, int NTL>
+__device__ __forceinline__ void fwd_chunk_store_t(float *buf, const f32x4 (&v)[NTL])
+{
+#pragma unroll
+    for (int it = 0; it < NTL; ++it) {
+        const int e = it * 256 + (int)threadIdx.x, r = e & 511;
+        float *p = buf + (r >> 4) * S + 64 * (e >> 9) + 4 * (r & 15);
+        if constexpr (S % 4 == 0) *reinterpret_cast<f32x4 *>(p) = v[it];
+        else { p[0] = v[it][0]; p[1] = v[it][1]; p[2] = v[it][2]; p[3] = v[it][3]; }
     }
 }
 template <int S, int NTL>
@@ -267,7 +304,7 @@ template <bool QG, int NTL_> struct FwdShape {
     static constexpr int LDS = (W1K * W1C + NW * 4 + 2 * 32 * S) * 4;
 };
 
-template <bool QG, int NTL_>
+template <bool QG, int NTL_, bool TL>
 __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const int by, float *smem)
 {
     typedef FwdShape<QG, NTL_> SH;
@@ -280,13 +317,19 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
     FwdJob J = job == 0 ? A.job[0] : job == 1 ? A.job[1] : A.job[2];
     gshift(J, (int64_t)by * A.gstride);
     const float *__restrict__ P = J.P;
-    const float *__restrict__ W2 = P + off_w2(J.in);
+    const float *__restrict__ W2 = TL ? J.w2t : P + off_w2(J.in);
     const int m = 32 * w + li;
+    auto chunk_load = [&](int c, f32x4 (&v)[NTL]) {
+        if constexpr (TL) fwd_chunk_load_t<NTL>(W2, n0, c, v); else fwd_chunk_load<NTL>(W2, n0, c, v);
+    };
+    auto chunk_store = [&](float *buf, const f32x4 (&v)[NTL]) {
+        if constexpr (TL) fwd_chunk_store_t<S, NTL>(buf, v); else fwd_chunk_store<S, NTL>(buf, v);
+    };
 
     // Every request of the prologue is issued before the first wait: the workgroups of a CU start together (at the launch and, staying
     // in step, after each generation), so their prologues are not covered by anybody's matrix work -- one exposed round trip, not four.
     f32x4 pv[NTL];
-    fwd_chunk_load<NTL>(W2, n0, 0, pv);
+    chunk_load(0, pv);
     f32x4 wi[3];
     {
         const f32x4 *g4 = reinterpret_cast<const f32x4 *>(J.w1i) + tid;
@@ -325,7 +368,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
         if (lh == 1) xreg[4] = a0; else xreg[5] = a1;          // row 9 = (s 4, lh 1), row 10 = (s 5, lh 0)
         if (J.api && nt == 0) J.api[lh * BP + m] = lh ? a1 : a0;
     }
-    fwd_chunk_store<S, NTL>(ring, pv);
+    chunk_store(ring, pv);
     // The operands above are consumed inside the chunk loop only.  Loads retire in order, so without this the compiler's wait in front of
     // their first use (counted for the loop's entry edge) also waits, on every later iteration, for the chunk prefetch issued just before it.
 #pragma unroll
@@ -349,7 +392,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
             const int c = it & 7;
             const float *buf = ring + (it & 1) * 32 * S;
             const bool more = wrap || c < 7;
-            if (more) fwd_chunk_load<NTL>(W2, n0, (it + 1) & 7, pv);
+            if (more) chunk_load((it + 1) & 7, pv);
             __builtin_amdgcn_sched_barrier(0);          // (where the request is unconditional the scheduler otherwise sinks it to the end of the iteration)
             if constexpr (!BWD) {
                 // layer 2: k-step r contracts over the two hidden units {32 c + drow(r, 0), 32 c + drow(r, 1)}; B = relu(t[r]) from registers.
@@ -410,7 +453,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
                     da1 = fmaf(pw[W1C + (r & 3) + 8 * (r >> 2)], v, da1);
                 }
             }
-            if (more) fwd_chunk_store<S, NTL>(ring + ((it + 1) & 1) * 32 * S, pv);
+            if (more) chunk_store(ring + ((it + 1) & 1) * 32 * S, pv);
             __syncthreads();
         }
     };
@@ -456,6 +499,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs &A, const int bx, const i
 // ================================================================================================================================
 struct NetArgs {
     shems_ddpg d;          // learner 0's record (heads, losses, workspace)
+    float *w2t;            // tiled layout: the network's region (learner 0's); null: Flux order
     AdamCtx c;
     int64_t gstride;
     int head;              // 1 = critic loss head, 2 = actor head
@@ -544,7 +588,7 @@ constexpr unsigned kNarrowBelow = 48;
 constexpr int d1_ring(int KT) { return 2 * 32 * KT * D1_S > 4 * KT * 8 * 64 ? 2 * 32 * KT * D1_S : 4 * KT * 8 * 64; }      // floats: the ring, later the four waves' gW1 partials
 constexpr int d1_lds(int KT) { return (d1_ring(KT) + 1024 + 2 * BP + 8 + W1K * BP + W1K * 32 * KT) * 4; }
 
-template <int IN, int KT>
+template <int IN, int KT, bool TL>
 __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const int by, float *smem)
 {
     typedef NetOf<IN> N;
@@ -570,11 +614,17 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 
     // A chunk q: W2[k0 .. k0 + 63][32 q .. 32 q + 31] (128 B per row), two float4 per thread; rows >= 250 clamped (their outputs are
     // never stored), columns >= 500 of the last chunk meet D2 rows that are exactly zero
+    // (tiled layout: the same 32 columns of rows k0 .. are 128-byte pieces 256 bytes apart inside tile (k0 / 64, q / 2); pad rows are zeros)
+    const float *__restrict__ Wt = TL ? gsh(A.w2t, off) + TL_P * TL_TILE + (int64_t)(k0 >> 6) * 8 * TL_BLOCK + (k0 & 63) * 64 : nullptr;
     auto a_load = [&](int q, f32x4 (&v)[KT]) {
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
-            const int e = it * 256 + tid, k = min(k0 + (e >> 3), H1N - 1);
-            v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + 32 * q + 4 * (e & 7));
+            const int e = it * 256 + tid;
+            if constexpr (TL) v[it] = *reinterpret_cast<const f32x4 *>(Wt + (int64_t)(q >> 1) * TL_BLOCK + (e >> 3) * 64 + 32 * (q & 1) + 4 * (e & 7));
+            else {
+                const int k = min(k0 + (e >> 3), H1N - 1);
+                v[it] = *reinterpret_cast<const f32x4 *>(W2 + (int64_t)k * H2N + 32 * q + 4 * (e & 7));
+            }
         }
     };
     auto a_store = [&](float *buf, const f32x4 (&v)[KT]) {
@@ -750,7 +800,7 @@ constexpr int GW_WGS = 4 * NT;     // k-tiles x n-tiles of 64 per learner
 constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3 + W1K * BP) * 4;
 static_assert(64 * GW_TS <= 64 * GW_S, "the row-major copy of a tile fits the D2 panel it replaces");
 
-template <int IN>
+template <int IN, bool TL>
 __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const int by, float *smem)
 {
     typedef NetOf<IN> N;
@@ -792,15 +842,24 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
     for (int s = 0; s < 6; ++s) xv[s] = X[s * 256 + tid];
     __builtin_amdgcn_sched_barrier(0);
     // this thread's 16 elements of the tile, row-major: float4 it = row 16 it + (tid >> 4), columns 4 (tid & 15) .. + 3
+    // Tiled layout: the same float4 (row 16 it + tid / 16, columns 4 (tid % 16) ..) is float4 number 256 it + tid of each of the tile's
+    // four arrays, which lie one behind the other: the workgroup's whole state is ONE contiguous 64 KB piece, read here, written below.
     int eidx[4];
     f32x4 am[4], av[4], ap[4], at[4];
+    float *tile = TL ? gsh(A.w2t, off) + tl_tile(kt, nt) + 4 * tid : nullptr;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int k = k0 + 16 * it + (tid >> 4), n = n0 + 4 * (tid & 15);
         eidx[it] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;          // (500 is a multiple of 4: a float4 is all in or all out)
-        const int e = off_w2(IN) + min(k, H1N - 1) * H2N + min(n, H2N - 4);
-        am[it] = *reinterpret_cast<const f32x4 *>(c.mt + e); av[it] = *reinterpret_cast<const f32x4 *>(c.vt + e);
-        ap[it] = *reinterpret_cast<const f32x4 *>(c.p + e); at[it] = *reinterpret_cast<const f32x4 *>(c.target + e);
+        if constexpr (TL) {
+            const float *q = tile + 1024 * it;
+            am[it] = *reinterpret_cast<const f32x4 *>(q + TL_M * TL_TILE); av[it] = *reinterpret_cast<const f32x4 *>(q + TL_V * TL_TILE);
+            ap[it] = *reinterpret_cast<const f32x4 *>(q + TL_P * TL_TILE); at[it] = *reinterpret_cast<const f32x4 *>(q + TL_T * TL_TILE);
+        } else {
+            const int e = off_w2(IN) + min(k, H1N - 1) * H2N + min(n, H2N - 4);
+            am[it] = *reinterpret_cast<const f32x4 *>(c.mt + e); av[it] = *reinterpret_cast<const f32x4 *>(c.vt + e);
+            ap[it] = *reinterpret_cast<const f32x4 *>(c.p + e); at[it] = *reinterpret_cast<const f32x4 *>(c.target + e);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     d3s[tid] = d3v;
@@ -871,10 +930,16 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
                 adam_math(c, g4[i], m_, v_, p_, t_);
                 am[it][i] = m_; av[it][i] = v_; ap[it][i] = p_; at[it][i] = t_;
             }
-            if (eidx[it] >= 0) {
+            if (eidx[it] >= 0) {                 // (pad rows / columns of the tiled layout stay zero: never written)
                 const int e = eidx[it];
-                *reinterpret_cast<f32x4 *>(c.mt + e) = am[it]; *reinterpret_cast<f32x4 *>(c.vt + e) = av[it];
-                *reinterpret_cast<f32x4 *>(c.p + e) = ap[it]; *reinterpret_cast<f32x4 *>(c.target + e) = at[it];
+                if constexpr (TL) {
+                    float *q = tile + 1024 * it;
+                    *reinterpret_cast<f32x4 *>(q + TL_M * TL_TILE) = am[it]; *reinterpret_cast<f32x4 *>(q + TL_V * TL_TILE) = av[it];
+                    *reinterpret_cast<f32x4 *>(q + TL_P * TL_TILE) = ap[it]; *reinterpret_cast<f32x4 *>(q + TL_T * TL_TILE) = at[it];
+                } else {
+                    *reinterpret_cast<f32x4 *>(c.mt + e) = am[it]; *reinterpret_cast<f32x4 *>(c.vt + e) = av[it];
+                    *reinterpret_cast<f32x4 *>(c.p + e) = ap[it]; *reinterpret_cast<f32x4 *>(c.target + e) = at[it];
+                }
                 if (store_grad) *reinterpret_cast<f32x4 *>(gW + e) = g4;
             }
         }
@@ -887,13 +952,13 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
 
 // ---- one launch per phase (the plain form: every learner of the group in the same phase) ---------------------------------------
 __global__ __launch_bounds__(256) void k_tp_prep(PrepArgs A) { prep_body(A, blockIdx.x, blockIdx.y); }
-template <bool QG, int NTL>
+template <bool QG, int NTL, bool TL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTL == 4 ? 3 : 4, 4))) void k_tp_fwd(FwdArgs A)      // (the wide form's LDS allows three workgroups per CU)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    fwd_body<QG, NTL>(A, blockIdx.x, blockIdx.y, smem);
+    fwd_body<QG, NTL, TL>(A, blockIdx.x, blockIdx.y, smem);
 }
-template <int IN, int KT>
+template <int IN, int KT, bool TL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -903,13 +968,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const unsigned id = blockIdx.x, xcd = id & 7u, q = id >> 3;
     const unsigned learner = 8u * (q / T) + xcd;
     if (learner >= (unsigned)A.learners) return;
-    d1_body<IN, KT>(A, (int)(q % T), (int)learner, smem);
+    d1_body<IN, KT, TL>(A, (int)(q % T), (int)learner, smem);
 }
-template <int IN>
+template <int IN, bool TL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_gw2(NetArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gw2_body<IN>(A, blockIdx.x, blockIdx.y, smem);
+    gw2_body<IN, TL>(A, blockIdx.x, blockIdx.y, smem);
 }
 
 // (Round 5 also built two ways of running the HBM-bound phases (P4, P7) under the MFMA-bound ones (P1, P2, P5) of OTHER learners: cohorts
@@ -917,20 +982,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 // Both verified, both measured slower than the plain sequence above (2.11-3.27 ms and 2.17-2.34 ms against 2.08-2.11 ms), both removed:
 // profiles/r05_tp_overlap_probe.json.)
 
-static int set_attrs()
+// ================================================================================================================================
+// Flux order <-> tiled layout of the two networks' layer-2 state (W2, m, v, target): one workgroup per (tile, network, learner).
+// TO_TILED writes the pad rows / columns as zeros (the kernels above rely on that and never write them); TO_FLUX skips them.
+// ================================================================================================================================
+struct LayoutArgs { shems_ddpg d; float *w2t_actor, *w2t_critic; int64_t gstride; };
+template <bool TO_TILED>
+__global__ __launch_bounds__(256) void k_tp_w2_layout(LayoutArgs A)
 {
-    static std::atomic<uint64_t> m0{0}, m1{0}, m2{0}, m3{0}, m4{0}, m5{0};
-    // (all below 64 KB: the opt-in is a no-op kept for the day a tile grows)
-    static std::atomic<uint64_t> m01{0};
-    constexpr int l4 = FwdShape<false, 4>::LDS, l2 = FwdShape<false, 2>::LDS, lq = FwdShape<true, 2>::LDS;
-    if (int rc = lds_optin(m0, reinterpret_cast<const void *>(&k_tp_fwd<false, 4>), l4, "attr k_tp_fwd")) return rc;
-    if (int rc = lds_optin(m01, reinterpret_cast<const void *>(&k_tp_fwd<false, 2>), l2, "attr k_tp_fwd")) return rc;
-    if (int rc = lds_optin(m1, reinterpret_cast<const void *>(&k_tp_fwd<true, 2>), lq, "attr k_tp_fwd<QG>")) return rc;
-    if (int rc = lds_optin(m2, reinterpret_cast<const void *>(&k_tp_d1<CIN, 2>), d1_lds(2), "attr k_tp_d1")) return rc;
-    if (int rc = lds_optin(m3, reinterpret_cast<const void *>(&k_tp_d1<SIN, 2>), d1_lds(2), "attr k_tp_d1")) return rc;
-    if (int rc = lds_optin(m4, reinterpret_cast<const void *>(&k_tp_gw2<CIN>), GW_LDS, "attr k_tp_gw2")) return rc;
-    if (int rc = lds_optin(m5, reinterpret_cast<const void *>(&k_tp_gw2<SIN>), GW_LDS, "attr k_tp_gw2")) return rc;
-    return SHEMS_OK;
+    const int tid = threadIdx.x, nt = blockIdx.x & 7, kt = blockIdx.x >> 3;
+    const bool critic = blockIdx.y == 1;
+    const int64_t off = (int64_t)blockIdx.z * A.gstride;
+    shems_ddpg d = A.d;
+    gshift(d, off);
+    float *flux[4] = {critic ? d.m_critic : d.m_actor, critic ? d.v_critic : d.v_actor, critic ? d.critic : d.actor, critic ? d.critic_t : d.actor_t};
+    float *tile = gsh(critic ? A.w2t_critic : A.w2t_actor, off) + tl_tile(kt, nt) + 4 * tid;
+    const int w2 = off_w2(critic ? CIN : SIN);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = 64 * kt + 16 * it + (tid >> 4), n = 64 * nt + 4 * (tid & 15);
+        const bool in = k < H1N && n < H2N;
+        const int e = w2 + min(k, H1N - 1) * H2N + min(n, H2N - 4);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 *t4 = reinterpret_cast<f32x4 *>(tile + 1024 * it + a * TL_TILE), *f4 = reinterpret_cast<f32x4 *>(flux[a] + e);
+            if constexpr (TO_TILED) *t4 = in ? *f4 : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            else if (in) *f4 = *t4;
+        }
+    }
 }
 
 }  // namespace tp
@@ -939,13 +1018,26 @@ static int set_attrs()
 using namespace shems;
 using namespace shems::tp;
 
-extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_replay *ring, const shems_group *g, int64_t ring_len, uint64_t seed,
-                                          uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,
-                                          double bp2_act, int32_t flags, void *stream)
+static int check_w2t(const shems_group_w2t *t, const char *fn)
 {
-    const char *fn = "shems_ddpg_group_update_tp";
+    if (!t || !t->actor || !t->critic) return set_error(SHEMS_ERR_ARG, "%s: shems_group_w2t needs both regions", fn);
+    if ((((uintptr_t)t->actor | (uintptr_t)t->critic) & 15) != 0) return set_error(SHEMS_ERR_ARG, "%s: the tiled regions must be 16-byte aligned", fn);
+    return SHEMS_OK;
+}
+static int check_group_tp(const shems_group *g, const char *fn)
+{
     if (!g || g->count < 1 || g->count > 65535 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
         return set_error(SHEMS_ERR_ARG, "%s: shems_group needs 1 <= count <= 65535 and a 16-byte-multiple stride", fn);
+    return SHEMS_OK;
+}
+
+// t == null: every array in Flux order (round 5's form); else the layer-2 state of both networks lives in the tiled regions.
+template <bool TL>
+static int group_update_tp(const char *fn, const shems_ddpg *d, const shems_replay *ring, const shems_group *g, const shems_group_w2t *t, int64_t ring_len,
+                           uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act, double bp2_act,
+                           int32_t flags, void *stream)
+{
+    if (int rc = check_group_tp(g, fn)) return rc;
     if (!d || !d->actor || !d->critic || !d->actor_t || !d->critic_t || !d->m_actor || !d->v_actor || !d->m_critic || !d->v_critic ||
         !d->s_min || !d->s_max || !d->ws || !d->losses)
         return set_error(SHEMS_ERR_ARG, "%s: shems_ddpg has a NULL buffer", fn);
@@ -958,12 +1050,14 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
         return set_error(SHEMS_ERR_ARG, "%s: bad replay ring / length", fn);
     for (double bp : {bp1_crit, bp2_crit, bp1_act, bp2_act})
         if (!(bp > 0.0 && bp < 1.0)) return set_error(SHEMS_ERR_ARG, "%s: beta powers must be in (0,1)", fn);
-    if (int rc = set_attrs()) return rc;
+    if (TL) if (int rc = check_w2t(t, fn)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const unsigned L = (unsigned)g->count;
     const int64_t gs = g->count > 1 ? g->stride_bytes : 0;
     const int sg = (flags & SHEMS_TP_STORE_GRAD) ? 1 : 0;
     float *ws = d->ws;
+    float *ta = TL ? t->actor : nullptr, *tc = TL ? t->critic : nullptr;
+    auto arr = [](float *region, int a) -> const float * { return region ? region + a * TL_TILE : nullptr; };
 
     auto adam_ctx = [&](bool critic) {
         const double eta = critic ? eta_crit : eta_act, bp1 = critic ? bp1_crit : bp1_act, bp2 = critic ? bp2_crit : bp2_act;
@@ -977,17 +1071,17 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     U.pa = PrepArgs{*d, *ring, ring_len, gs, seed, tick};
     for (FwdArgs *f : {&U.f1, &U.f2, &U.f5}) { f->gstride = gs; f->batch = d->batch; }
     // P1: three independent forward passes
-    U.f1.job[0] = FwdJob{d->actor_t, ws + TP_X2, w1i_of(ws, NET_ACTOR_T), nullptr, nullptr, nullptr, nullptr, p3_of(ws, NET_ACTOR_T), nullptr, SIN, 2};
-    U.f1.job[1] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, NET_CRITIC), nullptr, nullptr, nullptr, ws + TP_H2C, p3_of(ws, NET_CRITIC), nullptr, CIN, 1};
-    U.f1.job[2] = FwdJob{d->actor, ws + TP_X, w1i_of(ws, NET_ACTOR), nullptr, nullptr, nullptr, ws + TP_H2A, p3_of(ws, NET_ACTOR), nullptr, SIN, 2};
+    U.f1.job[0] = FwdJob{arr(ta, TL_T), d->actor_t, ws + TP_X2, w1i_of(ws, NET_ACTOR_T), nullptr, nullptr, nullptr, nullptr, p3_of(ws, NET_ACTOR_T), nullptr, SIN, 2};
+    U.f1.job[1] = FwdJob{arr(tc, TL_P), d->critic, ws + TP_X, w1i_of(ws, NET_CRITIC), nullptr, nullptr, nullptr, ws + TP_H2C, p3_of(ws, NET_CRITIC), nullptr, CIN, 1};
+    U.f1.job[2] = FwdJob{arr(ta, TL_P), d->actor, ws + TP_X, w1i_of(ws, NET_ACTOR), nullptr, nullptr, nullptr, ws + TP_H2A, p3_of(ws, NET_ACTOR), nullptr, SIN, 2};
     // P2: critic_target on [s'; actor_target(s')]
-    U.f2.job[0] = FwdJob{d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
+    U.f2.job[0] = FwdJob{arr(tc, TL_T), d->critic_t, ws + TP_X2, w1i_of(ws, NET_CRITIC_T), p3_of(ws, NET_ACTOR_T), ws + TP_FB3 + 4, nullptr, nullptr,
                          p3_of(ws, NET_CRITIC_T), nullptr, CIN, 1};
     // P5: updated critic on [s; actor(s)], forward + input gradient
-    U.f5.job[0] = FwdJob{d->critic, ws + TP_X, w1i_of(ws, IMG_CRITIC_NEW), p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
+    U.f5.job[0] = FwdJob{arr(tc, TL_P), d->critic, ws + TP_X, w1i_of(ws, IMG_CRITIC_NEW), p3_of(ws, NET_ACTOR), ws + TP_FB3 + 2, ws + TP_API, nullptr, p3_of(ws, PASS_CRITIC2),
                          ws + TP_DAP, CIN, 1};
-    U.nc = NetArgs{*d, adam_ctx(true), gs, 1, sg, (int)L};
-    U.na = NetArgs{*d, adam_ctx(false), gs, 2, sg, (int)L};
+    U.nc = NetArgs{*d, tc, adam_ctx(true), gs, 1, sg, (int)L};
+    U.na = NetArgs{*d, ta, adam_ctx(false), gs, 2, sg, (int)L};
     hipLaunchKernelGGL(k_tp_prep, dim3(5, L), dim3(256), 0, st, U.pa);
     typedef FwdShape<false, 4> SW;           // (typedefs: the launch macro splits its arguments at the commas of a template argument list)
     typedef FwdShape<false, 2> SN;
@@ -996,16 +1090,56 @@ extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_repla
     // the wide shapes leave CUs without work (P3 at 32 learners: 128 workgroups); measured per grouped update, wide / narrow: 32 learners
     // 247 / 226 us, 48 learners 322 / 320, 64 learners 362 / 372, 128 learners 669 / 695 (profiles/NOTES.md, round-5 log).
     const bool narrow = L < kNarrowBelow;
-    if (narrow) hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(3 * SN::TILES, L), dim3(256), SN::LDS, st, U.f1);
-    else hipLaunchKernelGGL((k_tp_fwd<false, 4>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
-    hipLaunchKernelGGL((k_tp_fwd<false, 2>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
+    if (narrow) hipLaunchKernelGGL((k_tp_fwd<false, 2, TL>), dim3(3 * SN::TILES, L), dim3(256), SN::LDS, st, U.f1);
+    else hipLaunchKernelGGL((k_tp_fwd<false, 4, TL>), dim3(3 * SW::TILES, L), dim3(256), SW::LDS, st, U.f1);
+    hipLaunchKernelGGL((k_tp_fwd<false, 2, TL>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
     const unsigned g8 = 8 * ((L + 7) / 8);
-    if (narrow) hipLaunchKernelGGL((k_tp_d1<CIN, 1>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.nc);
-    else hipLaunchKernelGGL((k_tp_d1<CIN, 2>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.nc);
-    hipLaunchKernelGGL(k_tp_gw2<CIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
-    hipLaunchKernelGGL((k_tp_fwd<true, 2>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
-    if (narrow) hipLaunchKernelGGL((k_tp_d1<SIN, 1>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.na);
-    else hipLaunchKernelGGL((k_tp_d1<SIN, 2>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.na);
-    hipLaunchKernelGGL(k_tp_gw2<SIN>, dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
+    if (narrow) hipLaunchKernelGGL((k_tp_d1<CIN, 1, TL>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.nc);
+    else hipLaunchKernelGGL((k_tp_d1<CIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.nc);
+    hipLaunchKernelGGL((k_tp_gw2<CIN, TL>), dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
+    hipLaunchKernelGGL((k_tp_fwd<true, 2, TL>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
+    if (narrow) hipLaunchKernelGGL((k_tp_d1<SIN, 1, TL>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.na);
+    else hipLaunchKernelGGL((k_tp_d1<SIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.na);
+    hipLaunchKernelGGL((k_tp_gw2<SIN, TL>), dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
+}
+
+extern "C" int shems_ddpg_group_update_tp(const shems_ddpg *d, const shems_replay *ring, const shems_group *g, int64_t ring_len, uint64_t seed,
+                                          uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,
+                                          double bp2_act, int32_t flags, void *stream)
+{
+    return group_update_tp<false>("shems_ddpg_group_update_tp", d, ring, g, nullptr, ring_len, seed, tick, eta_crit, bp1_crit, bp2_crit, eta_act, bp1_act, bp2_act,
+                                  flags, stream);
+}
+
+extern "C" int shems_ddpg_group_update_tiled(const shems_ddpg *d, const shems_replay *ring, const shems_group *g, const shems_group_w2t *t, int64_t ring_len,
+                                             uint64_t seed, uint32_t tick, double eta_crit, double bp1_crit, double bp2_crit, double eta_act, double bp1_act,
+                                             double bp2_act, int32_t flags, void *stream)
+{
+    return group_update_tp<true>("shems_ddpg_group_update_tiled", d, ring, g, t, ring_len, seed, tick, eta_crit, bp1_crit, bp2_crit, eta_act, bp1_act, bp2_act,
+                                 flags, stream);
+}
+
+static int w2_layout(const char *fn, bool to_tiled, const shems_ddpg *d, const shems_group *g, const shems_group_w2t *t, void *stream)
+{
+    if (int rc = check_group_tp(g, fn)) return rc;
+    if (int rc = check_w2t(t, fn)) return rc;
+    if (!d || !d->actor || !d->critic || !d->actor_t || !d->critic_t || !d->m_actor || !d->v_actor || !d->m_critic || !d->v_critic)
+        return set_error(SHEMS_ERR_ARG, "%s: shems_ddpg has a NULL network / moment buffer", fn);
+    for (const float *p : {(const float *)d->actor, (const float *)d->critic, (const float *)d->actor_t, (const float *)d->critic_t, (const float *)d->m_actor,
+                           (const float *)d->v_actor, (const float *)d->m_critic, (const float *)d->v_critic})
+        if (((uintptr_t)p & 15) != 0) return set_error(SHEMS_ERR_ARG, "%s: parameter and moment blocks must be 16-byte aligned", fn);
+    LayoutArgs A{*d, t->actor, t->critic, g->count > 1 ? g->stride_bytes : 0};
+    const dim3 grid(32, 2, (unsigned)g->count);
+    if (to_tiled) hipLaunchKernelGGL(k_tp_w2_layout<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_tp_w2_layout<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    return hip_ok(hipGetLastError(), fn);
+}
+extern "C" int shems_group_w2_to_tiled(const shems_ddpg *d0, const shems_group *g, const shems_group_w2t *t, void *stream)
+{
+    return w2_layout("shems_group_w2_to_tiled", true, d0, g, t, stream);
+}
+extern "C" int shems_group_w2_to_flux(const shems_ddpg *d0, const shems_group *g, const shems_group_w2t *t, void *stream)
+{
+    return w2_layout("shems_group_w2_to_flux", false, d0, g, t, stream);
 }

@@ -111,6 +111,9 @@ struct ActArgs {
     int gcount;
     int64_t gstride;
     int64_t genvs;
+    // learner groups on the tiled working layout (shems_group_w2t): learner 0's actor region; W2 is read from its p arrays instead of
+    // from the Flux-order block (the free-running forms of k_act only).  null: Flux order.
+    const float *w2t;
 };
 
 template <class T>
@@ -456,14 +459,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_act(ActArgs A)
     // One address pair per chunk: the chunk's base is wave-uniform (SGPR pair), a lane's 32-bit offset for piece q is constant over the
     // whole kernel (8 registers), and the instruction's immediate -- added to the global AND the LDS address -- selects the LDS piece:
     //   global = (W2 + 512 w + 32000 c) + [lane part + 4000 q - 1024 (q - 4)] + 1024 (q - 4),   LDS = (ring buffer + 4096) + 1024 (q - 4)
-    const char *wsbase = W2g + wave * 512;
+    // Tiled working layout of a learner group (A.w2t: [kt][nt][m | v | p | target][64][64], 64 KB per tile): the wave's 128 columns are the
+    // n-tiles 2 w and 2 w + 1, chunk c = rows 16 (c & 3) .. of k-tile c / 4, a row of a tile 256 contiguous bytes.  The same three-part
+    // address -- wave-uniform chunk base, a lane's constant per piece, the immediate -- with other constants: a piece (rows 2 q, 2 q + 1
+    // x 128 columns = 1 KB of LDS) takes lanes 0..15 / 16..31 from the two tiles' row 2 q and lanes 32..63 likewise from row 2 q + 1.
+    // Pad rows / columns are zeros there (nothing runs into the next row).
+    const bool tiled = A.w2t != nullptr;
+    constexpr size_t kTlTile = 4 * 64 * 64 * 4, kTlP = 2 * 64 * 64 * 4;          // bytes: one tile's four arrays; offset of its p array
+    const char *wsbase = tiled ? reinterpret_cast<const char *>(gsh(A.w2t, goff)) + kTlP + (size_t)wave * (2 * kTlTile) : W2g + wave * 512;
     uint32_t wvoff[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) wvoff[q] = (uint32_t)((lane >> 5) * (kH2 * 4) + (lane & 31) * 16 + q * (2 * kH2 * 4) - (q - 4) * 1024);
+    for (int q = 0; q < 8; ++q)
+        wvoff[q] = tiled ? (uint32_t)(((lane & 31) >> 4) * kTlTile + (lane >> 5) * 256 + (lane & 15) * 16 + q * 512 - (q - 4) * 1024)
+                         : (uint32_t)((lane >> 5) * (kH2 * 4) + (lane & 31) * 16 + q * (2 * kH2 * 4) - (q - 4) * 1024);
     const uint32_t wf_lds = lds_addr(Wf) + 4 * 1024;          // piece 4 of ring buffer 0
     // (asm LDS-DMA: see glds16_asm -- the compiler's LDS / VMEM waits stay exact)
+#define FREE_CHUNK_OFF(chunk) (tiled ? (size_t)((chunk) >> 2) * (8 * kTlTile) + (size_t)((chunk) & 3) * (kKC * 256) : (size_t)(chunk) * (kKC * kH2 * 4))
 #define FREE_PIECE(chunk, q)                                                                      \
-    glds16_asm_piece8(wsbase + (size_t)(chunk) * (kKC * kH2 * 4), wvoff[q],                        \
+    glds16_asm_piece8(wsbase + FREE_CHUNK_OFF(chunk), wvoff[q],                                   \
                       wf_lds + ((chunk) % (RD ? RD : 1)) * (kFreeChunkFloats * 4), (q))
 #define STAGE0_DMA()                                                                              \
     do {                                                                                          \
@@ -1713,6 +1726,10 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     const bool want_sum = a.block_reward != nullptr;          // per-tile reward sums: a form whose one workgroup finishes the whole tile
 #endif
     const int64_t cnt = a.m - a.m0;                           // envs of this launch (a range launch: every form writes the same bytes)
+    if (a.w2t) {                                              // tiled learner group: the free-running forms read W2 from the tiled regions
+        const int tmt = pick_tm(cnt);
+        return tmt == 4 ? launch_act<4, 4, 2>(a, st) : tmt == 2 ? launch_act<2, 4, 2>(a, st) : launch_act<1, 4, 2>(a, st);
+    }
     if (form4 == 2 && form < 0 && cnt > 8192 && a.gcount <= 1) return launch_act2(a, st);
     if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
     const int tm = pick_tm(cnt);
@@ -1777,7 +1794,10 @@ int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
     if (n_envs <= 0 || !out || cap < 2) return set_error(SHEMS_ERR_ARG, "shems_act_step_kernel: bad arguments");
     const int form = act_form(), form4 = act_form4();
     const char *name;
-    if (form4 == 2 && ((form < 0 && n_envs > 8192 && !grouped) || form == 12)) name = "shems::k_act2";
+    if (grouped == 2) {                                       // a learner group on the tiled working layout
+        const int tmt = pick_tm(n_envs);
+        name = tmt == 4 ? "shems::k_act<4, 4, 2>" : tmt == 2 ? "shems::k_act<2, 4, 2>" : "shems::k_act<1, 4, 2>";
+    } else if (form4 == 2 && ((form < 0 && n_envs > 8192 && !grouped) || form == 12)) name = "shems::k_act2";
     else {
         const int tm = pick_tm(n_envs);
         if (tm == 4) name = form4 == 0 ? "shems::k_act<4, 4, 0>" : "shems::k_act<4, 4, 2>";
@@ -1897,33 +1917,48 @@ int shems_wide_act_step_dev(const shems_view *v, const shems_act_params *p, int3
     return wide_act(a, l1, l2, d_ws, (hipStream_t)stream);
 }
 
-int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,
-                             double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
+static int act_step_group(const char *fn, const shems_view *v, const shems_act_params *p0, const shems_group *g, const float *w2t, float *d_a,
+                          double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
 {
-    if (int rc = check_act(p0, "shems_act_step_group_dev")) return rc;
-    if (int rc = check_view(v, "shems_act_step_group_dev")) return rc;
+    if (int rc = check_act(p0, fn)) return rc;
+    if (int rc = check_view(v, fn)) return rc;
     if (!g || g->count < 1 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
-        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: shems_group needs count >= 1 and a 16-byte-multiple stride");
+        return set_error(SHEMS_ERR_ARG, "%s: shems_group needs count >= 1 and a 16-byte-multiple stride", fn);
     if (g->envs_per_learner < 128 || g->envs_per_learner % 128 != 0 || g->envs_per_learner * g->count != v->n_envs)
-        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: envs_per_learner must be a multiple of 128 and count * envs_per_learner == n_envs "
-                         "(got %lld x %d for %lld envs)", (long long)g->envs_per_learner, g->count, (long long)v->n_envs);
+        return set_error(SHEMS_ERR_ARG, "%s: envs_per_learner must be a multiple of 128 and count * envs_per_learner == n_envs "
+                         "(got %lld x %d for %lld envs)", fn, (long long)g->envs_per_learner, g->count, (long long)v->n_envs);
     ActArgs a;
     std::memset(&a, 0, sizeof a);
     a.v = *v; a.p = *p0; a.obs = v->obs; a.m = v->n_envs; a.a_out = d_a;
     a.returns_acc = d_returns_acc;
     a.do_step = 1;
     a.gcount = g->count; a.gstride = g->count > 1 ? g->stride_bytes : 0; a.genvs = g->envs_per_learner;
+    a.w2t = w2t;
     if (ring0 && window && window->count > 0) {
         if (ring0->capacity <= 0 || !ring0->s || !ring0->a || !ring0->r || !ring0->s2 || !ring0->done)
-            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: incomplete replay ring");
+            return set_error(SHEMS_ERR_ARG, "%s: incomplete replay ring", fn);
         if (window->count > ring0->capacity || window->count > g->envs_per_learner || window->pos < 0)
-            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: ring window larger than the ring or a learner's env block");
+            return set_error(SHEMS_ERR_ARG, "%s: ring window larger than the ring or a learner's env block", fn);
         if (window->offset < 0 || window->offset >= g->envs_per_learner)
-            return set_error(SHEMS_ERR_ARG, "shems_act_step_group_dev: ring window offset %lld outside a learner's block of %lld envs",
+            return set_error(SHEMS_ERR_ARG, "%s: ring window offset %lld outside a learner's block of %lld envs", fn,
                              (long long)window->offset, (long long)g->envs_per_learner);
         a.ring = *ring0; a.win = *window; a.use_ring = 1;
     }
     return dispatch_act(a, (hipStream_t)stream);
+}
+
+int shems_act_step_group_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, float *d_a,
+                             double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
+{
+    return act_step_group("shems_act_step_group_dev", v, p0, g, nullptr, d_a, d_returns_acc, ring0, window, stream);
+}
+
+int shems_act_step_group_tiled_dev(const shems_view *v, const shems_act_params *p0, const shems_group *g, const shems_group_w2t *t, float *d_a,
+                                   double *d_returns_acc, const shems_replay *ring0, const shems_ring_window *window, void *stream)
+{
+    if (!t || !t->actor || ((uintptr_t)t->actor & 15) != 0)
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_tiled_dev: shems_group_w2t.actor must be a 16-byte aligned device pointer");
+    return act_step_group("shems_act_step_group_tiled_dev", v, p0, g, t->actor, d_a, d_returns_acc, ring0, window, stream);
 }
 
 }  // extern "C"

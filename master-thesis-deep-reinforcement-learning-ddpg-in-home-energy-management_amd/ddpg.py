@@ -144,9 +144,10 @@ def _declare():
 
 def act_kernel_name(n_envs, grouped=False):
     """The kernel the fused-step dispatcher runs for n_envs envs, by its profiler name (shems_act_step_kernel: the dispatcher's own
-    decision, environment overrides included) -- bench.py's roofline.kernel."""
+    decision, environment overrides included) -- bench.py's roofline.kernel.  grouped: False / True = a learner group in Flux order /
+    2 = a learner group on the tiled working layout."""
     buf = C.create_string_buffer(96)
-    _capi.check(_declare().shems_act_step_kernel(int(n_envs), 1 if grouped else 0, buf, 96))
+    _capi.check(_declare().shems_act_step_kernel(int(n_envs), int(grouped), buf, 96))
     return buf.value.decode()
 
 
@@ -350,6 +351,9 @@ class Agent:
                      pn_sigma=self.pn_sigma, fused=self.fused))
 
     def restore(self, snap):
+        hook = getattr(self, "_before_param_write", None)
+        if hook is not None:
+            hook()
         tensors, host = snap
         for k, v in tensors.items():
             getattr(self, k).copy_(v)
@@ -373,6 +377,9 @@ class Agent:
         """actor / critic: flat Flux-layout vectors, either of this learner's network size (padded here) or already in the (250, 500)
         layout."""
         t = self.torch
+        hook = getattr(self, "_before_param_write", None)      # a learner of a group on the tiled working layout (group.py)
+        if hook is not None:
+            hook()
         for name, vec, n_lay, n_own in (("actor", actor, self.n_actor, net_size(STATE, ACTION, self.hidden)),
                                         ("critic", critic, self.n_critic, net_size(STATE + ACTION, 1, self.hidden))):
             if vec is not None and np.asarray(vec).size not in (n_lay, n_own):
@@ -796,13 +803,26 @@ class TrainWorkload:
             import os
             import sys
             log = lambda m: print(m, file=sys.stderr, flush=True)
+            # How the two gradient all-reduces of an update travel (SHEMS_DP):
+            #   torch  (default)  torch.distributed all_reduce on the gradient buffers between the launches ("nccl" = RCCL on ROCm) -- the one
+            #                     path whose collective library every multi-GPU PyTorch job on this image exercises.  It is the default because
+            #                     NO path of this code has exchanged a byte between two GPUs yet: until a SCALE record exists the
+            #                     default is the form with the fewest unknowns, not the fastest projected one.
+            #   native            RCCL called in the update's own stream from native code (csrc/shems_dp.hip; a second communicator, made by
+            #                     vote, self-tested, falling back to torch on any rank's failure): 63.9 us against 80.6-88.1 us per step with a
+            #                     one-rank communicator on one GPU.
+            #   direct            no collective: peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg).
             native, direct = None, False
+            how = os.environ.get("SHEMS_DP", "torch")
+            if how not in ("torch", "native", "direct"):
+                raise ValueError("SHEMS_DP must be torch, native or direct")
             if not self.agent.wide:
-                if os.environ.get("SHEMS_DP") == "direct":          # opt-in: gradients through peer-mapped inboxes, no collective launch
+                if how == "direct":
                     native = direct_comm(dist, log=log)
                     direct = native is not None
-                if native is None:
+                if how == "native" or (how == "direct" and native is None):
                     native = native_comm(dist, log=log)
+            self.dp_requested = how
             self.agent.enable_data_parallel(dist, native=native, direct=direct)
             if os.environ.get("SHEMS_DP_OVERLAP") in ("0", "1"):   # A/B knob: "1" = the critic's all-reduce asynchronous, under the actor's E products
                 self.agent.dp_overlap = os.environ["SHEMS_DP_OVERLAP"] == "1"
@@ -1092,6 +1112,7 @@ class TrainWorkload:
                     "direct exchange through peer-mapped inboxes inside the ADAM sweeps (k_adam_xchg), no collective launch" if getattr(self.agent.sync, "direct", False) else
                     "RCCL all-reduce in the update's own stream, issued from native code (shems_ddpg_update_dp)" if self.agent.sync.native is not None else
                     "torch.distributed all_reduce (its own stream)"),
+                "dp_requested": getattr(self, "dp_requested", None),
                 "replay_window_envs_per_step": self.win, "update_us": getattr(self, "update_us", None),
                 "update_mflop": 307.8 if self.hidden == (L1, L2) else 20 * (10 * self.hidden[0] + self.hidden[0] * self.hidden[1] + 1.5 * self.hidden[1]) * BATCH_SIZE / 1e6,
                 "hidden": list(self.hidden), "data_parallel": getattr(self, "dp", None)}

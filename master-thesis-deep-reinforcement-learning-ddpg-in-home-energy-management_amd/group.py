@@ -25,15 +25,28 @@ class Group(C.Structure):              # shems_group
     _fields_ = [("count", C.c_int32), ("reserved", C.c_int32), ("stride_bytes", C.c_int64), ("envs_per_learner", C.c_int64)]
 
 
+class GroupW2T(C.Structure):           # shems_group_w2t
+    _fields_ = [("actor", C.c_void_p), ("critic", C.c_void_p)]
+
+
+W2T_FLOATS = 32 * 4 * 64 * 64          # SHEMS_W2T_FLOATS: [4 k-tiles][8 n-tiles][m | v | p | target][64][64] per network
+
+
 def _declare_group():
     L = _declare()
     if getattr(L, "_group_declared", False):
         return L
     vp, i64 = C.c_void_p, C.c_int64
     from .ddpg import ActParams, DdpgArgs
-    PD, PG, PR = C.POINTER(DdpgArgs), C.POINTER(Group), C.POINTER(_capi.Replay)
+    PD, PG, PR, PT = C.POINTER(DdpgArgs), C.POINTER(Group), C.POINTER(_capi.Replay), C.POINTER(GroupW2T)
     L.shems_act_step_group_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), PG, vp, vp, PR, C.POINTER(RingWindow), vp]
+    L.shems_act_step_group_tiled_dev.argtypes = [C.POINTER(_capi.View), C.POINTER(ActParams), PG, PT, vp, vp, PR, C.POINTER(RingWindow), vp]
     dbl = C.c_double
+    L.shems_ddpg_group_update_tiled.argtypes = [PD, PR, PG, PT, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, C.c_int32, vp]
+    L.shems_group_w2_to_tiled.argtypes = [PD, PG, PT, vp]
+    L.shems_group_w2_to_flux.argtypes = [PD, PG, PT, vp]
+    for fn in ("shems_act_step_group_tiled_dev", "shems_ddpg_group_update_tiled", "shems_group_w2_to_tiled", "shems_group_w2_to_flux"):
+        getattr(L, fn).restype = C.c_int
     L.shems_ddpg_group_update.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, vp]
     L.shems_ddpg_group_update.restype = C.c_int
     L.shems_ddpg_group_update_tp.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, C.c_int32, vp]
@@ -63,7 +76,15 @@ class LearnerGroup:
     # bit-identical to Agent.replay).  Default: throughput from TP_MIN_LEARNERS learners up.
     TP_MIN_LEARNERS = 16
 
-    def __init__(self, count, envs_per_learner, seed=1231, rng_seed=None, capacity=MEM_SIZE, sigma=NOISE_SIGMA, device=None, form=None):
+    def __init__(self, count, envs_per_learner, seed=1231, rng_seed=None, capacity=MEM_SIZE, sigma=NOISE_SIGMA, device=None, form=None, tiled=None):
+        """tiled (throughput form only; default on, SHEMS_GROUP_TILED=0 switches it off): the layer-2 state of both networks (W2, its
+        ADAM moments, the target's W2) is kept in the TILED working layout (shems_group_w2t, include/shems_hip.h) while the group trains:
+        one contiguous 64 KB piece per 64 x 64 tile for the update's W2-gradient / ADAM launches (4.78 against 3.85 TB/s), read from
+        there by the forward / D1 launches and by the fused act/step launch.  The Flux-order blocks -- what `learners[l].actor` etc. ARE --
+        keep everything else and are the API's view of W2: `flux_()` brings their W2 ranges up to date (call it before reading a learner's
+        tensors, evaluating a learner through its Agent, or saving), `Agent.set_params` on a learner of the group is noticed by itself,
+        any other write into those tensors must be followed by `flux_changed()`."""
+        import os
         import torch
         self.torch = torch
         self.L = _declare_group()
@@ -72,6 +93,10 @@ class LearnerGroup:
         if self.form not in ("throughput", "latency"):
             raise ValueError("form must be 'throughput' or 'latency'")
         self.store_grad = False                    # throughput form: also leave the gradients in grad_actor / grad_critic (tests)
+        self.tiled = (self.form == "throughput" and os.environ.get("SHEMS_GROUP_TILED", "1") != "0") if tiled is None else bool(tiled)
+        if self.tiled and self.form != "throughput":
+            raise ValueError("the tiled working layout belongs to the throughput form")
+        self._flux_valid, self._tiled_valid = True, False          # which copy of the layer-2 state is current (both may be)
         if self.count < 1 or self.envs_per_learner % 128 != 0:
             raise ValueError("a learner group needs count >= 1 and envs_per_learner a multiple of 128")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -83,6 +108,7 @@ class LearnerGroup:
         layout, off = {}, 0
         for name, n in (("actor", N_ACTOR), ("critic", N_CRITIC), ("actor_t", N_ACTOR), ("critic_t", N_CRITIC),
                         ("m_actor", N_ACTOR), ("v_actor", N_ACTOR), ("m_critic", N_CRITIC), ("v_critic", N_CRITIC),
+                        ("w2t_actor", W2T_FLOATS if self.tiled else 0), ("w2t_critic", W2T_FLOATS if self.tiled else 0),
                         ("grad_actor", N_ACTOR), ("grad_critic", N_CRITIC), ("s_min", STATE), ("s_max", STATE), ("losses", 2),
                         ("ws", nws.value), ("ring_s", self.capacity * STATE), ("ring_a", self.capacity * ACTION),
                         ("ring_r", self.capacity), ("ring_s2", self.capacity * STATE), ("ring_done", (self.capacity + 3) // 4)):
@@ -96,6 +122,8 @@ class LearnerGroup:
             tens = {k: v(k) for k in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic",
                                       "grad_actor", "grad_critic", "s_min", "s_max", "ws", "losses")}
             self.learners.append(Agent(seed=self.seed + l, rng_seed=self.rng_seed + l, sigma=sigma, device=self.device, tensors=tens))
+            if self.tiled:
+                self.learners[-1]._before_param_write = self._before_flux_write
             done = v("ring_done").view(torch.uint8)[:self.capacity]
             self.rings.append(ReplayRing(self.capacity, tensors=(v("ring_s").view(self.capacity, STATE), v("ring_a").view(self.capacity, ACTION),
                                                                  v("ring_r"), v("ring_s2").view(self.capacity, STATE), done)))
@@ -108,6 +136,44 @@ class LearnerGroup:
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    # ---- the tiled working layout of the layer-2 state -----------------------------------------------------------------------------
+    def w2t_struct(self):
+        base = self.slab.data_ptr()
+        return GroupW2T(base + 4 * self.layout["w2t_actor"][0], base + 4 * self.layout["w2t_critic"][0])
+
+    def _use_tiled(self):
+        """Before a launch that reads / writes the tiled regions: bring them up to date from the Flux-order blocks if those were written."""
+        if self.tiled and self.form != "throughput":
+            self.flux_()                               # the form was switched on a tiled group: the latency form speaks Flux order
+            self._tiled_valid = False
+            return False
+        if not self.tiled:
+            return False
+        if not self._tiled_valid:
+            d, g, t = self.learners[0]._ddpg_args(), self.struct(), self.w2t_struct()
+            _capi.check(self.L.shems_group_w2_to_tiled(C.byref(d), C.byref(g), C.byref(t), self._stream()))
+            self._tiled_valid = True
+        return True
+
+    def flux_(self):
+        """Bring the W2 ranges of the Flux-order blocks (learners[l].actor / critic / actor_t / critic_t / m_* / v_*) up to date."""
+        if self.tiled and not self._flux_valid:
+            d, g, t = self.learners[0]._ddpg_args(), self.struct(), self.w2t_struct()
+            _capi.check(self.L.shems_group_w2_to_flux(C.byref(d), C.byref(g), C.byref(t), self._stream()))
+            self._flux_valid = True
+        return self
+
+    def flux_changed(self):
+        """The caller wrote into Flux-order tensors of the group (after flux_()): the tiled regions are re-made before their next use."""
+        if self.tiled and not self._flux_valid:
+            raise RuntimeError("flux_changed(): the Flux-order blocks were stale when they were written -- call flux_() before writing into them")
+        self._tiled_valid = False
+        return self
+
+    def _before_flux_write(self):
+        self.flux_()
+        self._tiled_valid = False
 
     @property
     def n_envs(self):
@@ -143,9 +209,15 @@ class LearnerGroup:
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         r0 = self.rings[0].struct()
         w = RingWindow(*window) if window is not None else None
-        _capi.check(self.L.shems_act_step_group_dev(C.byref(v), C.byref(p), C.byref(g), ptr(a_out), ptr(returns_acc),
-                                                    C.byref(r0) if w is not None else None, C.byref(w) if w is not None else None,
-                                                    self._stream()))
+        if self._use_tiled():
+            t = self.w2t_struct()
+            _capi.check(self.L.shems_act_step_group_tiled_dev(C.byref(v), C.byref(p), C.byref(g), C.byref(t), ptr(a_out), ptr(returns_acc),
+                                                              C.byref(r0) if w is not None else None, C.byref(w) if w is not None else None,
+                                                              self._stream()))
+        else:
+            _capi.check(self.L.shems_act_step_group_dev(C.byref(v), C.byref(p), C.byref(g), ptr(a_out), ptr(returns_acc),
+                                                        C.byref(r0) if w is not None else None, C.byref(w) if w is not None else None,
+                                                        self._stream()))
         if w is not None:
             for ring in self.rings:
                 ring.pushed += int(window[1])
@@ -157,7 +229,13 @@ class LearnerGroup:
         d = a0._ddpg_args()
         st = self._stream()
         tick = self.updates if tick is None else tick
-        if self.form == "throughput":
+        if self._use_tiled():
+            t = self.w2t_struct()
+            _capi.check(self.L.shems_ddpg_group_update_tiled(C.byref(d), C.byref(r0), C.byref(g), C.byref(t), len(self.rings[0]), self.rng_seed, int(tick) & 0xFFFFFFFF,
+                                                             a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], a0.eta_act, a0.bp_actor[0], a0.bp_actor[1],
+                                                             1 if self.store_grad else 0, st))
+            self._flux_valid = False
+        elif self.form == "throughput":
             _capi.check(self.L.shems_ddpg_group_update_tp(C.byref(d), C.byref(r0), C.byref(g), len(self.rings[0]), self.rng_seed, int(tick) & 0xFFFFFFFF,
                                                           a0.eta_crit, a0.bp_critic[0], a0.bp_critic[1], a0.eta_act, a0.bp_actor[0], a0.bp_actor[1],
                                                           1 if self.store_grad else 0, st))
@@ -278,7 +356,7 @@ class GroupWorkload:
         torch.cuda.synchronize()
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
-        act = dict(kernel=act_kernel_name(self.n, grouped=True), avg_us=avg_us, median_us=med_us, launches=reps,
+        act = dict(kernel=act_kernel_name(self.n, grouped=2 if g.tiled else True), avg_us=avg_us, median_us=med_us, launches=reps,
                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
         if self.update_us <= avg_us:
             return act
@@ -302,4 +380,5 @@ class GroupWorkload:
     def extra(self):
         return {"learners": self.count, "envs_per_learner": self.n // self.count, "updates_per_step": self.count,
                 "batch_size": BATCH_SIZE, "mem_size": MEM_SIZE, "replay_window_envs_per_step": self.win,
-                "group_update_us": getattr(self, "update_us", None), "update_mflop": 307.8, "update_form": self.group.form}
+                "group_update_us": getattr(self, "update_us", None), "update_mflop": 307.8, "update_form": self.group.form,
+                "w2_layout": "tiled (shems_group_w2t: one 64 KB piece per 64 x 64 tile of W2 | m | v | target)" if self.group.tiled else "Flux order"}

@@ -149,9 +149,10 @@ def _check_data_parallel_fields(d, world):
     # (gloo on one device is host-synchronous: a 700 us update next to a 25 us k_act -- the difference of two such group times is
     # noise here and may come out below zero; on RCCL the collectives are stream-ordered and it is the k_act time at the shard size)
     assert abs(d["update_us"] - dp["update_us_dp"]) < 1e-6 and abs(d["roofline"]["kernel_avg_us"]) < 1e4
-    # round 4: how the gradients travel.  Two ranks on ONE device cannot have an RCCL communicator ("Duplicate GPU detected"), so the
-    # rehearsal must have fallen back -- on every rank, by vote -- to torch.distributed, and the line says which path ran
-    assert d["dp_exchange"].startswith("torch.distributed") and d["loop"] == "host"
+    # how the gradients travel: the line says which path was asked for and which ran.  Round 6: torch.distributed is the DEFAULT at
+    # world > 1 (no path of this code has moved a byte between two GPUs yet; the native RCCL-in-stream form and the direct exchange are
+    # opt-in, SHEMS_DP=native / direct)
+    assert d["dp_requested"] == "torch" and d["dp_exchange"].startswith("torch.distributed") and d["loop"] == "host"
     assert d["replica_crc32_distinct"] == 1                             # every rank's learner ended with the same bytes (gathered in finish())
 
 
@@ -201,11 +202,15 @@ def test_direct_gradient_exchange_two_ranks_on_one_device():
     stores).  With two replicas the rank-order sum IS the all-reduce's sum (a + b), so the learner must end with the bytes of the
     torch.distributed (gloo) path; no exchange wait may have given up (TrainWorkload.finish raises otherwise)."""
     out = {}
-    for how in ("torch", "direct"):
+    for how in ("torch", "direct", "native"):
         d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "48", "--warmup", "6", "--envs", "4096", "--prewarm-s", "0"],
                  env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo", "SHEMS_DP": how})
-        assert d["n_gpus"] == 2 and d["value"] > 0
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["dp_requested"] == how
         out[how] = d
+    # SHEMS_DP=native on this rehearsal: two ranks on ONE device cannot have an RCCL communicator ("Duplicate GPU detected"), so the attempt
+    # must fall back -- on every rank, by vote -- to torch.distributed; the line says what was asked for and what ran
+    assert out["native"]["dp_exchange"].startswith("torch.distributed") and out["native"]["loop"] == "host"
+    assert out["native"]["learner_crc32"] == out["torch"]["learner_crc32"]
     assert out["direct"]["dp_exchange"].startswith("direct exchange") and out["direct"]["loop"] == "native"
     assert out["torch"]["dp_exchange"].startswith("torch.distributed") and out["torch"]["loop"] == "host"
     assert out["direct"]["learner_crc32"] == out["torch"]["learner_crc32"], (out["direct"]["learner_crc32"], out["torch"]["learner_crc32"])

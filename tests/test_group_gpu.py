@@ -20,7 +20,7 @@ def _mods():
     return torch, S, D, G
 
 
-def _setup(L=3, E=256, cap=2400, mixed=False, form="latency"):
+def _setup(L=3, E=256, cap=2400, mixed=False, form="latency", tiled=None):
     torch, S, D, G = _mods()
     if mixed:                                       # the thesis grid: learner l trains on charger profile l mod 10 (ids 1-9, 98; LU1:47-58)
         ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
@@ -32,7 +32,7 @@ def _setup(L=3, E=256, cap=2400, mixed=False, form="latency"):
     else:
         tab = S.tables.synthetic_table("train", 98)
         env = S.ShemsBatch(L * E, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
-    grp = G.LearnerGroup(L, E, seed=21, rng_seed=77, capacity=cap, form=form)
+    grp = G.LearnerGroup(L, E, seed=21, rng_seed=77, capacity=cap, form=form, tiled=tiled)
     grp.populate_memory(env, seed=5)
     grp.min_max_buffer()
     env.reset_(9, episode=1)
@@ -150,12 +150,14 @@ def _assert_blocks_or_the_other_relu_decision(TD, g, evaluate, nets, in_dim, out
         return TD._assert_blocks(g, evaluate(flipped), in_dim, out_dim, what + " (tied relus decided the other way)"), True
 
 
-def _throughput_vs_float64(L, batch, check=None, ticks=(3, 4)):
+def _throughput_vs_float64(L, batch, check=None, ticks=(3, 4), tiled=None):
     """Two grouped updates in a row of an L-learner group (throughput form, store_grad on); the learners in `check` (default: all) are
-    held, per Flux.params block, to the float64 evaluation of DDPG.jl:121-145.  Returns (worst per-block errors, ties set aside)."""
+    held, per Flux.params block, to the float64 evaluation of DDPG.jl:121-145.  Returns (worst per-block errors, ties set aside, the
+    group).  tiled: the working layout of the layer-2 state (None = the default, tiled); results are read in Flux order (flux_())."""
     import test_ddpg_gpu as TD
     ties = []
-    torch, S, D, G, env, grp = _setup(L=L, E=128, cap=2400, form="throughput")
+    torch, S, D, G, env, grp = _setup(L=L, E=128, cap=2400, form="throughput", tiled=tiled)
+    assert grp.tiled == (True if tiled is None else tiled)
     grp.store_grad = True
     rng = np.random.default_rng(5)
     check = list(range(L)) if check is None else sorted(set(int(l) for l in check))
@@ -176,6 +178,7 @@ def _throughput_vs_float64(L, batch, check=None, ticks=(3, 4)):
     worst = {}
     for tick in ticks:
         grp.replay(tick=tick)
+        grp.flux_()
         torch.cuda.synchronize()
         for l in check:
             ag, h = grp.learners[l], host[l]
@@ -235,13 +238,20 @@ def _throughput_vs_float64(L, batch, check=None, ticks=(3, 4)):
     assert bool(torch.isfinite(grp.slab[:, :end]).all())
     print(f"throughput form, {L} learners, batch {batch}: worst per-block gradient error (fraction of the block's max-abs):", worst,
           "comparisons that needed a tied relu decided the other way:", ties)
-    return worst, ties
+    return worst, ties, grp
 
 
 @pytest.mark.parametrize("L,batch", [(5, 120), (3, 128), (2, 17), (11, 120), (48, 120)])      # < 48 learners: the narrow launch shapes; 48: the wide ones
 def test_throughput_form_matches_float64_oracle_per_block(L, batch):
-    worst, ties = _throughput_vs_float64(L, batch)
+    worst, ties, grp = _throughput_vs_float64(L, batch)
     assert ties == EXPECTED_TIES[(L, batch)], ties
+    # the same two updates on the Flux-order layout (round 5's form, SHEMS_GROUP_TILED=0): the tiled working layout changes where the
+    # layer-2 state lives, not one operation on it -- every learner's networks, targets, moments and gradients bit for bit
+    _, _, grp_f = _throughput_vs_float64(L, batch, check=(), tiled=False)
+    torch = grp.torch
+    for name in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic", "grad_actor", "grad_critic", "losses"):
+        (o, n), (of, nf) = grp.layout[name], grp_f.layout[name]
+        assert n == nf and torch.equal(grp.slab[:, o:o + n].contiguous().view(torch.int32), grp_f.slab[:, of:of + nf].contiguous().view(torch.int32)), name
 
 
 def test_throughput_form_at_the_benched_width_400_learners():
@@ -251,7 +261,7 @@ def test_throughput_form_at_the_benched_width_400_learners():
     batch 120, two updates in a row."""
     L = 400
     pick = [0, 1, 199, 398, 399] + [int(x) for x in np.random.default_rng(400).choice(np.arange(2, 398), 5, replace=False)]
-    worst, ties = _throughput_vs_float64(L, 120, check=pick)
+    worst, ties, grp = _throughput_vs_float64(L, 120, check=pick)
     assert ties == EXPECTED_TIES[(L, 120)], ties
 
 
@@ -269,6 +279,8 @@ def test_one_remembered_transition_per_update_in_reference_push_order():
     a = torch.empty((n, 2), dtype=torch.float32, device="cuda")
     TP_IDX = 2 * 12 * 128 + 2 * 128                 # csrc/shems_gupd.hip: [BP] int32 sampled ring slots behind the two input blocks, r, done
     prev_s2 = None
+    pushed0 = grp.rings[0].pushed                   # populate_memory's count (whole rollouts: >= capacity)
+    assert all(r.pushed == pushed0 for r in grp.rings) and all(len(r) == 2400 for r in grp.rings)
     for step in range(5):
         pre = env.state
         pos = grp.rings[0].pos
@@ -281,7 +293,7 @@ def test_one_remembered_transition_per_update_in_reference_push_order():
         torch.cuda.synchronize()
         post, ah, rh = env.state, a.cpu().numpy(), ret.cpu().numpy()
         for l, ring in enumerate(grp.rings):
-            assert ring.pushed == 2400 + step + 1                                            # exactly one per step
+            assert ring.pushed == pushed0 + step + 1                                            # exactly one per step
             e = l * E                                                                         # the learner's household 0
             assert (U.bits32(ring.s[pos].cpu().numpy()) == U.bits32(pre[e])).all()
             assert (U.bits32(ring.a[pos].cpu().numpy()) == U.bits32(ah[e])).all() and np.abs(ah[e]).max() <= 1.0      # as act() returned it, not scale_action's
@@ -316,12 +328,14 @@ def test_throughput_and_latency_forms_agree_and_leave_no_gradient_unless_asked()
     torch, S, D, G, env, grp = _setup(L=4, E=128, cap=2400, form="throughput")
     snap = grp.slab.clone()
     grp.replay(tick=2)
+    grp.flux_()                                    # (tiled working layout: the W2 ranges of the Flux-order blocks are made current)
     torch.cuda.synchronize()
     tp = grp.slab.clone()
     for name in ("grad_actor", "grad_critic"):
         off, cnt = grp.layout[name]
         assert torch.equal(tp[:, off:off + cnt], snap[:, off:off + cnt]), name
     grp.slab.copy_(snap)
+    grp.flux_changed()                             # the Flux-order blocks were written behind the group's back
     for ag in grp.learners:
         ag.bp_critic, ag.bp_actor, ag.updates = [0.9, 0.999], [0.9, 0.999], 0
     grp.updates = 0
@@ -336,6 +350,69 @@ def test_throughput_and_latency_forms_agree_and_leave_no_gradient_unless_asked()
     for name in ("losses",):
         off, cnt = grp.layout[name]
         assert torch.allclose(tp[:, off:off + cnt], grp.slab[:, off:off + cnt], rtol=1e-4, atol=1e-5)
+
+
+def test_tiled_layout_round_trip_and_fused_step_reads_the_same_weights():
+    """shems_group_w2_to_tiled / _to_flux are inverse on the W2 ranges and touch nothing else; pad rows / columns of the tiled regions are
+    zero; the fused act/step launch reading every learner's actor W2 from its tiled region (the free-running k_act forms) leaves the bytes
+    the Flux-order launch leaves: actions, env state, returns, ring."""
+    import ctypes as C
+    torch, S, D, G, env, grp = _setup(L=16, E=128, cap=2400, form="throughput")
+    assert grp.tiled
+    rng = np.random.default_rng(3)
+    for name in ("actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic"):       # distinct values in every array
+        o, n = grp.layout[name]
+        grp.slab[:, o:o + n] = torch.from_numpy(rng.normal(0, 0.05, (grp.count, n)).astype(np.float32)).cuda()
+    grp.flux_changed()
+    before = grp.slab.clone()
+    assert grp._use_tiled() and grp._tiled_valid
+    torch.cuda.synchronize()
+    o, n = grp.layout["w2t_actor"]
+    reg = grp.slab[:, o:o + n].view(grp.count, 4, 8, 4, 64, 64).cpu().numpy()                # [learner][kt][nt][m | v | p | target][row][col]
+    for a, name in enumerate(("m_actor", "v_actor", "actor", "actor_t")):
+        fo, _ = grp.layout[name]
+        w2 = before[:, fo + 2500:fo + 2500 + 125000].view(grp.count, 250, 500).cpu().numpy()
+        full = np.zeros((grp.count, 256, 512), np.float32)
+        full[:, :250, :500] = w2
+        want = full.reshape(grp.count, 4, 64, 8, 64).transpose(0, 1, 3, 2, 4)
+        assert np.array_equal(reg[:, :, :, a], want), name
+    # scribble over the Flux-order W2 ranges, then bring them back from the tiles: everything as before
+    for name in ("actor", "critic", "actor_t", "critic_t", "m_actor", "v_actor", "m_critic", "v_critic"):
+        fo, _ = grp.layout[name]
+        w2o = 2500 if "actor" in name else 3000
+        grp.slab[:, fo + w2o:fo + w2o + 125000] = -7.0
+    grp._flux_valid = False
+    grp.flux_()
+    torch.cuda.synchronize()
+    for name, (fo, n) in grp.layout.items():
+        if not name.startswith("w2t_"):
+            assert torch.equal(grp.slab[:, fo:fo + n].contiguous().view(torch.int32), before[:, fo:fo + n].contiguous().view(torch.int32)), name
+    # fused step: tiled against Flux order
+    n_envs = grp.n_envs
+    outs = []
+    st0, idx0, step0 = env.state, env.idx, env.step
+    ring0 = [tuple(t.clone() for t in (r.s, r.a, r.r, r.s2, r.done)) for r in grp.rings]
+    pushed0 = [r.pushed for r in grp.rings]
+    for tiled in (True, False):
+        env.state, env.idx, env.step = st0, idx0, step0
+        for r, old, pu in zip(grp.rings, ring0, pushed0):
+            for cur, o_ in zip((r.s, r.a, r.r, r.s2, r.done), old):
+                cur.copy_(o_)
+            r.pushed = pu
+        grp.tiled = tiled
+        a = torch.empty((n_envs, 2), dtype=torch.float32, device="cuda")
+        ret = torch.zeros(n_envs, dtype=torch.float64, device="cuda")
+        for t in range(3):
+            grp.tick = t
+            grp.act_step(env, train=True, tick=t, a_out=a, returns_acc=ret, window=(grp.rings[0].pos, *grp.ring_window(72, None)))
+        torch.cuda.synchronize()
+        outs.append((a.cpu().numpy(), ret.cpu().numpy(), env.state.copy(), [tuple(t.cpu().numpy() for t in (r.s, r.a, r.r, r.s2)) for r in grp.rings]))
+    grp.tiled = True
+    (a1, r1, s1, g1), (a2, r2, s2, g2) = outs
+    assert np.array_equal(a1, a2) and np.array_equal(r1, r2) and np.array_equal(s1, s2)
+    for x, y in zip(g1, g2):
+        assert all(np.array_equal(u, v) for u, v in zip(x, y))
+    env.check_error()
 
 
 def test_group_exploration_noise_is_keyed_by_the_global_env_index():

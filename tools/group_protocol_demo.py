@@ -42,6 +42,7 @@ for ep in range(1, episodes + 1):
     last = ret
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
+grp.flux_()             # (tiled working layout: the learners' Flux-order tensors are made current before anything reads them)
 finite = bool(torch.isfinite(grp.slab[:, :grp.layout["ws"][0]]).all())
 # evaluation: every learner on its own charger's eval table; the rule-based controller on the same starts
 scores, rule = np.zeros(L), {}

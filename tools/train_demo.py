@@ -70,6 +70,7 @@ for ep in range(1, gep + 1):
     last = ret
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
+grp.flux_()
 scores = [float(a.episode_(env_eval, None, train=False, num_steps=72, rng_ep=123, episode=1).mean().item()) for a in grp.learners]
 group = {"learners": L, "envs_per_learner": E, "episodes": gep, "updates_per_learner": grp.updates, "wall_s": wall,
          "train_return_first": [float(x) for x in first], "train_return_last": [float(x) for x in last], "eval_score_per_learner": scores}
