@@ -616,7 +616,8 @@ def main():
             if mode == "group":
                 # counters of the grouped update (all eight launches of one grouped replay()), only for the shape they were collected on
                 if (rec.get("learners") == args.learners and rec.get("envs_per_gpu") == args.envs and k["kernel"].startswith("grouped replay()")
-                        and rec.get("form") == getattr(wl.group, "form", None)):
+                        and rec.get("form") == getattr(wl.group, "form", None)
+                        and rec.get("w2_layout", "flux") == ("tiled" if getattr(wl.group, "tiled", False) else "flux")):
                     traffic = rec.get("bytes_as_read")
                     traffic_src = ("profiles/pmc_traffic.json (static: FETCH_SIZE + WRITE_SIZE as read over the eight launches of one grouped replay(), separate "
                                    "rocprofv3 --pmc passes of this command, " + str(rec.get("round")) + "; with the guide's 2x FETCH correction: "

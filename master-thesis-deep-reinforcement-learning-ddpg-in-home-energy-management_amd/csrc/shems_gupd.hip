@@ -797,6 +797,8 @@ __device__ __forceinline__ void d1_body(const NetArgs &A, const int bx, const in
 constexpr int GW_S = BP + 1;
 constexpr int GW_TS = 68;          // row stride of the row-major copy of the finished tile [64 k][68] (over the D2 panel)
 constexpr int GW_WGS = 4 * NT;     // k-tiles x n-tiles of 64 per learner
+// (Round 6 also built a four-workgroups-per-CU form -- the error signal from registers instead of LDS: 40 448 B, and a 128-register budget, which
+// spills 12 registers -- no gain at 400 learners (1.926-1.938 against 1.927-1.935 ms per step), 3 % slower at 32 (profiles/r06_gw2_ab.txt); removed.)
 constexpr int GW_LDS = (64 * GW_S + 2 * BP + 64 * 2 + 64 * 3 + W1K * BP) * 4;
 static_assert(64 * GW_TS <= 64 * GW_S, "the row-major copy of a tile fits the D2 panel it replaces");
 
@@ -852,9 +854,14 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
         const int k = k0 + 16 * it + (tid >> 4), n = n0 + 4 * (tid & 15);
         eidx[it] = (k < H1N && n < H2N) ? off_w2(IN) + k * H2N + n : -1;          // (500 is a multiple of 4: a float4 is all in or all out)
         if constexpr (TL) {
+            // (non-temporal: a tile's state is next touched one whole grouped update -- 4 GB of other traffic -- later; on the 64 KB
+            // pieces the hint is worth 4.90 -> 5.13 TB/s, a device copy's rate; on the Flux order's 256-byte pieces it costs a third:
+            // tools/micro/adam_stream.hip, profiles/r06_micro_adam_stream.txt)
             const float *q = tile + 1024 * it;
-            am[it] = *reinterpret_cast<const f32x4 *>(q + TL_M * TL_TILE); av[it] = *reinterpret_cast<const f32x4 *>(q + TL_V * TL_TILE);
-            ap[it] = *reinterpret_cast<const f32x4 *>(q + TL_P * TL_TILE); at[it] = *reinterpret_cast<const f32x4 *>(q + TL_T * TL_TILE);
+            am[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(q + TL_M * TL_TILE));
+            av[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(q + TL_V * TL_TILE));
+            ap[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(q + TL_P * TL_TILE));
+            at[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(q + TL_T * TL_TILE));
         } else {
             const int e = off_w2(IN) + min(k, H1N - 1) * H2N + min(n, H2N - 4);
             am[it] = *reinterpret_cast<const f32x4 *>(c.mt + e); av[it] = *reinterpret_cast<const f32x4 *>(c.vt + e);
@@ -934,8 +941,10 @@ __device__ __forceinline__ void gw2_body(const NetArgs &A, const int bx, const i
                 const int e = eidx[it];
                 if constexpr (TL) {
                     float *q = tile + 1024 * it;
-                    *reinterpret_cast<f32x4 *>(q + TL_M * TL_TILE) = am[it]; *reinterpret_cast<f32x4 *>(q + TL_V * TL_TILE) = av[it];
-                    *reinterpret_cast<f32x4 *>(q + TL_P * TL_TILE) = ap[it]; *reinterpret_cast<f32x4 *>(q + TL_T * TL_TILE) = at[it];
+                    __builtin_nontemporal_store(am[it], reinterpret_cast<f32x4 *>(q + TL_M * TL_TILE));
+                    __builtin_nontemporal_store(av[it], reinterpret_cast<f32x4 *>(q + TL_V * TL_TILE));
+                    __builtin_nontemporal_store(ap[it], reinterpret_cast<f32x4 *>(q + TL_P * TL_TILE));
+                    __builtin_nontemporal_store(at[it], reinterpret_cast<f32x4 *>(q + TL_T * TL_TILE));
                 } else {
                     *reinterpret_cast<f32x4 *>(c.mt + e) = am[it]; *reinterpret_cast<f32x4 *>(c.vt + e) = av[it];
                     *reinterpret_cast<f32x4 *>(c.p + e) = ap[it]; *reinterpret_cast<f32x4 *>(c.target + e) = at[it];

@@ -32,7 +32,7 @@ struct Args {
     AdamCtx c;
 };
 
-template <int LAYOUT>
+template <int LAYOUT, bool NTMP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_stream(Args A)
 {
     extern __shared__ float smem[];
@@ -60,8 +60,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             const int e3 = it * 1024 + 768 + tid;
             ok[it] = 64 * kt + (e3 >> 6) < K + 6 && true;                                   // (micro: rows only; the tail columns are streamed)
         }
-        am[it] = *reinterpret_cast<const f32x4 *>(S + im[it]); av[it] = *reinterpret_cast<const f32x4 *>(S + iv[it]);
-        ap[it] = *reinterpret_cast<const f32x4 *>(S + ip[it]); at[it] = *reinterpret_cast<const f32x4 *>(S + itg[it]);
+        if (NTMP) {
+            am[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(S + im[it])); av[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(S + iv[it]));
+            ap[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(S + ip[it])); at[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(S + itg[it]));
+        } else {
+            am[it] = *reinterpret_cast<const f32x4 *>(S + im[it]); av[it] = *reinterpret_cast<const f32x4 *>(S + iv[it]);
+            ap[it] = *reinterpret_cast<const f32x4 *>(S + ip[it]); at[it] = *reinterpret_cast<const f32x4 *>(S + itg[it]);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     if (smem[tid] == 123.0f) return;             // (keeps the dynamic LDS allocation: it sets the workgroups per CU)
@@ -85,29 +90,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
                 am[it][i] = m_; av[it][i] = v_; ap[it][i] = p_; at[it][i] = t_;
             }
         }
-        if (ok[it]) {
+        if (ok[it] && NTMP) {
+            __builtin_nontemporal_store(am[it], reinterpret_cast<f32x4 *>(S + im[it])); __builtin_nontemporal_store(av[it], reinterpret_cast<f32x4 *>(S + iv[it]));
+            __builtin_nontemporal_store(ap[it], reinterpret_cast<f32x4 *>(S + ip[it])); __builtin_nontemporal_store(at[it], reinterpret_cast<f32x4 *>(S + itg[it]));
+        } else if (ok[it]) {
             *reinterpret_cast<f32x4 *>(S + im[it]) = am[it]; *reinterpret_cast<f32x4 *>(S + iv[it]) = av[it];
             *reinterpret_cast<f32x4 *>(S + ip[it]) = ap[it]; *reinterpret_cast<f32x4 *>(S + itg[it]) = at[it];
         }
     }
 }
 
+// copy with 16 float4 per thread requested before the first store (64 KB per workgroup in flight, as the stream kernels)
 __global__ __launch_bounds__(256) void k_copy(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    for (int64_t b = (int64_t)blockIdx.x * 4096; b + 4096 <= n4; b += (int64_t)gridDim.x * 4096) {
+        f32x4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[b + j * 256 + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[b + j * 256 + threadIdx.x] = v[j];
+    }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, bool NTMP = false>
 static void run(const char *what, Args A, int L, int lds)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stream<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_stream<LAYOUT>, dim3(KT * NT, L), dim3(256), lds, 0, A);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stream<LAYOUT, NTMP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_stream<LAYOUT, NTMP>), dim3(KT * NT, L), dim3(256), lds, 0, A);
     hipDeviceSynchronize();
     const int reps = 10;
     hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_stream<LAYOUT>, dim3(KT * NT, L), dim3(256), lds, 0, A);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_stream<LAYOUT, NTMP>), dim3(KT * NT, L), dim3(256), lds, 0, A);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -140,6 +155,8 @@ int main(int argc, char **argv)
         run<3>("m, v tile-major; p, t row-major", mix3, L, lds);
         run<4>("m, v, t tile-major; p row-major", mix4, L, lds);
         run<5>("element-interleaved {m,v,p,t}, tile-major", blk, L, lds);
+        run<2, true>("tile-major 64 KB blocks, non-temporal loads + stores", blk, L, lds);
+        run<0, true>("row-major, non-temporal loads + stores", rm, L, lds);
     }
     // device copy of the same bytes
     {

@@ -60,9 +60,11 @@ def main():
             v = [x for (k, c), vals in rows if c == ctr and name in k for x in vals]
             return sum(v) / len(v)
         # launches of one grouped replay() at >= 48 learners: prep, fwd<false, 4>, fwd<false, 2>, fwd<true, 2>, d1<., 2> x2, gw2 x2
-        names = ("k_tp_prep", "k_tp_fwd<false, 4>", "k_tp_fwd<false, 2>", "k_tp_fwd<true, 2>", "k_tp_d1<11,", "k_tp_d1<9,", "k_tp_gw2<11>", "k_tp_gw2<9>")
+        # (name prefixes: round 6 added the layout flag as a last template argument, e.g. k_tp_gw2<11, true>)
+        names = ("k_tp_prep", "k_tp_fwd<false, 4", "k_tp_fwd<false, 2", "k_tp_fwd<true, 2", "k_tp_d1<11,", "k_tp_d1<9,", "k_tp_gw2<11", "k_tp_gw2<9")
+        tiled = any("k_tp_gw2<11, true>" in k for (k, c), vals in rows)
         fetch_kb, write_kb = sum(gmean(n, "FETCH_SIZE") for n in names), sum(gmean(n, "WRITE_SIZE") for n in names)
-        doc["group"] = {"round": tag.split("_")[0], "learners": group[0], "envs_per_gpu": group[1], "form": "throughput",
+        doc["group"] = {"round": tag.split("_")[0], "learners": group[0], "envs_per_gpu": group[1], "form": "throughput", "w2_layout": "tiled" if tiled else "flux",
                         "launches": "k_tp_prep + k_tp_fwd x3 + k_tp_d1 x2 + k_tp_gw2 x2", "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                         "bytes_as_read": (fetch_kb + write_kb) * 1024.0, "bytes_fetch_x2": (2.0 * fetch_kb + write_kb) * 1024.0,
                         "source": f"profiles/{tag}_pmc_counters_train.csv (two rocprofv3 --pmc passes of bench.py --mode group, tools/profile_group.sh)"}
