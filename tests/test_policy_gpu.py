@@ -251,6 +251,30 @@ for n, mixed in ((1, False), (2048 + 13, False), (6000 + 5, False), (20000, Fals
         ag.act_step(env, train=True, tick=t, ring=ring)
     torch.cuda.synchronize()
     out.append(zlib.crc32(env.state.tobytes()) ^ zlib.crc32(ring.s2.cpu().numpy().tobytes()) ^ zlib.crc32(ring.a.cpu().numpy().tobytes()))
+# the GROUPED call (shems_act_step_group_dev: env i acts with learner i / E's actor, every learner pushes into its own ring): 32-, 64- and
+# 128-env tiles, Flux order (the forced form applies) and the tiled working layout (always the free-running forms, W2 from the tiles)
+G = importlib.import_module(U.PKG_NAME + ".group")
+for L, E, tiled in ((5, 256, False), (20, 1024, False), (40, 1024, False), (16, 128, True), (20, 1024, True), (40, 1024, True)):
+    n = L * E
+    tab = S.tables.synthetic_table("train", 98)
+    env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
+    grp = G.LearnerGroup(L, E, seed=7, rng_seed=11, capacity=720, form="throughput" if tiled else "latency")
+    assert grp.tiled == tiled
+    env.reset_(3, episode=0)
+    st = env.state
+    for ag in grp.learners:
+        ag.set_norm(st.min(0), st.max(0))
+    for t in range(3):
+        grp.tick = t
+        grp.act_step(env, train=True, tick=t, window=(grp.rings[0].pos, *grp.ring_window(72, None)))
+    torch.cuda.synchronize()
+    env.check_error()
+    c = zlib.crc32(env.state.tobytes())
+    for r in grp.rings:
+        c ^= zlib.crc32(r.s2.cpu().numpy().tobytes()) ^ zlib.crc32(r.a.cpu().numpy().tobytes())
+    out.append(c)
+    env.close()
+assert out[-1] == out[-4] and out[-2] == out[-5]          # tiled == Flux order at the same shape
 print("FORMS", *out)
 """
 
