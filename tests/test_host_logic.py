@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import util as U
 
@@ -94,3 +95,32 @@ def test_all_cores_fused_step_agrees_with_the_oracle():
         s = s2
     rc, act, _, _ = a.policy_step_omp(actor, lo, hi, s, train=False)
     assert np.abs(act - DO.act(actor, s, lo, hi, False)).max() < 2e-6
+
+
+def test_group_ring_window_and_layout_bookkeeping_without_a_gpu():
+    """LearnerGroup's host-side decisions (no device call): how many transitions a learner remembers per vector step and from which
+    household -- window_count 1 is the reference's one transition per replay() (DDPG.jl:229-233), always household 0 -- and which copy
+    of the layer-2 state is current on the tiled working layout."""
+    import importlib
+    import types
+    G = importlib.import_module(U.PKG_NAME + ".group")
+    g = types.SimpleNamespace(envs_per_learner=128, capacity=24000, tick=0)
+    rw = lambda *a: G.LearnerGroup.ring_window(g, *a)
+    assert rw(72, None) == (128, 0)                     # min(E, 24 000 / 72 = 333)
+    g.tick = 5
+    assert rw(72, 1) == (1, 0) and rw(72, 32) == (32, (5 * 32) % 128)
+    g.envs_per_learner, g.capacity = 2048, 24000
+    assert rw(72, None) == (333, (5 * 333) % 2048)
+    for bad in (0, 2049):
+        with pytest.raises(ValueError):
+            rw(72, bad)
+    # validity flags: a write into Flux-order tensors while they are stale must be refused, not silently lose the tiles' state
+    s = types.SimpleNamespace(tiled=True, _flux_valid=False, _tiled_valid=True)
+    with pytest.raises(RuntimeError):
+        G.LearnerGroup.flux_changed(s)
+    s._flux_valid = True
+    G.LearnerGroup.flux_changed(s)
+    assert s._tiled_valid is False
+    assert G.W2T_FLOATS == 32 * 4 * 64 * 64
+    hdr = open(os.path.join(U.ROOT, "include", "shems_hip.h")).read()
+    assert "SHEMS_W2T_FLOATS = 32 * 4 * 64 * 64" in hdr
