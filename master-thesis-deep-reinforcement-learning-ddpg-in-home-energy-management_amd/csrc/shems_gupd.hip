@@ -581,6 +581,9 @@ __device__ __forceinline__ void head_actor(const NetArgs &A, const shems_ddpg &d
 // D layout is then the B operand of the layer-1 gradient gW1[j][k] = sum_m x[j][m] D1[k][m], which follows on the matrix pipe without
 // any LDS round trip (the bias gradient is the row of ones of the input block).  ADAM + soft update for the k-tile's layer-1 columns.
 // ================================================================================================================================
+#ifndef SHEMS_D1_PAD
+#define SHEMS_D1_PAD 0      // (diagnostic builds: extra dynamic LDS = fewer resident workgroups, to read the launch's sensitivity to occupancy)
+#endif
 constexpr int D1_S = 33;
 constexpr unsigned kNarrowBelow = 48;
 // KT = 32-wide sub-tiles per workgroup: 2 = a 64-wide k-tile (four workgroups per learner -- the form for wide groups, fewest reads of
@@ -1104,11 +1107,11 @@ static int group_update_tp(const char *fn, const shems_ddpg *d, const shems_repl
     hipLaunchKernelGGL((k_tp_fwd<false, 2, TL>), dim3(SN::TILES, L), dim3(256), SN::LDS, st, U.f2);
     const unsigned g8 = 8 * ((L + 7) / 8);
     if (narrow) hipLaunchKernelGGL((k_tp_d1<CIN, 1, TL>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.nc);
-    else hipLaunchKernelGGL((k_tp_d1<CIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.nc);
+    else hipLaunchKernelGGL((k_tp_d1<CIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2) + SHEMS_D1_PAD, st, U.nc);
     hipLaunchKernelGGL((k_tp_gw2<CIN, TL>), dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.nc);
     hipLaunchKernelGGL((k_tp_fwd<true, 2, TL>), dim3(SQ::TILES, L), dim3(256), SQ::LDS, st, U.f5);
     if (narrow) hipLaunchKernelGGL((k_tp_d1<SIN, 1, TL>), dim3(8 * g8), dim3(256), d1_lds(1), st, U.na);
-    else hipLaunchKernelGGL((k_tp_d1<SIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2), st, U.na);
+    else hipLaunchKernelGGL((k_tp_d1<SIN, 2, TL>), dim3(4 * g8), dim3(256), d1_lds(2) + SHEMS_D1_PAD, st, U.na);
     hipLaunchKernelGGL((k_tp_gw2<SIN, TL>), dim3(GW_WGS, L), dim3(256), GW_LDS, st, U.na);
     return hip_ok(hipGetLastError(), "grouped update (throughput form) launches");
 }
