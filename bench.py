@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--mode", default="auto", choices=["auto", "train", "policy", "env", "group"])
     ap.add_argument("--group-form", default=None, choices=["throughput", "latency"], help="group mode: the form of the grouped replay() (default: throughput from 16 learners up; csrc/shems_gupd.hip / csrc/shems_ddpg.hip)")
-    ap.add_argument("--learners", type=int, default=32, help="group mode: independent learners per GPU (the thesis protocol of many seeds x chargers, SURVEY 8(f) rank 4); --envs must be learners x a multiple of 128")
+    ap.add_argument("--learners", type=int, default=32, help="group mode: independent learners per GPU (the thesis protocol of many seeds x chargers, SURVEY 8(f) rank 4); --envs must be learners x a multiple of 32")
     ap.add_argument("--updates", type=int, default=1, help="DDPG updates per vector step (train mode)")
     ap.add_argument("--overlap", nargs="?", const="pipelined", default=None, choices=["pipelined", "exact"],
                     help="train mode: run replay() on a second stream under the act/step launch (DESIGN.md 5b; not the headline configuration).  "

@@ -246,6 +246,9 @@ int shems_scale_action_dev(const float *d_a, int64_t n, float *d_out, void *stre
 /* The kernel shems_act_step_dev (grouped = 0) / shems_act_step_group_dev (grouped != 0) dispatches for n_envs envs, by the name a
  * profiler shows (e.g. "shems::k_act2", "shems::k_actg<1, 8, 1, 3>"), NUL-terminated into out[cap]: bench.py's roofline.kernel. */
 int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap);
+/* The same for a learner group of envs_per_learner households per learner (a tile never straddles two learners; tiled != 0: the group's
+ * W2 is read from its tiled regions, shems_act_step_group_tiled_dev). */
+int shems_act_step_group_kernel(int64_t n_envs, int64_t envs_per_learner, int tiled, char *out, int32_t cap);
 /* Number of workgroups shems_act_step_dev launches for n envs (length of d_block_reward). */
 int shems_act_step_grid(int64_t n_envs, int64_t *out_blocks);
 
@@ -423,7 +426,7 @@ int shems_train_loop_release(shems_train_loop *loop);
  * result is bit-identical to the single-learner entry points run on that learner's buffers with seed + l.
  *   act/step:  env i is driven by learner i / envs_per_learner's actor and normalisation; the ring window applies
  *              inside each learner's env block (n = envs_per_learner) and pushes into that learner's ring.
- *              envs_per_learner must be a multiple of 128.
+ *              envs_per_learner must be a multiple of 32 (tiles of 128 / 64 envs are used where they divide it).
  *   update:    grid z = learner; minibatch l is sampled with Philox key seed + l; ADAM scalars are shared (the
  *              learners advance in lockstep). */
 typedef struct shems_group {

@@ -114,6 +114,7 @@ struct ActArgs {
     // learner groups on the tiled working layout (shems_group_w2t): learner 0's actor region; W2 is read from its p arrays instead of
     // from the Flux-order block (the free-running forms of k_act only).  null: Flux order.
     const float *w2t;
+    int tm_max;                // learner groups: largest env tile (in units of 32 envs) that divides envs_per_learner -- a tile never straddles two learners; 0 = no limit
 };
 
 template <class T>
@@ -1626,12 +1627,13 @@ static int launch_act2(const ActArgs &a, hipStream_t st)
 }
 
 // BM: as large as keeps >= 2 workgroups per CU's worth of tiles (256 CUs); smaller batches use smaller tiles.
-static int pick_tm(int64_t m)
+static int pick_tm(int64_t m, int tm_max = 0)
 {
-    if (m >= 256 * 128) return 4;
-    if (m >= 256 * 64) return 2;
-    return 1;
+    const int tm = m >= 256 * 128 ? 4 : m >= 256 * 64 ? 2 : 1;
+    return tm_max > 0 && tm > tm_max ? tm_max : tm;
 }
+// learner groups: envs_per_learner is a multiple of 32; tiles of 128 / 64 envs only where they divide it
+static int group_tm_max(int64_t envs_per_learner) { return envs_per_learner % 128 == 0 ? 4 : envs_per_learner % 64 == 0 ? 2 : 1; }
 
 template <int TM, int NW, int RD = 0>
 static int launch_act(const ActArgs &a, hipStream_t st)
@@ -1727,12 +1729,12 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
 #endif
     const int64_t cnt = a.m - a.m0;                           // envs of this launch (a range launch: every form writes the same bytes)
     if (a.w2t) {                                              // tiled learner group: the free-running forms read W2 from the tiled regions
-        const int tmt = pick_tm(cnt);
+        const int tmt = pick_tm(cnt, a.tm_max);
         return tmt == 4 ? launch_act<4, 4, 2>(a, st) : tmt == 2 ? launch_act<2, 4, 2>(a, st) : launch_act<1, 4, 2>(a, st);
     }
     if (form4 == 2 && form < 0 && cnt > 8192 && a.gcount <= 1) return launch_act2(a, st);
-    if (form4 == 2 && form == 12) return launch_act2(a, st);                      // A/B: the two-per-CU form at any size
-    const int tm = pick_tm(cnt);
+    if (form4 == 2 && form == 12 && (a.tm_max == 0 || a.tm_max >= 2)) return launch_act2(a, st);      // A/B: the two-per-CU form (64-env tiles) at any size
+    const int tm = pick_tm(cnt, a.tm_max);
     if (tm == 4) return form4 == 0 ? launch_act<4, 4>(a, st) : launch_act<4, 4, 2>(a, st);
     if (tm == 2) return form == 0 || form4 == 0 ? launch_act<2, 4>(a, st) : launch_act<2, 4, 2>(a, st);
     if (form == 0) return launch_act<1, 4>(a, st);
@@ -1809,6 +1811,23 @@ int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
         else if (form == 8 || (form != 9 && n_envs > 128 * 32)) name = "shems::k_actg<1, 8, 1, 3>";
         else name = "shems::k_actg<1, 4, 2, 3>";
     }
+    snprintf(out, (size_t)cap, "%s", name);
+    return SHEMS_OK;
+}
+
+/* The same for a learner group: the tile never straddles two learners, so envs_per_learner limits it. */
+int shems_act_step_group_kernel(int64_t n_envs, int64_t envs_per_learner, int tiled, char *out, int32_t cap)
+{
+    if (n_envs <= 0 || envs_per_learner < 32 || envs_per_learner % 32 != 0 || !out || cap < 2)
+        return set_error(SHEMS_ERR_ARG, "shems_act_step_group_kernel: bad arguments");
+    const int form = act_form(), form4 = act_form4(), tmax = group_tm_max(envs_per_learner);
+    const int tm = pick_tm(n_envs, tmax);
+    const char *name;
+    if (tiled) name = tm == 4 ? "shems::k_act<4, 4, 2>" : tm == 2 ? "shems::k_act<2, 4, 2>" : "shems::k_act<1, 4, 2>";
+    else if (form4 == 2 && form == 12 && tmax >= 2) name = "shems::k_act2";
+    else if (tm == 4) name = form4 == 0 ? "shems::k_act<4, 4, 0>" : "shems::k_act<4, 4, 2>";
+    else if (tm == 2) name = form == 0 || form4 == 0 ? "shems::k_act<2, 4, 0>" : "shems::k_act<2, 4, 2>";
+    else return shems_act_step_kernel(n_envs, 1, out, cap);          // 32-env tiles: the ungrouped decision tree below tm = 2
     snprintf(out, (size_t)cap, "%s", name);
     return SHEMS_OK;
 }
@@ -1924,8 +1943,8 @@ static int act_step_group(const char *fn, const shems_view *v, const shems_act_p
     if (int rc = check_view(v, fn)) return rc;
     if (!g || g->count < 1 || g->stride_bytes < 0 || (g->stride_bytes & 15) != 0 || (g->count > 1 && g->stride_bytes == 0))
         return set_error(SHEMS_ERR_ARG, "%s: shems_group needs count >= 1 and a 16-byte-multiple stride", fn);
-    if (g->envs_per_learner < 128 || g->envs_per_learner % 128 != 0 || g->envs_per_learner * g->count != v->n_envs)
-        return set_error(SHEMS_ERR_ARG, "%s: envs_per_learner must be a multiple of 128 and count * envs_per_learner == n_envs "
+    if (g->envs_per_learner < 32 || g->envs_per_learner % 32 != 0 || g->envs_per_learner * g->count != v->n_envs)
+        return set_error(SHEMS_ERR_ARG, "%s: envs_per_learner must be a multiple of 32 and count * envs_per_learner == n_envs "
                          "(got %lld x %d for %lld envs)", fn, (long long)g->envs_per_learner, g->count, (long long)v->n_envs);
     ActArgs a;
     std::memset(&a, 0, sizeof a);
@@ -1934,6 +1953,7 @@ static int act_step_group(const char *fn, const shems_view *v, const shems_act_p
     a.do_step = 1;
     a.gcount = g->count; a.gstride = g->count > 1 ? g->stride_bytes : 0; a.genvs = g->envs_per_learner;
     a.w2t = w2t;
+    a.tm_max = group_tm_max(g->envs_per_learner);
     if (ring0 && window && window->count > 0) {
         if (ring0->capacity <= 0 || !ring0->s || !ring0->a || !ring0->r || !ring0->s2 || !ring0->done)
             return set_error(SHEMS_ERR_ARG, "%s: incomplete replay ring", fn);

@@ -45,7 +45,8 @@ def _declare_group():
     L.shems_ddpg_group_update_tiled.argtypes = [PD, PR, PG, PT, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, C.c_int32, vp]
     L.shems_group_w2_to_tiled.argtypes = [PD, PG, PT, vp]
     L.shems_group_w2_to_flux.argtypes = [PD, PG, PT, vp]
-    for fn in ("shems_act_step_group_tiled_dev", "shems_ddpg_group_update_tiled", "shems_group_w2_to_tiled", "shems_group_w2_to_flux"):
+    L.shems_act_step_group_kernel.argtypes = [i64, i64, C.c_int, C.c_char_p, C.c_int32]
+    for fn in ("shems_act_step_group_tiled_dev", "shems_ddpg_group_update_tiled", "shems_group_w2_to_tiled", "shems_group_w2_to_flux", "shems_act_step_group_kernel"):
         getattr(L, fn).restype = C.c_int
     L.shems_ddpg_group_update.argtypes = [PD, PR, PG, i64, C.c_uint64, C.c_uint32, dbl, dbl, dbl, dbl, dbl, dbl, vp]
     L.shems_ddpg_group_update.restype = C.c_int
@@ -61,6 +62,14 @@ def _declare_group():
         getattr(L, fn).restype = C.c_int
     L._group_declared = True
     return L
+
+
+def group_act_kernel_name(n_envs, envs_per_learner, tiled):
+    """The kernel the fused-step dispatcher runs for a learner group, by its profiler name (shems_act_step_group_kernel)."""
+    L = _declare_group()
+    buf = C.create_string_buffer(96)
+    _capi.check(L.shems_act_step_group_kernel(int(n_envs), int(envs_per_learner), 1 if tiled else 0, buf, 96))
+    return buf.value.decode()
 
 
 def _pad4(n):
@@ -97,8 +106,8 @@ class LearnerGroup:
         if self.tiled and self.form != "throughput":
             raise ValueError("the tiled working layout belongs to the throughput form")
         self._flux_valid, self._tiled_valid = True, False          # which copy of the layer-2 state is current (both may be)
-        if self.count < 1 or self.envs_per_learner % 128 != 0:
-            raise ValueError("a learner group needs count >= 1 and envs_per_learner a multiple of 128")
+        if self.count < 1 or self.envs_per_learner < 32 or self.envs_per_learner % 32 != 0:
+            raise ValueError("a learner group needs count >= 1 and envs_per_learner a multiple of 32")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.seed = int(seed)
         self.rng_seed = self.seed if rng_seed is None else int(rng_seed)
@@ -296,8 +305,8 @@ class GroupWorkload:
         """window: transitions each learner remembers per vector step (None: min(E, MEM_SIZE / 72), the rotating window; 1: the reference's
         one transition per replay(), LearnerGroup.ring_window)."""
         self.S, self.torch, self.n, self.count = S, torch, int(n), int(learners)
-        if self.n % self.count or (self.n // self.count) % 128:
-            raise ValueError("--envs must be learners x a multiple of 128")
+        if self.n % self.count or (self.n // self.count) % 32:
+            raise ValueError("--envs must be learners x a multiple of 32")
         E = self.n // self.count
         if mixed:                       # the thesis grid: learner l trains on charger profile l mod 10 (ids 1-9, 98; LU1:47-58)
             ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
@@ -356,7 +365,7 @@ class GroupWorkload:
         torch.cuda.synchronize()
         self.update_us = e0.elapsed_time(e1) * 1e3 / nup
         flops = 2 * (9 * 250 + 250 * 500 + 500 * 2) * self.n
-        act = dict(kernel=act_kernel_name(self.n, grouped=2 if g.tiled else True), avg_us=avg_us, median_us=med_us, launches=reps,
+        act = dict(kernel=group_act_kernel_name(self.n, g.envs_per_learner, g.tiled), avg_us=avg_us, median_us=med_us, launches=reps,
                    bound="mfma", algorithmic=flops, unit="TFLOP/s", peak=157.3)
         if self.update_us <= avg_us:
             return act

@@ -80,6 +80,10 @@ def test_bench_group_window_one():
     d = _run([sys.executable, "bench.py", "--mode", "group", "--learners", "16", "--envs", "2048", "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
               "--prewarm-s", "0.1", "--group-window", "1"])
     assert d["replay_window_envs_per_step"] == 1 and d["learners"] == 16 and d["updates_per_sec"] > 1600
+    # ... on 32 households per learner (the smallest env block: the reference's learner owns ONE household, the other 31 only act)
+    d = _run([sys.executable, "bench.py", "--mode", "group", "--learners", "16", "--envs", "512", "--steps", "12", "--warmup", "2", "--no-cpu-baseline",
+              "--prewarm-s", "0.1", "--group-window", "1"])
+    assert d["replay_window_envs_per_step"] == 1 and d["envs_per_learner"] == 32 and d["updates_per_sec"] > 1600
 
 
 def test_bench_kernel_name_follows_the_dispatcher():

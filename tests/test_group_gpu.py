@@ -55,7 +55,9 @@ def test_learners_are_independent_and_populated():
 # 8 learners: the grouped update switches to its wider forward tile; (40, 128, mixed): the thesis protocol's shape -- 40 seeds, each on one
 # of the 10 charger profiles (RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87 runs 40 seeds x 10 chargers = 400 learners; bench.py
 # --mode group --learners 400 --envs 51200 --mixed is that width, profiles/r04_group400_bench.json)
-@pytest.mark.parametrize("L,E,mixed", [(3, 256, False), (8, 128, False), (40, 128, True)])
+# (12, 32) / (6, 96): env blocks that are multiples of 32 but not of 128 / 64 (round 6: the thesis-exact protocol needs ONE household per learner;
+# 32 is the smallest tile) -- the dispatcher must pick tiles that never straddle two learners
+@pytest.mark.parametrize("L,E,mixed", [(3, 256, False), (8, 128, False), (40, 128, True), (12, 32, False), (6, 96, False)])
 def test_group_step_and_update_match_single_learner_calls_bitwise(L, E, mixed):
     torch, S, D, G, env, grp = _setup(L=L, E=E, mixed=mixed)
     L, E, n = grp.count, grp.envs_per_learner, grp.n_envs
@@ -66,7 +68,7 @@ def test_group_step_and_update_match_single_learner_calls_bitwise(L, E, mixed):
     a_g = torch.empty((n, 2), dtype=torch.float32, device="cuda")
     ret_g = torch.zeros(n, dtype=torch.float64, device="cuda")
     for rep in range(2):                                                   # two rounds: the second uses advanced beta powers
-        grp.act_step(env, train=False, tick=3 + rep, a_out=a_g, returns_acc=ret_g, window=(grp.rings[0].pos, 40, 7 + rep))
+        grp.act_step(env, train=False, tick=3 + rep, a_out=a_g, returns_acc=ret_g, window=(grp.rings[0].pos, min(40, E), 7 + rep))
         grp.replay()
     torch.cuda.synchronize()
     slab_g, state_g, a_gh, ret_gh = grp.slab.clone(), env.state, a_g.cpu().numpy(), ret_g.cpu().numpy()
@@ -82,8 +84,8 @@ def test_group_step_and_update_match_single_learner_calls_bitwise(L, E, mixed):
         sub = env.slice(l * E, E)
         for rep in range(2):
             ag.act_step(sub, train=False, tick=3 + rep, a_out=a_s[l * E:(l + 1) * E], returns_acc=ret_s[l * E:(l + 1) * E], ring=ring,
-                        window=D.RingWindow(ring.pos, 40, 7 + rep))
-            ring.pushed += 40
+                        window=D.RingWindow(ring.pos, min(40, E), 7 + rep))
+            ring.pushed += min(40, E)
             ag.replay(ring, tick=rep)
     torch.cuda.synchronize()
     assert np.array_equal(a_s.cpu().numpy(), a_gh) and np.array_equal(ret_s.cpu().numpy(), ret_gh)

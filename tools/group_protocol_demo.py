@@ -3,7 +3,9 @@
 grouped launches -- fused act/step for all 51 200 households + the throughput form of the grouped replay() (csrc/shems_gupd.hip) -- for
 argv[2] episodes of 72 hours, then every learner's deterministic evaluation score on its own charger's eval table (100 starts, 72
 hours), next to the rule-based controller on the same starts.  argv[3] = "latency" runs the same protocol on the five-launch form
-(fewer episodes advised).  Writes one JSON document to argv[1]."""
+(fewer episodes advised).  argv[5] = households per learner (default 128; any multiple of 32: with argv[4] = 1 only household 0 feeds the learner, so 32 -- the smallest tile of
+the fused kernel -- is the closest this framework comes to the reference's ONE household per learner).
+Writes one JSON document to argv[1]."""
 import importlib
 import json
 import os
@@ -23,7 +25,8 @@ out_path = sys.argv[1] if len(sys.argv) > 1 else "group_protocol.json"
 episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 form = sys.argv[3] if len(sys.argv) > 3 else "throughput"
 window = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] not in ("", "default") else None
-SEEDS, E = 40, 128
+SEEDS = 40
+E = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 ids = (1, 2, 3, 4, 5, 6, 7, 8, 9, 98)
 L = SEEDS * len(ids)
 tabs = [S.tables.synthetic_table("train", c) for c in ids]
@@ -60,7 +63,7 @@ for k, cid in enumerate(ids):
     per_charger[str(cid)] = {"rule_based": rule[cid], "learners": SEEDS, "score_mean": float(sc.mean()), "score_best": float(sc.max()),
                              "score_worst": float(sc.min()), "beat_rule_based": int((sc > rule[cid]).sum())}
 wc = grp.ring_window(72, window)[0]
-doc = {"protocol": "40 seeds x 10 chargers = 400 learners x 128 households, grouped launches", "form": grp.form, "episodes": episodes,
+doc = {"protocol": f"40 seeds x 10 chargers = 400 learners x {E} households, grouped launches", "households_per_learner": E, "form": grp.form, "episodes": episodes,
        "remembered_transitions_per_learner_update": wc,
        "update_to_data": ("1 update per remembered transition: the reference's ratio (DDPG.jl:229-233)" if wc == 1 else
                           f"1 update per {wc} remembered transitions ({wc} x the reference's data per update)"),
