@@ -75,7 +75,7 @@ def parse():
 
 
 # The other workloads this repo quotes numbers for, timed by the default run so that every claimed figure stands under the driver's clock
-# (VERDICT round 5, item 1): BASELINE configs[1] (4 096 envs), the configs[3] shard (8 192 envs per GPU), configs[4] on one GPU (65 536
+# (a sixth record added for the thesis-exact ratio): BASELINE configs[1] (4 096 envs), the configs[3] shard (8 192 envs per GPU), configs[4] on one GPU (65 536
 # envs x 10 charger profiles x discomfort-weight sweep), and the learner groups of SURVEY 8(f) rank 4 at the thesis protocol's width
 # (40 seeds x 10 chargers, RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87) and at 32 learners x 2 048 households.
 ALSO = [
@@ -84,6 +84,9 @@ ALSO = [
     ("config5_mixed_65536_envs", dict(kind="train", envs=65536, mixed=True, steps=360, warmup=72)),
     ("group_400x128", dict(kind="group", learners=400, envs=51200, mixed=True, steps=72, warmup=8)),
     ("group_32x2048", dict(kind="group", learners=32, envs=65536, mixed=True, steps=144, warmup=16)),
+    # the thesis protocol at the reference's update-to-data ratio: ONE remembered transition per learner-update (DDPG.jl:229-233) -- household 0 of a
+    # 32-household block (the smallest tile of the fused kernel; the reference's learner owns one household)
+    ("group_400x32_one_transition_per_update", dict(kind="group", learners=400, envs=12800, mixed=True, window=1, steps=72, warmup=8)),
 ]
 
 

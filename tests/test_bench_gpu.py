@@ -52,7 +52,7 @@ def test_bench_json_contract_small():
 
 
 def test_bench_also_records():
-    """The default run's "also" object (here switched on for a small headline and two of its five entries): compact sub-records of the other
+    """The default run's "also" object (here switched on for a small headline and two of its six entries): compact sub-records of the other
     configurations and of the learner groups, each with value, ms_per_step, steps, updates_per_sec and roofline{kernel, kernel_avg_us, frac}."""
     d = _run([sys.executable, "bench.py", "--steps", "16", "--warmup", "4", "--envs", "8192", "--no-cpu-baseline", "--prewarm-s", "0.2",
               "--also", "on", "--also-which", "config2_4096_envs,group_32x2048"])

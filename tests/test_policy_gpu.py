@@ -254,7 +254,7 @@ for n, mixed in ((1, False), (2048 + 13, False), (6000 + 5, False), (20000, Fals
 # the GROUPED call (shems_act_step_group_dev: env i acts with learner i / E's actor, every learner pushes into its own ring): 32-, 64- and
 # 128-env tiles, Flux order (the forced form applies) and the tiled working layout (always the free-running forms, W2 from the tiles)
 G = importlib.import_module(U.PKG_NAME + ".group")
-pairs = {}
+pairs = dict()
 for L, E, tiled in ((5, 256, False), (20, 1024, False), (40, 1024, False), (16, 128, True), (20, 1024, True), (40, 1024, True), (48, 32, False), (48, 32, True),
                     (300, 96, False), (300, 96, True)):          # env blocks of 32 / 96: tiles that never straddle two learners
     n = L * E
