@@ -1745,7 +1745,9 @@ static int dispatch_act(const ActArgs &a, hipStream_t st)
     // waves wait at the barrier for the late ones): 23.1 against 23.8 us at 8 192 envs.  At <= 4 096 envs (one workgroup per CU) the
     // shallower ring costs more than it wins (17.7 against 16.2 us): ring of three there.  Per-tile reward sums need ONE workgroup per tile.
     if ((form == 10 || (form < 0 && cnt > 128 * 32)) && !want_sum && (cnt + 31) / 32 <= kSplitMaxTiles) return launch_actg<1, 4, 2, 2>(a, st);
-    if (form == 8 || (form != 9 && (cnt > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
+    // (a learner group whose env block admits only 32-env tiles can be large: beyond the split forms' exchange scratch the one-workgroup-per-tile form runs)
+    const bool split_fits = (cnt + 31) / 32 <= kSplitMaxTiles;
+    if (form == 8 || !split_fits || (form != 9 && (cnt > 128 * 32 || want_sum))) return launch_actg<1, 8, 1, 3>(a, st);
     return launch_actg<1, 4, 2, 3>(a, st);
 }
 
@@ -1808,7 +1810,7 @@ int shems_act_step_kernel(int64_t n_envs, int grouped, char *out, int32_t cap)
         else if (form == 2) name = "shems::k_act<1, 4, 2>";
         else if (form == 3) name = "shems::k_act<1, 4, 3>";
         else if ((form == 10 || (form < 0 && n_envs > 128 * 32)) && (n_envs + 31) / 32 <= kSplitMaxTiles) name = "shems::k_actg<1, 4, 2, 2>";
-        else if (form == 8 || (form != 9 && n_envs > 128 * 32)) name = "shems::k_actg<1, 8, 1, 3>";
+        else if (form == 8 || (n_envs + 31) / 32 > kSplitMaxTiles || (form != 9 && n_envs > 128 * 32)) name = "shems::k_actg<1, 8, 1, 3>";
         else name = "shems::k_actg<1, 4, 2, 3>";
     }
     snprintf(out, (size_t)cap, "%s", name);
