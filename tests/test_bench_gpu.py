@@ -86,6 +86,18 @@ def test_bench_group_window_one():
     assert d["replay_window_envs_per_step"] == 1 and d["envs_per_learner"] == 32 and d["updates_per_sec"] > 1600
 
 
+def test_group_mode_shards_as_plain_replicas_over_ranks():
+    """Learner groups shard over GPUs as plain replicas: every rank advances its own learners on its own env shard, no collective on the
+    data path; `value` / `updates_per_sec` are whole-job aggregates.  Rehearsal form: two rank processes on device 0, gloo for the
+    barriers and the MAX over ranks."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--mode", "group", "--learners", "16", "--envs", "2048", "--steps", "12", "--warmup", "2",
+              "--prewarm-s", "0.1", "--no-cpu-baseline"], env={"SHEMS_BENCH_ONE_DEVICE": "1", "SHEMS_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["mode"] == "group" and d["learners"] == 16 and d["rccl_ranks"] == 2
+    assert abs(d["value"] - 2 * 2048 * 12 / (d["ms_per_step"] * 1e-3 * 12)) < 1e-3 * d["value"]
+    assert abs(d["updates_per_sec"] - 2 * 16 * 1e3 / d["ms_per_step"]) < 1e-3 * d["updates_per_sec"]
+    assert len({c["pid"] for c in d["rank_census"]}) == 2
+
+
 def test_bench_kernel_name_follows_the_dispatcher():
     import importlib
     D = importlib.import_module(U.PKG_NAME + ".ddpg")
