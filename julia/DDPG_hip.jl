@@ -18,7 +18,7 @@ using Random
 using Statistics: mean
 
 export EnvBatch, Agent, ReplayRing, act, act_step!, replay, populate_memory, min_max_buffer, episode!, run_episodes, inference, train_steps!,
-       flat_params, set_params!, actor_params, STATE_SIZE, ACTION_SIZE
+       flat_params, set_params!, actor_params, STATE_SIZE, ACTION_SIZE, LearnerGroup, flux!, learner_params
 
 const LIB = get(ENV, "SHEMS_HIP_LIB", joinpath(@__DIR__, "..", "master-thesis-deep-reinforcement-learning-ddpg-in-home-energy-management_amd", "libshems_hip.so"))
 const HIP = "libamdhip64"
@@ -156,6 +156,17 @@ struct ShemsTrainLoop                  # shems_train_loop: the hour loop of epis
     bp_act::NTuple{2, Float64}
     sync::Ptr{Cvoid}
     dp::Ptr{Cvoid}
+end
+
+struct ShemsGroup                      # shems_group: `count` independent learners, learner l's buffers at learner 0's pointers + l * stride_bytes
+    count::Int32
+    reserved::Int32
+    stride_bytes::Int64
+    envs_per_learner::Int64
+end
+struct ShemsGroupW2T                   # shems_group_w2t: the tiled working layout of the two networks' layer-2 state (learner 0's regions)
+    actor::Ptr{Float32}
+    critic::Ptr{Float32}
 end
 
 # ---- N households on one table (the batched Shems; shems_LU1.jl:169-262) -------------------------------------------------------------
@@ -386,6 +397,160 @@ function inference(env::EnvBatch, nsteps::Integer; track::Real=1, actors::Union{
     end
     check_error(env)
     return download(ret), reshape(download(res), 23, nsteps, env.n)
+end
+
+# ---- learner groups: the scheduler's 40 seeds x 10 chargers in ONE process (RL-SHEMS_bs_scheduler_1179_08_on_01-98.sh:67-87) ------------------
+const W2T_FLOATS = 32 * 4 * 64 * 64                              # SHEMS_W2T_FLOATS
+pad4(n) = (n + 3) & ~3
+
+"""LearnerGroup(actor_params, critic_params, envs_per_learner): `count = length(actor_params)` independent learners (one flat parameter vector
+each: the scheduler's seeds / chargers), every learner's networks, targets, ADAM moments, tiled layer-2 regions, workspace, normalisation and
+replay ring carved identically out of ONE slab; learner l owns the households [l * E, (l + 1) * E) of the env batch (E a multiple of 32).
+replay / act_step! advance all of them with the same launches (shems_ddpg_group_update_tiled: eight launches for the whole group).
+While the group trains, the layer-2 state lives in the tiled regions; flux!(g) brings the Flux-order blocks (what learner_params reads) up to date."""
+mutable struct LearnerGroup
+    count::Int; envs_per_learner::Int; capacity::Int
+    slab::DevBuf{Float32}; slab_floats::Int; off::Dict{Symbol, Int}
+    gamma::Float32; tau::Float32; eta_act::Float64; eta_crit::Float64; batch::Int; sigma::Float32; seed::UInt64
+    bp_actor::Vector{Float64}; bp_critic::Vector{Float64}
+    updates::Int; tick::Int; pushed::Int
+    flux_valid::Bool; tiled_valid::Bool
+end
+function LearnerGroup(actors::Vector{Vector{Float32}}, critics::Vector{Vector{Float32}}, envs_per_learner::Integer; capacity::Integer=MEM_SIZE,
+                      gamma=0.99f0, tau=1f-3, eta_act=1f-4, eta_crit=1f-3, batch::Integer=BATCH_SIZE, sigma=0.1f0, seed::Integer=1231)
+    count = length(actors)
+    count == length(critics) && count >= 1 && envs_per_learner % 32 == 0 || throw(ArgumentError("one actor and one critic per learner, env blocks of a multiple of 32"))
+    nws = Ref{Int64}(0)
+    check(ccall((:shems_ddpg_workspace_floats, LIB), Cint, (Ptr{Int64},), nws))
+    off, o = Dict{Symbol, Int}(), 0
+    for (name, n) in ((:actor, N_ACTOR), (:critic, N_CRITIC), (:actor_t, N_ACTOR), (:critic_t, N_CRITIC), (:m_actor, N_ACTOR), (:v_actor, N_ACTOR),
+                      (:m_critic, N_CRITIC), (:v_critic, N_CRITIC), (:w2t_actor, W2T_FLOATS), (:w2t_critic, W2T_FLOATS), (:grad_actor, N_ACTOR),
+                      (:grad_critic, N_CRITIC), (:s_min, STATE_SIZE), (:s_max, STATE_SIZE), (:losses, 2), (:ws, nws[]), (:ring_s, capacity * STATE_SIZE),
+                      (:ring_a, capacity * ACTION_SIZE), (:ring_r, capacity), (:ring_s2, capacity * STATE_SIZE), (:ring_done, cld(capacity, 4)))
+        off[name] = o
+        o = pad4(o + n)
+    end
+    host = zeros(Float32, o, count)                              # column l = learner l's slab
+    for l in 1:count
+        length(actors[l]) == N_ACTOR && length(critics[l]) == N_CRITIC || throw(DimensionMismatch("expected $N_ACTOR / $N_CRITIC parameters per learner"))
+        host[off[:actor] + 1:off[:actor] + N_ACTOR, l] = actors[l];   host[off[:actor_t] + 1:off[:actor_t] + N_ACTOR, l] = actors[l]      # deepcopy(actor), DDPG.jl:38
+        host[off[:critic] + 1:off[:critic] + N_CRITIC, l] = critics[l]; host[off[:critic_t] + 1:off[:critic_t] + N_CRITIC, l] = critics[l]
+        host[off[:s_max] + 1:off[:s_max] + STATE_SIZE, l] .= 1f0
+    end
+    return LearnerGroup(count, envs_per_learner, capacity, DevBuf(vec(host)), o, off, Float32(gamma), Float32(tau), Float64(Float32(eta_act)),
+                        Float64(Float32(eta_crit)), batch, Float32(sigma), UInt64(seed), [0.9, 0.999], [0.9, 0.999], 0, 0, 0, true, false)
+end
+at(g::LearnerGroup, name::Symbol) = g.slab.ptr + 4 * g.off[name]                       # learner 0's block (Ptr{Float32} arithmetic is in bytes)
+group_struct(g::LearnerGroup) = ShemsGroup(Int32(g.count), Int32(0), 4 * g.slab_floats, g.envs_per_learner)
+w2t_struct(g::LearnerGroup) = ShemsGroupW2T(at(g, :w2t_actor), at(g, :w2t_critic))
+ddpg_struct(g::LearnerGroup) = ShemsDdpg(at(g, :actor), at(g, :critic), at(g, :actor_t), at(g, :critic_t), at(g, :m_actor), at(g, :v_actor), at(g, :m_critic),
+                                         at(g, :v_critic), at(g, :grad_actor), at(g, :grad_critic), at(g, :s_min), at(g, :s_max), at(g, :ws), at(g, :losses),
+                                         g.gamma, g.tau, Int32(g.batch), Int32(0))
+ring_struct(g::LearnerGroup) = ShemsReplay(g.capacity, at(g, :ring_s), at(g, :ring_a), at(g, :ring_r), at(g, :ring_s2), Ptr{UInt8}(at(g, :ring_done)))
+function use_tiled!(g::LearnerGroup)
+    g.tiled_valid && return nothing
+    check(ccall((:shems_group_w2_to_tiled, LIB), Cint, (Ptr{ShemsDdpg}, Ptr{ShemsGroup}, Ptr{ShemsGroupW2T}, Ptr{Cvoid}),
+                Ref(ddpg_struct(g)), Ref(group_struct(g)), Ref(w2t_struct(g)), C_NULL))
+    g.tiled_valid = true
+    return nothing
+end
+"flux!(g): bring the W2 ranges of the Flux-order blocks up to date (before learner_params, a checkpoint, or a single-learner call on a learner's buffers)"
+function flux!(g::LearnerGroup)
+    g.flux_valid && return g
+    check(ccall((:shems_group_w2_to_flux, LIB), Cint, (Ptr{ShemsDdpg}, Ptr{ShemsGroup}, Ptr{ShemsGroupW2T}, Ptr{Cvoid}),
+                Ref(ddpg_struct(g)), Ref(group_struct(g)), Ref(w2t_struct(g)), C_NULL))
+    g.flux_valid = true
+    return g
+end
+"learner_params(g, l): learner l's actor as the flat Flux-order vector (what saveBSON turns back into a Chain, memory_plotting_saving.jl:263-268)"
+function learner_params(g::LearnerGroup, l::Integer)
+    flux!(g)
+    host = Vector{Float32}(undef, N_ACTOR)
+    hipcheck(ccall((:hipMemcpy, HIP), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), host, at(g, :actor) + 4 * g.slab_floats * (l - 1), N_ACTOR * sizeof(Float32), 2))
+    return host
+end
+
+"""populate_memory (memory_plotting_saving.jl:9-29) per learner on its own env block: uniform random actions until every ring is full (learner l: key rng + l).
+The households of learner l are a sub-view of the batch (the same arrays, offset pointers), its ring the slab's ring blocks + l * stride."""
+function populate_memory(g::LearnerGroup, env::EnvBatch; rng::Integer=g.seed)
+    E, v, stride = g.envs_per_learner, env.view, 4 * g.slab_floats
+    n_ep = cld(g.capacity, env.maxsteps)
+    k = min(E, n_ep)
+    pushed = 0
+    while pushed < g.capacity
+        reset_batch!(env; rng=rng, episode=0x7FFF0000 + pushed ÷ env.maxsteps)
+        for l in 0:(g.count - 1)
+            sub = ShemsView(E, v.maxsteps, v.n_cfg, v.obs + 4 * STATE_SIZE * E * l, v.idx + 4 * E * l, v.step + 4 * E * l,
+                            v.cfg_of_env == C_NULL ? v.cfg_of_env : v.cfg_of_env + 2 * E * l, v.cfgs, v.tables, v.total_rows, v.err)
+            r0 = ring_struct(g)
+            ring = ShemsReplay(r0.capacity, r0.s + stride * l, r0.a + stride * l, r0.r + stride * l, r0.s2 + stride * l, r0.done + stride * l)
+            check(ccall((:shems_rollout_dev, LIB), Cint,
+                        (Ptr{ShemsView}, Cint, Int32, UInt64, Ptr{Float64}, Ptr{ShemsReplay}, Int64, Int64, Ptr{Cvoid}),
+                        Ref(sub), 1, env.maxsteps, rng + l + pushed, C_NULL, Ref(ring), pushed % g.capacity, k, C_NULL))
+        end
+        pushed += k * env.maxsteps
+    end
+    g.pushed = pushed
+    return g
+end
+
+"""min_max_buffer (memory_plotting_saving.jl:50-53) for every learner of the group in one launch (learner l: key seed + l)."""
+function min_max_buffer(g::LearnerGroup; rng_mm::Integer=g.seed)
+    n = min(g.pushed, g.capacity)
+    check(ccall((:shems_minmax_group_dev, LIB), Cint, (Ptr{ShemsReplay}, Ptr{ShemsGroup}, Int64, Int64, UInt64, Ptr{Float32}, Ptr{Float32}, Ptr{Cvoid}),
+                Ref(ring_struct(g)), Ref(group_struct(g)), n, n, rng_mm, at(g, :s_min), at(g, :s_max), C_NULL))
+    return nothing
+end
+
+"""One fused vector step for all learners (DDPG.jl:195-234): household i acts with learner i ÷ E's actor; with `window` > 0 every learner remembers
+`window` transitions of its own block (window = 1: household 0 -- the reference's ONE transition per replay(), DDPG.jl:229-233)."""
+function act_step!(g::LearnerGroup, env::EnvBatch; train::Bool=true, tick::Integer=g.tick, returns::Union{Nothing, DevBuf{Float64}}=nothing, window::Integer=0)
+    env.n == g.count * g.envs_per_learner || throw(DimensionMismatch("the env batch must hold count * envs_per_learner households"))
+    use_tiled!(g)
+    p = Ref(ShemsActParams(at(g, :actor), at(g, :s_min), at(g, :s_max), 0f0, g.sigma, Int32(train), UInt32(tick % 0x100000000), g.seed, Int32(0),
+                           0f0, 0f0, 0f0, Ptr{Float32}(C_NULL), Ptr{Float32}(C_NULL)))
+    ret = returns === nothing ? Ptr{Float64}(C_NULL) : returns.ptr
+    if window > 0
+        w = Ref(ShemsRingWindow(g.pushed % g.capacity, window, window == 1 ? 0 : (g.tick * window) % g.envs_per_learner))
+        check(ccall((:shems_act_step_group_tiled_dev, LIB), Cint,
+                    (Ptr{ShemsView}, Ptr{ShemsActParams}, Ptr{ShemsGroup}, Ptr{ShemsGroupW2T}, Ptr{Float32}, Ptr{Float64}, Ptr{ShemsReplay}, Ptr{ShemsRingWindow}, Ptr{Cvoid}),
+                    Ref(env.view), p, Ref(group_struct(g)), Ref(w2t_struct(g)), C_NULL, ret, Ref(ring_struct(g)), w, C_NULL))
+        g.pushed += window
+    else
+        check(ccall((:shems_act_step_group_tiled_dev, LIB), Cint,
+                    (Ptr{ShemsView}, Ptr{ShemsActParams}, Ptr{ShemsGroup}, Ptr{ShemsGroupW2T}, Ptr{Float32}, Ptr{Float64}, Ptr{ShemsReplay}, Ptr{ShemsRingWindow}, Ptr{Cvoid}),
+                    Ref(env.view), p, Ref(group_struct(g)), Ref(w2t_struct(g)), C_NULL, ret, C_NULL, C_NULL, C_NULL))
+    end
+    return nothing
+end
+
+"replay (DDPG.jl:121-145) for every learner of the group: eight launches in all (the throughput form on the tiled layout); minibatch l = key seed + l"
+function replay(g::LearnerGroup; rng_rpl::Integer=g.updates)
+    use_tiled!(g)
+    check(ccall((:shems_ddpg_group_update_tiled, LIB), Cint,
+                (Ptr{ShemsDdpg}, Ptr{ShemsReplay}, Ptr{ShemsGroup}, Ptr{ShemsGroupW2T}, Int64, UInt64, UInt32, Float64, Float64, Float64, Float64, Float64, Float64, Int32, Ptr{Cvoid}),
+                Ref(ddpg_struct(g)), Ref(ring_struct(g)), Ref(group_struct(g)), Ref(w2t_struct(g)), min(g.pushed, g.capacity), g.seed, UInt32(rng_rpl % 0x100000000),
+                g.eta_crit, g.bp_critic[1], g.bp_critic[2], g.eta_act, g.bp_actor[1], g.bp_actor[2], Int32(0), C_NULL))
+    g.flux_valid = false
+    g.bp_critic .*= [0.9, 0.999]
+    g.bp_actor .*= [0.9, 0.999]
+    g.updates += 1
+    return nothing
+end
+
+"""episode! (DDPG.jl:186-242) for all learners at once; window = 1 is the reference's update-to-data ratio.  Returns the per-household returns."""
+function episode!(g::LearnerGroup, env::EnvBatch; train::Bool=true, num_steps::Integer=EP_LENGTH, rng_ep::Integer=0, episode::Integer=0, window::Integer=1)
+    reset_batch!(env; rng=rng_ep, episode=episode)
+    returns = DevBuf{Float64}(env.n)
+    for step in 0:(num_steps - 1)
+        act_step!(g, env; train=train, tick=(episode * 4096 + step) % 0x100000000, returns=returns, window=train ? window : 0)
+        if train
+            replay(g)
+            g.tick += 1
+        end
+    end
+    check_error(env)
+    return download(returns)
 end
 
 end # module

@@ -116,7 +116,8 @@ def test_synthetic_table_properties_and_csv_roundtrip(tmp_path):
 _C_SCALARS = {"int": "Cint", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "uint32_t": "UInt32", "uint16_t": "UInt16",
               "uint8_t": "UInt8", "float": "Float32", "double": "Float64", "shems_config": "ShemsConfig", "void": "Cvoid",
               "shems_env": "Cvoid", "shems_view": "ShemsView", "shems_act_params": "ShemsActParams", "shems_replay": "ShemsReplay",
-              "shems_ring_window": "ShemsRingWindow", "shems_ddpg": "ShemsDdpg", "shems_train_loop": "ShemsTrainLoop", "shems_dp": "Cvoid"}
+              "shems_ring_window": "ShemsRingWindow", "shems_ddpg": "ShemsDdpg", "shems_train_loop": "ShemsTrainLoop", "shems_dp": "Cvoid",
+              "shems_group": "ShemsGroup", "shems_group_w2t": "ShemsGroupW2T"}
 
 
 def _julia_types_for(c_arg):
@@ -218,7 +219,10 @@ def test_julia_learner_module_matches_the_header(built_lib):
     calls = re.findall(r"ccall\(\(:(\w+), LIB\), (\w+),\s*\(([^)]*)\)", src)
     assert len(calls) >= 16 and {c[0] for c in calls} >= {"shems_act_step_dev", "shems_ddpg_update", "shems_rollout_dev", "shems_minmax_dev",
                                                            "shems_track_dev", "shems_get_view", "shems_reset_seeded_dev", "shems_train_steps",
-                                                           "shems_train_loop_release"}
+                                                           "shems_train_loop_release",
+                                                           # round 6: learner groups on the tiled working layout
+                                                           "shems_act_step_group_tiled_dev", "shems_ddpg_group_update_tiled", "shems_group_w2_to_tiled",
+                                                           "shems_group_w2_to_flux", "shems_minmax_group_dev"}
     for name, ret, args in calls:
         assert hasattr(L, name), name
         m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
@@ -232,7 +236,7 @@ def test_julia_learner_module_matches_the_header(built_lib):
         assert ret == {"int": "Cint", "const char *": "Cstring"}[c_ret], (name, c_ret, ret)
     for cname, jname in (("shems_config", "ShemsConfig"), ("shems_view", "ShemsView"), ("shems_replay", "ShemsReplay"),
                          ("shems_act_params", "ShemsActParams"), ("shems_ring_window", "ShemsRingWindow"), ("shems_ddpg", "ShemsDdpg"),
-                         ("shems_train_loop", "ShemsTrainLoop")):
+                         ("shems_train_loop", "ShemsTrainLoop"), ("shems_group", "ShemsGroup"), ("shems_group_w2t", "ShemsGroupW2T")):
         assert _julia_struct_fields(src, jname) == _c_struct_fields(hdr, cname), (cname, _julia_struct_fields(src, jname), _c_struct_fields(hdr, cname))
     # the ctypes mirrors the tests drive have the same sizes as those field lists imply (8-byte pointers, natural alignment)
     D = importlib.import_module(U.PKG_NAME + ".ddpg")
@@ -249,5 +253,7 @@ def test_julia_learner_module_matches_the_header(built_lib):
     for needed in ("module DDPG_hip", "function act(ag::Agent", "function act_step!(ag::Agent", "function replay(ag::Agent", "function populate_memory(ag::Agent",
                    "function min_max_buffer(ag::Agent", "function episode!(ag::Agent", "function run_episodes(ag::Agent", "function inference(env::EnvBatch",
                    "function train_steps!(ag::Agent",
-                   "flat_params(params)"):
+                   "flat_params(params)", "mutable struct LearnerGroup", "function act_step!(g::LearnerGroup", "function replay(g::LearnerGroup",
+                   "function episode!(g::LearnerGroup", "function flux!(g::LearnerGroup", "function min_max_buffer(g::LearnerGroup",
+                   "function populate_memory(g::LearnerGroup"):
         assert needed in src, needed
