@@ -970,6 +970,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NTL == 4 ? 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     fwd_body<QG, NTL, TL>(A, blockIdx.x, blockIdx.y, smem);
 }
+// (Round 6 also built the forward launches as PERSISTENT workgroups -- 768 / 1 024 of them drawing their (n-tile, learner) items from a counter, which
+// tools/micro/fwd_anatomy.hip rates 0.86 against 0.82 of the peak for loops without prologues -- verified against the float64 oracle, measured slower
+// with the real prologues and epilogues (P1 373.5 against 355.3 us, P2 143.0 / 133.6, P5 278.9 / 273.8; 204.4 against 207.6 k updates/s), removed:
+// profiles/r06_fwd_persistent_ab.txt.)
 template <int IN, int KT, bool TL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_tp_d1(NetArgs A)
 {
