@@ -256,7 +256,7 @@ for n, mixed in ((1, False), (2048 + 13, False), (6000 + 5, False), (20000, Fals
 G = importlib.import_module(U.PKG_NAME + ".group")
 pairs = dict()
 for L, E, tiled in ((5, 256, False), (20, 1024, False), (40, 1024, False), (16, 128, True), (20, 1024, True), (40, 1024, True), (48, 32, False), (48, 32, True),
-                    (300, 96, False), (300, 96, True)):          # env blocks of 32 / 96: tiles that never straddle two learners
+                    (300, 96, False), (300, 96, True), (520, 64, False), (520, 64, True)):   # env blocks of 32 / 96 / 64: tiles never straddle two learners (64: 64-env tiles where the batch alone would take 128)
     n = L * E
     tab = S.tables.synthetic_table("train", 98)
     env = S.ShemsBatch(n, 72, [tab], [S.make_config(98, 0, tab.shape[0])]).use_torch_stream()
