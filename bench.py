@@ -142,6 +142,7 @@ def run_also(S, torch, which=None, prewarm_s=0.7, log=None):
                 rec["update_us"] = upd_us
             if spec["kind"] == "group":
                 rec["update_form"] = wl.group.form
+                rec["w2_layout"] = "tiled" if wl.group.tiled else "flux"
                 rec["replay_window_envs_per_step"] = wl.win
             out[name] = rec
         except Exception as e:                      # noqa: BLE001 -- the headline line must still be printed
