@@ -158,6 +158,8 @@ class LearnerGroup:
             self._tiled_valid = False
             return False
         if not self.tiled:
+            if not self._flux_valid:                   # (the flag was switched off on a group whose current layer-2 state is in the tiles)
+                raise RuntimeError("this group's Flux-order blocks are stale: call flux_() while it is still tiled")
             return False
         if not self._tiled_valid:
             d, g, t = self.learners[0]._ddpg_args(), self.struct(), self.w2t_struct()
