@@ -2,7 +2,7 @@
 #   gpurun --timeout 900 -- 'bash tools/profile_group.sh r05 base'
 # kernel-trace stats, MFMA-pipe counters and FETCH/WRITE passes of `bench.py --mode group --learners 400 --envs 51200 --mixed`.
 set -e
-# LEARNERS / ENVS (environment): another group shape (default 400 x 128 = 51200); KT_ONLY=1: kernel-trace stats only.
+# LEARNERS / ENVS (environment): another group shape (default 400 x 128 = 51200); GROUP_WINDOW=1: one remembered transition per update; KT_ONLY=1: kernel-trace stats only.
 TAG=${1:-r05}
 SUF=${2:-}
 LEARNERS=${LEARNERS:-400}
@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}_group${LEARNERS}${SUF:+_$SUF}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--mode group --learners $LEARNERS --envs $ENVS --mixed --no-cpu-baseline"
+B="--mode group --learners $LEARNERS --envs $ENVS --mixed --no-cpu-baseline ${GROUP_WINDOW:+--group-window $GROUP_WINDOW}"
 python3 $R/bench.py $B --steps 144 --warmup 16 > $O/${TAG}_group${LEARNERS}_bench.json 2> $O/bench.err
 echo bench-done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $B --steps 72 --warmup 8 --prewarm-s 0.5 > $O/kt.log 2>&1
